@@ -1,0 +1,185 @@
+/*
+ * nmvllm_hip.h -- C ABI of libnmvllm_hip.so: the MI355X (gfx950) hot path of nm-vllm 0.5.1.
+ *
+ * Every entry point replaces one native op the reference registers in
+ * csrc/torch_bindings.cpp (TORCH_LIBRARY _C / _C_cache_ops / _C_cuda_utils) and declares in
+ * csrc/ops.h / csrc/cache.h.  The signatures are plain C: raw device pointers, sizes, strides
+ * (in ELEMENTS unless noted), enums for dtypes and a hipStream_t passed as void*.  No torch
+ * types cross this boundary; the Python host layer (neural_magic_vllm_amd/_torch_bindings.py)
+ * re-creates the reference's torch.ops._C.* schemas on top of it.
+ *
+ * Conventions
+ *  - return value: 0 = NMV_OK, <0 = error; nmv_last_error() returns the message of the last
+ *    failing call on the calling thread (the analogue of TORCH_CHECK -> RuntimeError).
+ *  - all launches are asynchronous on `stream`, never synchronise, never allocate
+ *    (hipGraph-capturable), except nmv_swap_blocks which issues hipMemcpyAsync per block like
+ *    the reference (csrc/cache_kernels.cu:24-63).
+ *  - pointers marked `dev` are device memory; `host` is host memory.
+ */
+#ifndef NMVLLM_HIP_H_
+#define NMVLLM_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NMV_OK 0
+#define NMV_ERR_INVALID (-1) /* argument / shape / dtype check failed (TORCH_CHECK analogue) */
+#define NMV_ERR_HIP (-2)     /* HIP runtime reported an error at launch */
+#define NMV_ERR_UNSUPPORTED (-3)
+
+/* activation / model dtype (scalar_t in the reference) */
+typedef enum { NMV_F16 = 0, NMV_BF16 = 1, NMV_F32 = 2 } nmv_dtype_t;
+/* kv-cache dtype: "auto" or "fp8"/"fp8_e4m3" (csrc/quantization/fp8/nvidia/quant_utils.cuh:545-571);
+ * on gfx950 fp8 is OCP e4m3fn */
+typedef enum { NMV_KV_AUTO = 0, NMV_KV_FP8_E4M3 = 1 } nmv_kv_dtype_t;
+/* 8-bit operand type of nmv_scaled_mm */
+typedef enum { NMV_I8 = 0, NMV_FP8_E4M3 = 1 } nmv_q8_dtype_t;
+
+const char* nmv_last_error(void);
+/* ABI version, bumped on any signature change */
+int nmv_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * KV-cache ops  (reference: csrc/cache.h:8-32, csrc/cache_kernels.cu)
+ * ---------------------------------------------------------------------------------------- */
+
+/* reshape_and_cache  (csrc/cache_kernels.cu:253-278, kernel :152-204)
+ * key/value: [num_tokens, num_kv_heads, head_size] with token strides key_stride/value_stride.
+ * key_cache: [num_blocks, num_kv_heads, head_size/x, block_size, x], x = 16/sizeof(cache elem)
+ * value_cache: [num_blocks, num_kv_heads, head_size, block_size]
+ * slot_mapping: int64 [num_tokens]; slot < 0 = padding token, skipped. */
+int nmv_reshape_and_cache(const void* key, const void* value, void* key_cache, void* value_cache,
+                          const int64_t* slot_mapping, int num_tokens, int num_kv_heads,
+                          int head_size, int block_size, int64_t key_stride, int64_t value_stride,
+                          nmv_dtype_t dtype, nmv_kv_dtype_t kv_dtype, float kv_scale,
+                          void* stream);
+
+/* reshape_and_cache_flash  (csrc/cache_kernels.cu:280-316): caches are
+ * [num_blocks, block_size, num_kv_heads, head_size]; block_stride = cache.stride(0). */
+int nmv_reshape_and_cache_flash(const void* key, const void* value, void* key_cache,
+                                void* value_cache, const int64_t* slot_mapping, int num_tokens,
+                                int num_kv_heads, int head_size, int block_size,
+                                int64_t key_stride, int64_t value_stride, int64_t block_stride,
+                                nmv_dtype_t dtype, void* stream);
+
+/* copy_blocks  (csrc/cache_kernels.cu:101-148): key_cache_ptrs/value_cache_ptrs are DEVICE arrays
+ * of num_layers device pointers; block_mapping: dev int64 [num_pairs, 2] (src, dst);
+ * numel_per_block elements of elem_size bytes each. */
+int nmv_copy_blocks(void* const* key_cache_ptrs, void* const* value_cache_ptrs,
+                    const int64_t* block_mapping, int num_layers, int num_pairs,
+                    int64_t numel_per_block, int elem_size, void* stream);
+
+/* swap_blocks  (csrc/cache_kernels.cu:24-63): block_mapping is a HOST int64 [num_pairs, 2];
+ * kind: 0 = device->device, 1 = host->device, 2 = device->host. */
+int nmv_swap_blocks(const void* src, void* dst, const int64_t* block_mapping_host, int num_pairs,
+                    int64_t block_bytes, int kind, void* stream);
+
+/* convert_fp8  (csrc/cache_kernels.cu:339-389): dst/src are [num_blocks, block_stride];
+ * exactly one side is fp8 (uint8), the other `dtype`.  to_fp8 != 0: dst = fp8(src / scale);
+ * else dst = float(src) * scale. */
+int nmv_convert_fp8(void* dst, const void* src, int64_t num_blocks, int64_t block_stride,
+                    nmv_dtype_t dtype, int to_fp8, float scale, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Paged attention  (reference: csrc/ops.h:6-25, csrc/attention/attention_kernels.cu)
+ * ---------------------------------------------------------------------------------------- */
+
+/* paged_attention_v1  (attention_kernels.cu:805-826)
+ * out, query: [num_seqs, num_heads, head_size]; q_stride = query.stride(0); out is contiguous.
+ * block_tables: int32 [num_seqs, max_num_blocks_per_seq]; seq_lens: int32 [num_seqs].
+ * kv_block_stride = key_cache.stride(0), kv_head_stride = key_cache.stride(1).
+ * alibi_slopes: float [num_heads] or NULL. */
+int nmv_paged_attention_v1(void* out, const void* query, const void* key_cache,
+                           const void* value_cache, int num_seqs, int num_heads, int head_size,
+                           int num_kv_heads, float scale, const int32_t* block_tables,
+                           const int32_t* seq_lens, int block_size, int max_seq_len,
+                           int max_num_blocks_per_seq, const float* alibi_slopes,
+                           int64_t q_stride, int64_t kv_block_stride, int64_t kv_head_stride,
+                           nmv_dtype_t dtype, nmv_kv_dtype_t kv_dtype, float kv_scale,
+                           void* stream);
+
+/* paged_attention_v2  (attention_kernels.cu:966-990): partition size 512.
+ * exp_sums, max_logits: float [num_seqs, num_heads, max_num_partitions];
+ * tmp_out: [num_seqs, num_heads, max_num_partitions, head_size]. */
+int nmv_paged_attention_v2(void* out, float* exp_sums, float* max_logits, void* tmp_out,
+                           const void* query, const void* key_cache, const void* value_cache,
+                           int num_seqs, int num_heads, int head_size, int num_kv_heads,
+                           float scale, const int32_t* block_tables, const int32_t* seq_lens,
+                           int block_size, int max_seq_len, int max_num_blocks_per_seq,
+                           const float* alibi_slopes, int64_t q_stride, int64_t kv_block_stride,
+                           int64_t kv_head_stride, nmv_dtype_t dtype, nmv_kv_dtype_t kv_dtype,
+                           float kv_scale, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Glue ops so a whole decoder layer runs without the reference's csrc
+ * (csrc/layernorm_kernels.cu, csrc/pos_encoding_kernels.cu, csrc/activation_kernels.cu)
+ * ---------------------------------------------------------------------------------------- */
+
+/* rms_norm (layernorm_kernels.cu:22-44,292-313): out/input [num_tokens, hidden] contiguous */
+int nmv_rms_norm(void* out, const void* input, const void* weight, float epsilon, int num_tokens,
+                 int hidden_size, nmv_dtype_t dtype, void* stream);
+/* fused_add_rms_norm (layernorm_kernels.cu:201-290,315-352): in place on input and residual */
+int nmv_fused_add_rms_norm(void* input, void* residual, const void* weight, float epsilon,
+                           int num_tokens, int hidden_size, nmv_dtype_t dtype, void* stream);
+/* rotary_embedding (pos_encoding_kernels.cu:71-93,121-160): positions int64 [num_tokens];
+ * query [num_tokens, num_heads*head_size] (stride query_stride), key likewise;
+ * cos_sin_cache [max_position, rot_dim] in `dtype`. In place. */
+int nmv_rotary_embedding(const int64_t* positions, void* query, void* key, int num_tokens,
+                         int num_heads, int num_kv_heads, int head_size, int rot_dim,
+                         int64_t query_stride, int64_t key_stride, const void* cos_sin_cache,
+                         int is_neox, nmv_dtype_t dtype, void* stream);
+/* batched_rotary_embedding (pos_encoding_kernels.cu:95-119,162-203):
+ * cos_sin_cache_offsets int64 [num_tokens] added to the position before the cache lookup */
+int nmv_batched_rotary_embedding(const int64_t* positions, void* query, void* key, int num_tokens,
+                                 int num_heads, int num_kv_heads, int head_size, int rot_dim,
+                                 int64_t query_stride, int64_t key_stride,
+                                 const void* cos_sin_cache, int is_neox,
+                                 const int64_t* cos_sin_cache_offsets, nmv_dtype_t dtype,
+                                 void* stream);
+/* act_and_mul family (activation_kernels.cu:14-26,63-90): input [num_tokens, 2*d] -> out [.., d].
+ * act: 0 silu_and_mul, 1 gelu_and_mul (erf), 2 gelu_tanh_and_mul */
+int nmv_act_and_mul(void* out, const void* input, int num_tokens, int d, int act,
+                    nmv_dtype_t dtype, void* stream);
+/* element-wise activations (activation_kernels.cu:96-162): act: 0 gelu_new, 1 gelu_fast,
+ * 2 gelu_quick; input/out [num_tokens, d] */
+int nmv_activation(void* out, const void* input, int num_tokens, int d, int act,
+                   nmv_dtype_t dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * W4A16 / W8A16 (GPTQ-Marlin format)  (csrc/ops.h:86-94, csrc/quantization/gptq_marlin/)
+ * ---------------------------------------------------------------------------------------- */
+
+/* gptq_marlin_repack  (gptq_marlin_repack.cu:267-348): GPTQ qweight int32 [size_k/pack, size_n]
+ * -> Marlin int32 [size_k/16, size_n*16/pack]; perm: int32 [size_k] or NULL (act-order). */
+int nmv_gptq_marlin_repack(const int32_t* b_q_weight, const int32_t* perm, int32_t* out,
+                           int size_k, int size_n, int num_bits, void* stream);
+
+/* bytes of scratch nmv_gptq_marlin_gemm needs for (size_m, size_n, size_k): fp32 split-K slabs
+ * plus, with act-order, the permuted copy of A (gptq_marlin.cu:1783-1785 allocates the latter) */
+int64_t nmv_gptq_marlin_gemm_scratch_bytes(int size_m, int size_n, int size_k, int has_act_order);
+
+/* gptq_marlin_gemm  (gptq_marlin.cu:1735-1868)
+ * c[size_m,size_n] = a[size_m,size_k] @ dequant(b_q_weight) ; a, c, b_scales in `dtype`.
+ * b_q_weight: Marlin int32 [size_k/16, size_n*16/pack]; b_scales: [num_groups, size_n]
+ * (marlin_permute_scales layout, gptq_marlin.py:47-56); g_idx/perm: int32 [size_k] or NULL;
+ * workspace: int32 [>= size_n/64*16], zero on entry, zero on exit (split-K tickets);
+ * scratch: >= nmv_gptq_marlin_gemm_scratch_bytes(). */
+int nmv_gptq_marlin_gemm(void* c, const void* a, const int32_t* b_q_weight, const void* b_scales,
+                         const int32_t* g_idx, const int32_t* perm, int32_t* workspace,
+                         int64_t workspace_len, void* scratch, int64_t scratch_bytes,
+                         int num_bits, int size_m, int size_n, int size_k, int num_groups,
+                         int is_k_full, nmv_dtype_t dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * device attributes (csrc/cuda_utils.h:3-5, csrc/cuda_utils_kernels.cu)
+ * ---------------------------------------------------------------------------------------- */
+int64_t nmv_get_device_attribute(int64_t attribute, int64_t device_id);
+int64_t nmv_get_max_shared_memory_per_block_device_attribute(int64_t device_id);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NMVLLM_HIP_H_ */

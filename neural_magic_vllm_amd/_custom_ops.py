@@ -1,0 +1,179 @@
+"""Drop-in for `vllm._custom_ops` (reference: vllm/_custom_ops.py:49-467).
+
+Same function names, argument order and return conventions; every call goes through
+torch.ops._C / _C_cache_ops / _C_cuda_utils, which neural_magic_vllm_amd/_torch_bindings.py
+registers on top of libnmvllm_hip.so.  Ops the reference exposes but that are outside the hot
+path (aqlm, squeezellm, marlin 2:4, moe, punica, custom all-reduce) are
+not defined here.
+"""
+from typing import List, Optional, Tuple, Type
+
+import torch
+
+from . import _torch_bindings
+
+_torch_bindings.register()
+
+
+def is_custom_op_supported(op_name: str) -> bool:
+    op, overloads = torch._C._jit_get_operation(op_name)
+    return op is not None
+
+
+# activation ops
+def silu_and_mul(out: torch.Tensor, x: torch.Tensor) -> None:
+    torch.ops._C.silu_and_mul(out, x)
+
+
+def gelu_and_mul(out: torch.Tensor, x: torch.Tensor) -> None:
+    torch.ops._C.gelu_and_mul(out, x)
+
+
+def gelu_tanh_and_mul(out: torch.Tensor, x: torch.Tensor) -> None:
+    torch.ops._C.gelu_tanh_and_mul(out, x)
+
+
+def gelu_fast(out: torch.Tensor, x: torch.Tensor) -> None:
+    torch.ops._C.gelu_fast(out, x)
+
+
+def gelu_new(out: torch.Tensor, x: torch.Tensor) -> None:
+    torch.ops._C.gelu_new(out, x)
+
+
+def gelu_quick(out: torch.Tensor, x: torch.Tensor) -> None:
+    torch.ops._C.gelu_quick(out, x)
+
+
+# page attention ops
+def paged_attention_v1(
+    out: torch.Tensor,
+    query: torch.Tensor,
+    key_cache: torch.Tensor,
+    value_cache: torch.Tensor,
+    num_kv_heads: int,
+    scale: float,
+    block_tables: torch.Tensor,
+    seq_lens: torch.Tensor,
+    block_size: int,
+    max_seq_len: int,
+    alibi_slopes: Optional[torch.Tensor],
+    kv_cache_dtype: str,
+    kv_scale: float,
+    tp_rank: int = 0,
+    blocksparse_local_blocks: int = 0,
+    blocksparse_vert_stride: int = 0,
+    blocksparse_block_size: int = 64,
+    blocksparse_head_sliding_step: int = 0,
+) -> None:
+    torch.ops._C.paged_attention_v1(out, query, key_cache, value_cache, num_kv_heads, scale,
+                                    block_tables, seq_lens, block_size, max_seq_len,
+                                    alibi_slopes, kv_cache_dtype, kv_scale, tp_rank,
+                                    blocksparse_local_blocks, blocksparse_vert_stride,
+                                    blocksparse_block_size, blocksparse_head_sliding_step)
+
+
+def paged_attention_v2(
+    out: torch.Tensor,
+    exp_sum: torch.Tensor,
+    max_logits: torch.Tensor,
+    tmp_out: torch.Tensor,
+    query: torch.Tensor,
+    key_cache: torch.Tensor,
+    value_cache: torch.Tensor,
+    num_kv_heads: int,
+    scale: float,
+    block_tables: torch.Tensor,
+    seq_lens: torch.Tensor,
+    block_size: int,
+    max_seq_len: int,
+    alibi_slopes: Optional[torch.Tensor],
+    kv_cache_dtype: str,
+    kv_scale: float,
+    tp_rank: int = 0,
+    blocksparse_local_blocks: int = 0,
+    blocksparse_vert_stride: int = 0,
+    blocksparse_block_size: int = 64,
+    blocksparse_head_sliding_step: int = 0,
+) -> None:
+    torch.ops._C.paged_attention_v2(out, exp_sum, max_logits, tmp_out, query, key_cache,
+                                    value_cache, num_kv_heads, scale, block_tables, seq_lens,
+                                    block_size, max_seq_len, alibi_slopes, kv_cache_dtype,
+                                    kv_scale, tp_rank, blocksparse_local_blocks,
+                                    blocksparse_vert_stride, blocksparse_block_size,
+                                    blocksparse_head_sliding_step)
+
+
+# pos encoding ops
+def rotary_embedding(positions: torch.Tensor, query: torch.Tensor, key: torch.Tensor,
+                     head_size: int, cos_sin_cache: torch.Tensor, is_neox: bool) -> None:
+    torch.ops._C.rotary_embedding(positions, query, key, head_size, cos_sin_cache, is_neox)
+
+
+def batched_rotary_embedding(positions: torch.Tensor, query: torch.Tensor, key: torch.Tensor,
+                             head_size: int, cos_sin_cache: torch.Tensor, is_neox: bool,
+                             rot_dim: int, cos_sin_cache_offsets: torch.Tensor) -> None:
+    torch.ops._C.batched_rotary_embedding(positions, query, key, head_size, cos_sin_cache,
+                                          is_neox, rot_dim, cos_sin_cache_offsets)
+
+
+# layer norm ops
+def rms_norm(out: torch.Tensor, input: torch.Tensor, weight: torch.Tensor,
+             epsilon: float) -> None:
+    torch.ops._C.rms_norm(out, input, weight, epsilon)
+
+
+def fused_add_rms_norm(input: torch.Tensor, residual: torch.Tensor, weight: torch.Tensor,
+                       epsilon: float) -> None:
+    torch.ops._C.fused_add_rms_norm(input, residual, weight, epsilon)
+
+
+# gptq_marlin
+def gptq_marlin_repack(b_q_weight: torch.Tensor, perm: torch.Tensor, size_k: int, size_n: int,
+                       num_bits: int) -> torch.Tensor:
+    return torch.ops._C.gptq_marlin_repack(b_q_weight, perm, size_k, size_n, num_bits)
+
+
+def gptq_marlin_gemm(a: torch.Tensor, b_q_weight: torch.Tensor, b_scales: torch.Tensor,
+                     g_idx: torch.Tensor, perm: torch.Tensor, workspace: torch.Tensor,
+                     num_bits: int, size_m: int, size_n: int, size_k: int,
+                     is_k_full: bool) -> torch.Tensor:
+    return torch.ops._C.gptq_marlin_gemm(a, b_q_weight, b_scales, g_idx, perm, workspace,
+                                         num_bits, size_m, size_n, size_k, is_k_full)
+
+
+# cache ops
+def reshape_and_cache(key: torch.Tensor, value: torch.Tensor, key_cache: torch.Tensor,
+                      value_cache: torch.Tensor, slot_mapping: torch.Tensor,
+                      kv_cache_dtype: str, kv_scale: float) -> None:
+    torch.ops._C_cache_ops.reshape_and_cache(key, value, key_cache, value_cache, slot_mapping,
+                                             kv_cache_dtype, kv_scale)
+
+
+def reshape_and_cache_flash(key: torch.Tensor, value: torch.Tensor, key_cache: torch.Tensor,
+                            value_cache: torch.Tensor, slot_mapping: torch.Tensor,
+                            kv_cache_dtype: str) -> None:
+    torch.ops._C_cache_ops.reshape_and_cache_flash(key, value, key_cache, value_cache,
+                                                   slot_mapping, kv_cache_dtype)
+
+
+def copy_blocks(key_caches: List[torch.Tensor], value_caches: List[torch.Tensor],
+                block_mapping: torch.Tensor) -> None:
+    torch.ops._C_cache_ops.copy_blocks(key_caches, value_caches, block_mapping)
+
+
+def swap_blocks(src: torch.Tensor, dst: torch.Tensor, block_mapping: torch.Tensor) -> None:
+    torch.ops._C_cache_ops.swap_blocks(src, dst, block_mapping)
+
+
+def convert_fp8(output: torch.Tensor, input: torch.Tensor, scale: float = 1.0,
+                kv_dtype: str = "fp8") -> None:
+    torch.ops._C_cache_ops.convert_fp8(output, input, scale, kv_dtype)
+
+
+def get_device_attribute(attribute: int, device: int) -> int:
+    return torch.ops._C_cuda_utils.get_device_attribute(attribute, device)
+
+
+def get_max_shared_memory_per_block_device_attribute(device: int) -> int:
+    return torch.ops._C_cuda_utils.get_max_shared_memory_per_block_device_attribute(device)

@@ -1,0 +1,429 @@
+"""torch.ops._C / _C_cache_ops / _C_cuda_utils registered on top of the C ABI.
+
+The reference registers its native ops from C++ (csrc/torch_bindings.cpp:18-259,
+`TORCH_LIBRARY_EXPAND(TORCH_EXTENSION_NAME, ops)`).  This module is the drop-in for that file:
+the SAME namespaces, op names and schema strings, dispatch key CUDA (HIP tensors carry the CUDA
+key on PyTorch-ROCm), but each impl unwraps the tensors to raw pointers / sizes / strides and
+calls libnmvllm_hip.so (include/nmvllm_hip.h) on the current HIP stream.  Importing it plays
+the role of `import vllm._C`.
+
+Only dispatch key CUDA gets an impl: calling any of these ops with CPU tensors raises
+NotImplementedError from the dispatcher -- there is deliberately no CPU path in the product.
+"""
+from typing import List, Optional
+
+import torch
+
+from . import _lib
+from ._lib import check, device_guard, dtype_code, kv_dtype_code, ptr, stream_of
+
+_libs = []  # keep torch.library.Library objects alive
+_registered = False
+
+
+def _req(cond: bool, msg: str) -> None:
+    if not cond:
+        raise _lib.NmvError(msg)
+
+
+# ----------------------------------------------------------------------------- attention
+def _pa_common(query, key_cache, value_cache, block_tables, seq_lens, blocksparse_vert_stride):
+    _req(blocksparse_vert_stride <= 1,
+         "blocksparse paged attention (blocksparse_vert_stride > 1) is out of scope on gfx950")
+    _req(block_tables.dtype == torch.int32 and seq_lens.dtype == torch.int32,
+         "block_tables and seq_lens must be int32")
+    _req(query.stride(-1) == 1 and query.stride(1) == query.shape[2],
+         "query must be [num_seqs, num_heads, head_size] with contiguous heads")
+    _req(key_cache.is_contiguous() or key_cache.stride(-1) == 1, "key_cache layout")
+
+
+def paged_attention_v1(out, query, key_cache, value_cache, num_kv_heads, scale, block_tables,
+                       seq_lens, block_size, max_seq_len, alibi_slopes, kv_cache_dtype, kv_scale,
+                       tp_rank, blocksparse_local_blocks, blocksparse_vert_stride,
+                       blocksparse_block_size, blocksparse_head_sliding_step) -> None:
+    """csrc/attention/attention_kernels.cu:805-826"""
+    _pa_common(query, key_cache, value_cache, block_tables, seq_lens, blocksparse_vert_stride)
+    num_seqs, num_heads, head_size = query.shape
+    _req(out.is_contiguous(), "out must be contiguous")
+    L = _lib.load()
+    with device_guard(query):
+        check(L.nmv_paged_attention_v1(
+            ptr(out), ptr(query), ptr(key_cache), ptr(value_cache), num_seqs, num_heads,
+            head_size, num_kv_heads, scale, ptr(block_tables), ptr(seq_lens), block_size,
+            max_seq_len, block_tables.shape[1], ptr(alibi_slopes), query.stride(0),
+            key_cache.stride(0), key_cache.stride(1), dtype_code(query.dtype),
+            kv_dtype_code(kv_cache_dtype), kv_scale, stream_of(query)))
+
+
+def paged_attention_v2(out, exp_sums, max_logits, tmp_out, query, key_cache, value_cache,
+                       num_kv_heads, scale, block_tables, seq_lens, block_size, max_seq_len,
+                       alibi_slopes, kv_cache_dtype, kv_scale, tp_rank, blocksparse_local_blocks,
+                       blocksparse_vert_stride, blocksparse_block_size,
+                       blocksparse_head_sliding_step) -> None:
+    """csrc/attention/attention_kernels.cu:966-990"""
+    _pa_common(query, key_cache, value_cache, block_tables, seq_lens, blocksparse_vert_stride)
+    num_seqs, num_heads, head_size = query.shape
+    _req(out.is_contiguous() and tmp_out.is_contiguous() and exp_sums.is_contiguous()
+         and max_logits.is_contiguous(), "out/tmp_out/exp_sums/max_logits must be contiguous")
+    max_parts = (max_seq_len + 511) // 512
+    _req(exp_sums.shape[-1] >= max_parts and tmp_out.shape[2] >= max_parts,
+         "partition buffers too small for max_seq_len")
+    _req(exp_sums.shape[-1] == max_parts and tmp_out.shape[2] == max_parts,
+         "partition buffers must be sized ceil(max_seq_len / 512)")
+    L = _lib.load()
+    with device_guard(query):
+        check(L.nmv_paged_attention_v2(
+            ptr(out), ptr(exp_sums), ptr(max_logits), ptr(tmp_out), ptr(query), ptr(key_cache),
+            ptr(value_cache), num_seqs, num_heads, head_size, num_kv_heads, scale,
+            ptr(block_tables), ptr(seq_lens), block_size, max_seq_len, block_tables.shape[1],
+            ptr(alibi_slopes), query.stride(0), key_cache.stride(0), key_cache.stride(1),
+            dtype_code(query.dtype), kv_dtype_code(kv_cache_dtype), kv_scale, stream_of(query)))
+
+
+# ----------------------------------------------------------------------------- glue
+def _rows(t: torch.Tensor) -> int:
+    return t.numel() // t.shape[-1] if t.numel() else 0
+
+
+def rms_norm(out, input, weight, epsilon) -> None:
+    """csrc/layernorm_kernels.cu:292-313"""
+    _req(input.is_contiguous() and out.is_contiguous(), "rms_norm: tensors must be contiguous")
+    with device_guard(input):
+        check(_lib.load().nmv_rms_norm(ptr(out), ptr(input), ptr(weight), epsilon, _rows(input),
+                                       input.shape[-1], dtype_code(input.dtype),
+                                       stream_of(input)))
+
+
+def fused_add_rms_norm(input, residual, weight, epsilon) -> None:
+    """csrc/layernorm_kernels.cu:315-352"""
+    _req(input.is_contiguous() and residual.is_contiguous(),
+         "fused_add_rms_norm: tensors must be contiguous")
+    with device_guard(input):
+        check(_lib.load().nmv_fused_add_rms_norm(ptr(input), ptr(residual), ptr(weight), epsilon,
+                                                 _rows(input), input.shape[-1],
+                                                 dtype_code(input.dtype), stream_of(input)))
+
+
+def _rope_args(positions, query, key, head_size, cos_sin_cache):
+    num_tokens = query.numel() // query.shape[-1]
+    _req(positions.dtype == torch.int64, "positions must be int64")
+    _req(positions.numel() == num_tokens, "positions / query token count mismatch")
+    rot_dim = cos_sin_cache.shape[1]
+    num_heads = query.shape[-1] // head_size
+    num_kv_heads = key.shape[-1] // head_size
+    return num_tokens, rot_dim, num_heads, num_kv_heads, query.stride(-2), key.stride(-2)
+
+
+def rotary_embedding(positions, query, key, head_size, cos_sin_cache, is_neox) -> None:
+    """csrc/pos_encoding_kernels.cu:121-160"""
+    nt, rot, nh, nkv, qs, ks = _rope_args(positions, query, key, head_size, cos_sin_cache)
+    _req(cos_sin_cache.dtype == query.dtype, "cos_sin_cache dtype must match query")
+    with device_guard(query):
+        check(_lib.load().nmv_rotary_embedding(
+            ptr(positions), ptr(query), ptr(key), nt, nh, nkv, head_size, rot, qs, ks,
+            ptr(cos_sin_cache), int(is_neox), dtype_code(query.dtype), stream_of(query)))
+
+
+def batched_rotary_embedding(positions, query, key, head_size, cos_sin_cache, is_neox, rot_dim,
+                             cos_sin_cache_offsets) -> None:
+    """csrc/pos_encoding_kernels.cu:162-203"""
+    nt, _, nh, nkv, qs, ks = _rope_args(positions, query, key, head_size, cos_sin_cache)
+    _req(cos_sin_cache_offsets.dtype == torch.int64, "cos_sin_cache_offsets must be int64")
+    with device_guard(query):
+        check(_lib.load().nmv_batched_rotary_embedding(
+            ptr(positions), ptr(query), ptr(key), nt, nh, nkv, head_size, rot_dim, qs, ks,
+            ptr(cos_sin_cache), int(is_neox), ptr(cos_sin_cache_offsets),
+            dtype_code(query.dtype), stream_of(query)))
+
+
+def _act_and_mul(act: int):
+
+    def fn(out, input) -> None:
+        d = input.shape[-1] // 2
+        _req(input.is_contiguous() and out.is_contiguous(), "act_and_mul: contiguous tensors")
+        with device_guard(input):
+            check(_lib.load().nmv_act_and_mul(ptr(out), ptr(input), _rows(input), d, act,
+                                              dtype_code(input.dtype), stream_of(input)))
+
+    return fn
+
+
+def _activation(act: int):
+
+    def fn(out, input) -> None:
+        _req(input.is_contiguous() and out.is_contiguous(), "activation: contiguous tensors")
+        with device_guard(input):
+            check(_lib.load().nmv_activation(ptr(out), ptr(input), _rows(input), input.shape[-1],
+                                             act, dtype_code(input.dtype), stream_of(input)))
+
+    return fn
+
+
+# ----------------------------------------------------------------------------- W4A16
+def gptq_marlin_repack(b_q_weight, perm, size_k, size_n, num_bits) -> torch.Tensor:
+    """csrc/quantization/gptq_marlin/gptq_marlin_repack.cu:267-348"""
+    _req(num_bits in (4, 8), f"num_bits must be 4 or 8. Got = {num_bits}")
+    pack = 32 // num_bits
+    _req(size_k % 16 == 0, f"size_k = {size_k} is not divisible by tile_k_size = 16")
+    _req(size_n % 64 == 0, f"size_n = {size_n} is not divisible by tile_n_size = 64")
+    _req(tuple(b_q_weight.shape) == (size_k // pack, size_n),
+         f"Shape mismatch: b_q_weight {tuple(b_q_weight.shape)} vs "
+         f"{(size_k // pack, size_n)}")
+    _req(b_q_weight.is_contiguous() and b_q_weight.dtype == torch.int32,
+         "b_q_weight must be contiguous int32")
+    has_perm = perm.numel() != 0
+    if has_perm:
+        _req(perm.dtype == torch.int32 and perm.numel() == size_k and perm.is_contiguous(),
+             "perm must be contiguous int32 [size_k]")
+    out = torch.empty((size_k // 16, size_n * 16 // pack), dtype=torch.int32,
+                      device=b_q_weight.device)
+    with device_guard(b_q_weight):
+        check(_lib.load().nmv_gptq_marlin_repack(ptr(b_q_weight), ptr(perm) if has_perm else None,
+                                                 ptr(out), size_k, size_n, num_bits,
+                                                 stream_of(b_q_weight)))
+    return out
+
+
+def gptq_marlin_gemm(a, b_q_weight, b_scales, g_idx, perm, workspace, num_bits, size_m, size_n,
+                     size_k, is_k_full) -> torch.Tensor:
+    """csrc/quantization/gptq_marlin/gptq_marlin.cu:1735-1868 (same argument checks)"""
+    _req(num_bits in (4, 8), f"num_bits must be 4 or 8. Got = {num_bits}")
+    pack = 32 // num_bits
+    _req(a.shape[0] == size_m, f"Shape mismatch: a.size(0) = {a.shape[0]}, size_m = {size_m}")
+    _req(a.shape[1] == size_k, f"Shape mismatch: a.size(1) = {a.shape[1]}, size_k = {size_k}")
+    _req(size_k % 16 == 0, f"size_k = {size_k} is not divisible by tile_size = 16")
+    _req(b_q_weight.shape[0] == size_k // 16,
+         f"Shape mismatch: b_q_weight.size(0) = {b_q_weight.shape[0]}, size_k = {size_k}")
+    _req(b_q_weight.shape[1] % 16 == 0, "b_q_weight.size(1) is not divisible by tile_size = 16")
+    _req(b_q_weight.shape[1] // 16 * pack == size_n,
+         f"size_n = {size_n}, actual_size_n = {b_q_weight.shape[1] // 16 * pack}")
+    _req(a.is_contiguous(), "A is not contiguous")
+    _req(b_q_weight.is_contiguous() and b_q_weight.dtype == torch.int32,
+         "b_q_weight must be contiguous int32")
+    _req(b_scales.is_contiguous() and b_scales.dtype == a.dtype,
+         "b_scales must be contiguous and of A's dtype")
+    _req(a.dtype in (torch.float16, torch.bfloat16), "gpt_marlin_gemm only supports bfloat16 and float16")
+    _req(size_n % 64 == 0, f"size_n = {size_n} is not divisible by min_thread_n = 64")
+    _req(workspace.dtype == torch.int32 and workspace.is_contiguous(), "workspace must be int32")
+    _req(workspace.numel() >= size_n // 64 * 16,
+         f"workspace.numel = {workspace.numel()} is below min_workspace_size = {size_n // 64 * 16}")
+    has_act_order = g_idx.numel() != 0 and perm.numel() != 0
+    if has_act_order:
+        _req(g_idx.numel() == size_k and perm.numel() == size_k,
+             "Unexpected g_idx.size / perm.size")
+        _req(g_idx.dtype == torch.int32 and perm.dtype == torch.int32, "g_idx/perm must be int32")
+    else:
+        _req(g_idx.numel() == 0 and perm.numel() == 0,
+             "g_idx and perm must both be empty or both be set")
+    num_groups = b_scales.shape[0]
+    _req(b_scales.shape[1] == size_n, "b_scales dim 1 != size_n")
+    if has_act_order:
+        if is_k_full:
+            _req(num_groups > 1, "For act_order, num_groups must be > 1")
+            _req(size_k % num_groups == 0, f"size_k = {size_k}, is not divisible by num_groups")
+    elif num_groups > 1:
+        _req(size_k % num_groups == 0, f"size_k = {size_k}, is not divisible by num_groups")
+        _req(size_k // num_groups in (32, 64, 128), "group_size must be 32, 64 or 128")
+    c = torch.empty((size_m, size_n), dtype=a.dtype, device=a.device)
+    if size_m == 0:
+        return c
+    L = _lib.load()
+    nbytes = L.nmv_gptq_marlin_gemm_scratch_bytes(size_m, size_n, size_k, int(has_act_order))
+    scratch = torch.empty((max(nbytes, 16), ), dtype=torch.uint8, device=a.device)
+    with device_guard(a):
+        check(L.nmv_gptq_marlin_gemm(
+            ptr(c), ptr(a), ptr(b_q_weight), ptr(b_scales),
+            ptr(g_idx) if has_act_order else None, ptr(perm) if has_act_order else None,
+            ptr(workspace), workspace.numel(), ptr(scratch), scratch.numel(), num_bits, size_m,
+            size_n, size_k, num_groups, int(is_k_full), dtype_code(a.dtype), stream_of(a)))
+    return c
+
+
+# ----------------------------------------------------------------------------- cache ops
+def reshape_and_cache(key, value, key_cache, value_cache, slot_mapping, kv_cache_dtype,
+                      kv_scale) -> None:
+    """csrc/cache_kernels.cu:253-278"""
+    num_tokens, num_heads, head_size = key.shape
+    block_size = key_cache.shape[3]
+    _req(slot_mapping.dtype == torch.int64, "slot_mapping must be int64")
+    _req(key.stride(-1) == 1 and key.stride(1) == head_size and value.stride(-1) == 1
+         and value.stride(1) == head_size, "key/value heads must be contiguous")
+    _req(key_cache.is_contiguous() and value_cache.is_contiguous(), "caches must be contiguous")
+    with device_guard(key):
+        check(_lib.load().nmv_reshape_and_cache(
+            ptr(key), ptr(value), ptr(key_cache), ptr(value_cache), ptr(slot_mapping),
+            slot_mapping.numel(), num_heads, head_size, block_size, key.stride(0),
+            value.stride(0), dtype_code(key.dtype), kv_dtype_code(kv_cache_dtype), kv_scale,
+            stream_of(key)))
+
+
+def reshape_and_cache_flash(key, value, key_cache, value_cache, slot_mapping,
+                            kv_cache_dtype) -> None:
+    """csrc/cache_kernels.cu:280-316"""
+    _req(kv_cache_dtype == "auto", "FlashAttention does not support FP8 kv-cache")
+    num_tokens, num_heads, head_size = key.shape
+    block_size = key_cache.shape[1]
+    _req(key_cache.stride(0) == value_cache.stride(0), "k/v cache block strides differ")
+    with device_guard(key):
+        check(_lib.load().nmv_reshape_and_cache_flash(
+            ptr(key), ptr(value), ptr(key_cache), ptr(value_cache), ptr(slot_mapping),
+            slot_mapping.numel(), num_heads, head_size, block_size, key.stride(0),
+            value.stride(0), key_cache.stride(0), dtype_code(key.dtype), stream_of(key)))
+
+
+def copy_blocks(key_caches: List[torch.Tensor], value_caches: List[torch.Tensor],
+                block_mapping: torch.Tensor) -> None:
+    """csrc/cache_kernels.cu:101-148 (the pointer tables are built on the host and copied)"""
+    num_layers = len(key_caches)
+    _req(num_layers == len(value_caches), "key_caches / value_caches length mismatch")
+    if num_layers == 0:
+        return
+    dev = key_caches[0].device
+    _req(dev.type == "cuda", "copy_blocks: caches must be on the GPU")
+    kptrs = torch.tensor([t.data_ptr() for t in key_caches], dtype=torch.int64).to(dev)
+    vptrs = torch.tensor([t.data_ptr() for t in value_caches], dtype=torch.int64).to(dev)
+    _req(block_mapping.dtype == torch.int64, "block_mapping must be int64")
+    bm = block_mapping.to(dev).contiguous()
+    numel_per_block = key_caches[0][0].numel()
+    with device_guard(key_caches[0]):
+        check(_lib.load().nmv_copy_blocks(ptr(kptrs), ptr(vptrs), ptr(bm), num_layers,
+                                          bm.shape[0], numel_per_block,
+                                          key_caches[0].element_size(),
+                                          stream_of(key_caches[0])))
+
+
+def swap_blocks(src: torch.Tensor, dst: torch.Tensor, block_mapping: torch.Tensor) -> None:
+    """csrc/cache_kernels.cu:24-63"""
+    if src.device.type == "cuda" and dst.device.type == "cuda":
+        _req(src.device.index == dst.device.index, "src and dst must be on the same GPU")
+        kind = 0
+    elif src.device.type == "cuda" and dst.device.type == "cpu":
+        kind = 2
+    elif src.device.type == "cpu" and dst.device.type == "cuda":
+        kind = 1
+    else:
+        raise _lib.NmvError("Invalid device combination")
+    _req(block_mapping.device.type == "cpu", "block_mapping must be on CPU")
+    bm = block_mapping.to(torch.int64).contiguous()
+    block_bytes = src.element_size() * src[0].numel()
+    gpu_t = src if src.device.type == "cuda" else dst
+    with device_guard(gpu_t):
+        check(_lib.load().nmv_swap_blocks(ptr(src), ptr(dst), ptr(bm), bm.shape[0], block_bytes,
+                                          kind, stream_of(gpu_t)))
+
+
+def convert_fp8(dst_cache, src_cache, scale, kv_cache_dtype) -> None:
+    """csrc/cache_kernels.cu:339-389"""
+    _req(kv_cache_dtype in ("auto", "fp8", "fp8_e4m3"),
+         f"Unsupported data type: {kv_cache_dtype}")
+    _req(src_cache.device == dst_cache.device and src_cache.device.type == "cuda",
+         "src and dst must be on the same GPU")
+    num_blocks = src_cache.shape[0]
+    block_stride = src_cache.stride(0)
+    if dst_cache.dtype == torch.uint8:
+        to_fp8, dt = 1, src_cache.dtype
+    else:
+        _req(src_cache.dtype == torch.uint8, "one of src/dst must be uint8 (fp8 storage)")
+        to_fp8, dt = 0, dst_cache.dtype
+    with device_guard(src_cache):
+        check(_lib.load().nmv_convert_fp8(ptr(dst_cache), ptr(src_cache), num_blocks,
+                                          block_stride, dtype_code(dt), to_fp8, scale,
+                                          stream_of(src_cache)))
+
+
+# ----------------------------------------------------------------------------- cuda utils
+def get_device_attribute(attribute: int, device_id: int) -> int:
+    v = _lib.load().nmv_get_device_attribute(attribute, device_id)
+    check(0 if v >= 0 else -1, "get_device_attribute")
+    return v
+
+
+def get_max_shared_memory_per_block_device_attribute(device_id: int) -> int:
+    v = _lib.load().nmv_get_max_shared_memory_per_block_device_attribute(device_id)
+    check(0 if v >= 0 else -1, "get_max_shared_memory_per_block_device_attribute")
+    return v
+
+
+# ----------------------------------------------------------------------------- registration
+_PA_TAIL = ("Tensor value_cache, int num_kv_heads, float scale, Tensor block_tables, "
+            "Tensor seq_lens, int block_size, int max_seq_len, Tensor? alibi_slopes, "
+            "str kv_cache_dtype, float kv_scale, int tp_rank, int blocksparse_local_blocks, "
+            "int blocksparse_vert_stride, int blocksparse_block_size, "
+            "int blocksparse_head_sliding_step) -> ()")
+
+# (schema, impl, dispatch key) -- schema strings follow csrc/torch_bindings.cpp line by line
+_C_OPS = [
+    ("paged_attention_v1(Tensor! out, Tensor query, Tensor key_cache, " + _PA_TAIL,
+     paged_attention_v1),
+    ("paged_attention_v2(Tensor! out, Tensor exp_sums, Tensor max_logits, Tensor tmp_out, "
+     "Tensor query, Tensor key_cache, " + _PA_TAIL, paged_attention_v2),
+    ("silu_and_mul(Tensor! out, Tensor input) -> ()", _act_and_mul(0)),
+    ("gelu_and_mul(Tensor! out, Tensor input) -> ()", _act_and_mul(1)),
+    ("gelu_tanh_and_mul(Tensor! out, Tensor input) -> ()", _act_and_mul(2)),
+    ("gelu_new(Tensor! out, Tensor input) -> ()", _activation(0)),
+    ("gelu_fast(Tensor! out, Tensor input) -> ()", _activation(1)),
+    ("gelu_quick(Tensor! out, Tensor input) -> ()", _activation(2)),
+    ("rms_norm(Tensor! out, Tensor input, Tensor weight, float epsilon) -> ()", rms_norm),
+    ("fused_add_rms_norm(Tensor! input, Tensor! residual, Tensor weight, float epsilon) -> ()",
+     fused_add_rms_norm),
+    ("rotary_embedding(Tensor positions, Tensor! query, Tensor! key, int head_size, "
+     "Tensor cos_sin_cache, bool is_neox) -> ()", rotary_embedding),
+    ("batched_rotary_embedding(Tensor positions, Tensor! query, Tensor! key, int head_size, "
+     "Tensor cos_sin_cache, bool is_neox, int rot_dim, Tensor cos_sin_cache_offsets) -> ()",
+     batched_rotary_embedding),
+    ("gptq_marlin_repack(Tensor b_q_weight, Tensor perm, int size_k, int size_n, int num_bits) "
+     "-> Tensor", gptq_marlin_repack),
+    ("gptq_marlin_gemm(Tensor a, Tensor b_q_weight, Tensor b_scales, Tensor g_idx, Tensor perm, "
+     "Tensor workspace, int num_bits, int size_m, int size_n, int size_k, bool is_k_full) "
+     "-> Tensor", gptq_marlin_gemm),
+]
+
+_CACHE_OPS = [
+    ("swap_blocks(Tensor src, Tensor! dst, Tensor block_mapping) -> ()", swap_blocks),
+    ("copy_blocks(Tensor[]! key_caches, Tensor[]! value_caches, Tensor block_mapping) -> ()",
+     copy_blocks),
+    ("reshape_and_cache(Tensor key, Tensor value, Tensor! key_cache, Tensor! value_cache, "
+     "Tensor slot_mapping, str kv_cache_dtype, float kv_scale) -> ()", reshape_and_cache),
+    ("reshape_and_cache_flash(Tensor key, Tensor value, Tensor! key_cache, "
+     "Tensor! value_cache, Tensor slot_mapping, str kv_cache_dtype) -> ()",
+     reshape_and_cache_flash),
+    ("convert_fp8(Tensor! dst_cache, Tensor src_cache, float scale, str kv_cache_dtype) -> ()",
+     convert_fp8),
+]
+
+_UTIL_OPS = [
+    ("get_device_attribute(int attribute, int device_id) -> int", get_device_attribute),
+    ("get_max_shared_memory_per_block_device_attribute(int device_id) -> int",
+     get_max_shared_memory_per_block_device_attribute),
+]
+
+
+def _op_name(schema: str) -> str:
+    return schema.split("(", 1)[0]
+
+
+def register() -> None:
+    """Define the three namespaces and attach the impls (idempotent)."""
+    global _registered
+    if _registered:
+        return
+    for ns, table in (("_C", _C_OPS), ("_C_cache_ops", _CACHE_OPS)):
+        lib = torch.library.Library(ns, "DEF")
+        for schema, fn in table:
+            lib.define(schema)
+            name = _op_name(schema)
+            lib.impl(name, fn, "CUDA")
+        _libs.append(lib)
+    lib = torch.library.Library("_C_cuda_utils", "DEF")
+    for schema, fn in _UTIL_OPS:
+        lib.define(schema)
+        # no tensor arguments: the reference registers these under kCUDA but they are
+        # dispatched without a tensor key, so give them the catch-all key.
+        lib.impl(_op_name(schema), fn, "CompositeExplicitAutograd")
+    _libs.append(lib)
+    _registered = True
+
+
+def all_schemas():
+    return {"_C": [s for s, _ in _C_OPS], "_C_cache_ops": [s for s, _ in _CACHE_OPS],
+            "_C_cuda_utils": [s for s, _ in _UTIL_OPS]}

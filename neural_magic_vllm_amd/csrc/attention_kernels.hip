@@ -1,0 +1,537 @@
+// Paged attention (single-query decode) for gfx950 / wave64.
+//
+// Behavioural reference: /root/reference/csrc/attention/attention_kernels.cu
+//   (paged_attention_kernel :86-496, v2 reduce :564-669, launchers :690-990).
+// Same inputs, same cache layouts (K [NB,kvh,D/x,BS,x], V [NB,kvh,D,BS]), same outputs
+// (incl. exp_sums / max_logits / tmp_out of v2), same 1/(sum+1e-6) normaliser.
+//
+// The decomposition is NOT the reference's.  The reference runs one 128-thread block per
+// *query* head and derives THREAD_GROUP_SIZE = WARP_SIZE / BLOCK_SIZE; with GQA that re-reads
+// every KV head num_queries_per_kv times.  Here one 256-thread workgroup (4 waves) serves a
+// GROUP of HG query heads that share one KV head, so K/V bytes cross HBM once per group:
+//
+//   * a wave walks 64-token windows; lane t owns token t of the window for the QK^T pass: it
+//     streams that token's head vector as HEAD_SIZE/x 16-byte chunks straight into VGPRs
+//     (16 tokens x 16 B = 256 contiguous bytes per chunk row of a block) and dots it against
+//     the HG queries, which are broadcast from LDS (ds_read_b128 of one address = no conflict);
+//     packed v_dot2c_f32_bf16 / v_dot2_f32_f16 do two MACs per lane-op with fp32 accumulate.
+//     No cross-lane traffic is needed for a logit.
+//   * softmax is online (flash-decoding): per window one wave-wide max (64-lane xor-shuffle
+//     reduction), the running row-sum stays per lane and is reduced once at the end.
+//   * for P.V the lanes re-map onto the V layout: a wave-load covers 64 consecutive 16-byte
+//     chunks of one (block, head) = 1 KiB contiguous; probabilities go through a 128-byte/head
+//     LDS strip (written by the token-owning lanes, read back as broadcast 16-byte vectors).
+//   * the 4 waves are merged through LDS at the end (max / sum / fp32 accumulators).
+//
+// There is no logits[max_seq_len] buffer, so v1 has no LDS-imposed context limit.
+// HBM-bound by construction: algorithmic bytes = 2 * L * D * sizeof(cache_t) per (seq, kv head).
+#include "common.h"
+
+namespace nmv {
+
+constexpr int PA_THREADS = 256;
+constexpr int PA_WAVES = PA_THREADS / WAVE;
+constexpr int PA_WIN = 64;  // tokens per wave-iteration
+constexpr int PA_PARTITION = 512;
+
+template <int HEAD_SIZE, int BLOCK_SIZE, int HG, bool FP8>
+struct PAGeom {
+  static constexpr int CB = FP8 ? 1 : 2;            // cache element bytes
+  static constexpr int EPC = 16 / CB;               // elements per 16-byte K chunk (= x)
+  static constexpr int NKC = HEAD_SIZE / EPC;       // K chunks per token
+  static constexpr int PPC = EPC / 2;               // packed pairs per K chunk
+  static constexpr int TPCV = EPC < BLOCK_SIZE ? EPC : BLOCK_SIZE;  // tokens per V chunk
+  static constexpr int VB = TPCV * CB;              // V chunk bytes (16, or 8 for fp8 + BS 8)
+  static constexpr int CPR = BLOCK_SIZE / TPCV;     // V chunks per row of a block
+  static constexpr int RPL = WAVE / CPR;            // V rows covered by one wave-load
+  static constexpr int NVL = (HEAD_SIZE + RPL - 1) / RPL;  // wave-loads per block
+  static constexpr int WB = PA_WIN / BLOCK_SIZE;    // blocks per window
+  static constexpr int KG = NKC < 8 ? NKC : 8;      // K chunks in flight per lane
+  static_assert(HEAD_SIZE % EPC == 0, "head size must be a multiple of x");
+  static_assert(PA_WIN % BLOCK_SIZE == 0, "block size must divide the window");
+};
+
+// fp8 x4 (one dword) -> two packed T pairs
+template <typename T>
+__device__ __forceinline__ void fp8x4_to_pairs(uint32_t w, uint32_t& p0, uint32_t& p1) {
+  f32x2_t a = fp8x2_to_f32<false>(w);
+  f32x2_t b = fp8x2_to_f32<true>(w);
+  p0 = T::pack2(a.x, a.y);
+  p1 = T::pack2(b.x, b.y);
+}
+
+template <typename T, bool FP8, int HEAD_SIZE, int BLOCK_SIZE, int HG>
+__global__ __launch_bounds__(PA_THREADS) void paged_attention_kernel(
+    float* __restrict__ exp_sums,    // [num_seqs, num_heads, max_num_partitions] (partitioned only)
+    float* __restrict__ max_logits,  // same
+    uint16_t* __restrict__ out,      // [num_seqs, num_heads, (max_num_partitions,) head_size]
+    const uint16_t* __restrict__ q,  // [num_seqs, num_heads, head_size], row stride q_stride
+    const uint8_t* __restrict__ k_cache, const uint8_t* __restrict__ v_cache, int num_heads,
+    int num_kv_heads, float scale, const int* __restrict__ block_tables,
+    const int* __restrict__ seq_lens, int max_num_blocks_per_seq,
+    const float* __restrict__ alibi_slopes, int64_t q_stride, int64_t kv_block_stride,
+    int64_t kv_head_stride, float kv_scale, int partition_size /* 0 = not partitioned */) {
+  using G = PAGeom<HEAD_SIZE, BLOCK_SIZE, HG, FP8>;
+  const int seq_idx = blockIdx.y;
+  const int part_idx = blockIdx.z;
+  const int max_num_partitions = gridDim.z;
+  const int seq_len = seq_lens[seq_idx];
+  const int start_tok = partition_size ? part_idx * partition_size : 0;
+  if (start_tok >= seq_len) return;  // uniform for the whole workgroup
+  const int end_tok = partition_size ? min(start_tok + partition_size, seq_len) : seq_len;
+
+  const int head0 = blockIdx.x * HG;
+  const int q_per_kv = num_heads / num_kv_heads;
+  const int kv_head = head0 / q_per_kv;
+  const int lane = threadIdx.x & 63;
+  // wave id, made provably wave-uniform
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+
+  __shared__ __attribute__((aligned(16))) uint32_t q_s[HG * HEAD_SIZE / 2];
+  __shared__ __attribute__((aligned(16))) uint32_t p_s[PA_WAVES][HG][PA_WIN / 2];
+  __shared__ float red_m[PA_WAVES][HG];
+  __shared__ float red_l[PA_WAVES][HG];
+  __shared__ float out_red[PA_WAVES][HG][HEAD_SIZE];
+
+  // ---- queries of the head group -> LDS (HG*HEAD_SIZE contiguous elements) ----
+  {
+    const uint32_t* q_ptr =
+        reinterpret_cast<const uint32_t*>(q + (int64_t)seq_idx * q_stride + (int64_t)head0 * HEAD_SIZE);
+    for (int i = threadIdx.x; i < HG * HEAD_SIZE / 2; i += PA_THREADS) q_s[i] = q_ptr[i];
+  }
+  __syncthreads();
+
+  float slope[HG];
+#pragma unroll
+  for (int h = 0; h < HG; ++h) slope[h] = alibi_slopes ? alibi_slopes[head0 + h] : 0.f;
+
+  float m_run[HG], l_lane[HG], acc[HG][G::NVL];
+#pragma unroll
+  for (int h = 0; h < HG; ++h) {
+    m_run[h] = -INFINITY;
+    l_lane[h] = 0.f;
+#pragma unroll
+    for (int i = 0; i < G::NVL; ++i) acc[h][i] = 0.f;
+  }
+
+  const int* block_table = block_tables + (int64_t)seq_idx * max_num_blocks_per_seq;
+  const int n_win = (end_tok - start_tok + PA_WIN - 1) / PA_WIN;
+  const float qk_scale = FP8 ? scale * kv_scale : scale;
+  const int64_t head_off_bytes = (int64_t)kv_head * kv_head_stride * G::CB;
+  const int64_t block_stride_bytes = kv_block_stride * G::CB;
+
+  // V-phase lane geometry
+  const int cpr_idx = lane % G::CPR;
+  const int row_l = lane / G::CPR;
+
+  auto phys_of = [&](int w) -> int {
+    const int tok = min(start_tok + w * PA_WIN + lane, end_tok - 1);
+    return block_table[tok / BLOCK_SIZE];
+  };
+  int phys = wave < n_win ? phys_of(wave) : 0;
+
+  for (int w = wave; w < n_win; w += PA_WAVES) {
+    const int wstart = start_tok + w * PA_WIN;
+    const int tok = wstart + lane;
+    const bool valid = tok < end_tok;
+    const int tok_c = valid ? tok : end_tok - 1;
+    const int boff = tok_c % BLOCK_SIZE;
+    // block-table lookup of the NEXT window issued before this window's loads are consumed
+    const int phys_next = (w + PA_WAVES < n_win) ? phys_of(w + PA_WAVES) : 0;
+
+    // ================= Q.K^T : lane = token =================
+    const uint8_t* kp = k_cache + (int64_t)phys * block_stride_bytes + head_off_bytes + boff * 16;
+    float s[HG];
+#pragma unroll
+    for (int h = 0; h < HG; ++h) s[h] = 0.f;
+#pragma unroll
+    for (int c0 = 0; c0 < G::NKC; c0 += G::KG) {
+      uint4 kc[G::KG];
+#pragma unroll
+      for (int j = 0; j < G::KG; ++j)
+        if (c0 + j < G::NKC) kc[j] = ld16(kp + (int64_t)(c0 + j) * (BLOCK_SIZE * 16));
+#pragma unroll
+      for (int j = 0; j < G::KG; ++j) {
+        if (c0 + j >= G::NKC) continue;
+        if constexpr (!FP8) {
+#pragma unroll
+          for (int h = 0; h < HG; ++h) {
+            const uint4 qv = *reinterpret_cast<const uint4*>(&q_s[h * (HEAD_SIZE / 2) + (c0 + j) * 4]);
+            float a = s[h];
+            a = T::dot2(kc[j].x, qv.x, a);
+            a = T::dot2(kc[j].y, qv.y, a);
+            a = T::dot2(kc[j].z, qv.z, a);
+            a = T::dot2(kc[j].w, qv.w, a);
+            s[h] = a;
+          }
+        } else {
+          uint32_t kpair[8];
+          fp8x4_to_pairs<T>(kc[j].x, kpair[0], kpair[1]);
+          fp8x4_to_pairs<T>(kc[j].y, kpair[2], kpair[3]);
+          fp8x4_to_pairs<T>(kc[j].z, kpair[4], kpair[5]);
+          fp8x4_to_pairs<T>(kc[j].w, kpair[6], kpair[7]);
+#pragma unroll
+          for (int h = 0; h < HG; ++h) {
+            const uint4 q0 = *reinterpret_cast<const uint4*>(&q_s[h * (HEAD_SIZE / 2) + (c0 + j) * 8]);
+            const uint4 q1 = *reinterpret_cast<const uint4*>(&q_s[h * (HEAD_SIZE / 2) + (c0 + j) * 8 + 4]);
+            float a = s[h];
+            a = T::dot2(kpair[0], q0.x, a);
+            a = T::dot2(kpair[1], q0.y, a);
+            a = T::dot2(kpair[2], q0.z, a);
+            a = T::dot2(kpair[3], q0.w, a);
+            a = T::dot2(kpair[4], q1.x, a);
+            a = T::dot2(kpair[5], q1.y, a);
+            a = T::dot2(kpair[6], q1.z, a);
+            a = T::dot2(kpair[7], q1.w, a);
+            s[h] = a;
+          }
+        }
+      }
+    }
+
+    // ================= online softmax =================
+#pragma unroll
+    for (int h = 0; h < HG; ++h) {
+      float sv = s[h] * qk_scale;
+      sv += (slope[h] != 0.f) ? slope[h] * (float)(tok - seq_len + 1) : 0.f;
+      sv = valid ? sv : -INFINITY;
+      const float m_new = fmaxf(m_run[h], wave_max(sv));
+      const float alpha = __expf(m_run[h] - m_new);  // exp(-inf) = 0 on the first window
+      const float p = valid ? __expf(sv - m_new) : 0.f;
+      l_lane[h] = l_lane[h] * alpha + p;
+      m_run[h] = m_new;
+#pragma unroll
+      for (int i = 0; i < G::NVL; ++i) acc[h][i] *= alpha;
+      // probabilities are rounded to the cache's compute dtype before P.V, as the reference
+      // does (attention_kernels.cu:398-400 from_float(logits_vec, ...))
+      reinterpret_cast<uint16_t*>(&p_s[wave][h][0])[lane] = T::from_float(p);
+    }
+    // p_s is private to this wave: LDS ops of one wave execute in order, only the compiler
+    // has to be kept from reordering the stores above past the loads below.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    // ================= P.V : lanes re-mapped onto V's [row][token] layout =================
+    const int win_tokens = min(end_tok - wstart, PA_WIN);
+    const int nb = (win_tokens + BLOCK_SIZE - 1) / BLOCK_SIZE;
+#pragma unroll
+    for (int b = 0; b < G::WB; ++b) {
+      if (b >= nb) break;  // wave-uniform
+      const int physb = __builtin_amdgcn_readlane(phys, b * BLOCK_SIZE);
+      const uint8_t* vp = v_cache + (int64_t)physb * block_stride_bytes + head_off_bytes +
+                          (int64_t)cpr_idx * G::VB;
+      // tokens of this lane's chunk: t0 .. t0+TPCV-1 (window-relative)
+      const int t0 = b * BLOCK_SIZE + cpr_idx * G::TPCV;
+      const bool partial = (b + 1) * BLOCK_SIZE > win_tokens;  // wave-uniform
+      constexpr int NP = G::TPCV / 2;  // packed pairs per V chunk
+      uint32_t pp[HG][NP];
+#pragma unroll
+      for (int h = 0; h < HG; ++h) {
+#pragma unroll
+        for (int j = 0; j < NP; j += 4) {
+          const uint4 t = *reinterpret_cast<const uint4*>(&p_s[wave][h][t0 / 2 + j]);
+          pp[h][j] = t.x; pp[h][j + 1] = t.y; pp[h][j + 2] = t.z; pp[h][j + 3] = t.w;
+        }
+      }
+      constexpr int VG = G::NVL < 4 ? G::NVL : 4;  // V wave-loads in flight per lane
+#pragma unroll
+      for (int i0 = 0; i0 < G::NVL; i0 += VG) {
+        uint32_t vraw[VG][4];
+#pragma unroll
+        for (int ii = 0; ii < VG; ++ii) {
+          if (i0 + ii >= G::NVL) continue;
+          const int row = (i0 + ii) * G::RPL + row_l;
+          const int rowc = (HEAD_SIZE % G::RPL == 0) ? row : min(row, HEAD_SIZE - 1);
+          const uint8_t* a = vp + (int64_t)rowc * (BLOCK_SIZE * G::CB);
+          if constexpr (G::VB == 16) {
+            const uint4 t = ld16(a);
+            vraw[ii][0] = t.x; vraw[ii][1] = t.y; vraw[ii][2] = t.z; vraw[ii][3] = t.w;
+          } else {
+            const uint2 t = ld8(a);
+            vraw[ii][0] = t.x; vraw[ii][1] = t.y; vraw[ii][2] = 0; vraw[ii][3] = 0;
+          }
+        }
+#pragma unroll
+        for (int ii = 0; ii < VG; ++ii) {
+          if (i0 + ii >= G::NVL) continue;
+          uint32_t vpair[NP];
+          if constexpr (!FP8) {
+#pragma unroll
+            for (int j = 0; j < NP; ++j) vpair[j] = vraw[ii][j];
+          } else {
+#pragma unroll
+            for (int j = 0; j < NP / 2; ++j)
+              fp8x4_to_pairs<T>(vraw[ii][j], vpair[2 * j], vpair[2 * j + 1]);
+          }
+          if (partial) {
+            // zero V of out-of-context tokens: the cache may hold NaN garbage there
+            // (attention_kernels.cu:424-434)
+#pragma unroll
+            for (int j = 0; j < NP; ++j) {
+              const int t = t0 + 2 * j;
+              vpair[j] = (t >= win_tokens) ? 0u
+                                           : ((t + 1 >= win_tokens) ? (vpair[j] & 0xffffu) : vpair[j]);
+            }
+          }
+#pragma unroll
+          for (int h = 0; h < HG; ++h) {
+            float a = acc[h][i0 + ii];
+#pragma unroll
+            for (int j = 0; j < NP; ++j) a = T::dot2(vpair[j], pp[h][j], a);
+            acc[h][i0 + ii] = a;
+          }
+        }
+      }
+    }
+    phys = phys_next;
+  }
+
+  // ================= merge =================
+  // (1) lanes that share a V row
+#pragma unroll
+  for (int h = 0; h < HG; ++h)
+#pragma unroll
+    for (int i = 0; i < G::NVL; ++i) {
+      float a = acc[h][i];
+#pragma unroll
+      for (int m = 1; m < G::CPR; m <<= 1) a += __shfl_xor(a, m, 64);
+      acc[h][i] = a;
+    }
+  // (2) per-wave row sums
+#pragma unroll
+  for (int h = 0; h < HG; ++h) {
+    const float lw = wave_sum(l_lane[h]);
+    if (lane == 0) {
+      red_m[wave][h] = m_run[h];
+      red_l[wave][h] = lw;
+    }
+  }
+  __syncthreads();
+  // (3) rescale to the workgroup max and park the accumulators in LDS
+  const float kvs = FP8 ? kv_scale : 1.f;
+#pragma unroll
+  for (int h = 0; h < HG; ++h) {
+    float mg = red_m[0][h];
+#pragma unroll
+    for (int ww = 1; ww < PA_WAVES; ++ww) mg = fmaxf(mg, red_m[ww][h]);
+    const float f = __expf(m_run[h] - mg) * kvs;  // wave without work: exp(-inf) = 0
+#pragma unroll
+    for (int i = 0; i < G::NVL; ++i) {
+      const int row = i * G::RPL + row_l;
+      if (cpr_idx == 0 && row < HEAD_SIZE) out_red[wave][h][row] = acc[h][i] * f;
+    }
+  }
+  __syncthreads();
+  // (4) sum the waves, normalise, store
+  for (int idx = threadIdx.x; idx < HG * HEAD_SIZE; idx += PA_THREADS) {
+    const int h = idx / HEAD_SIZE;
+    const int d = idx % HEAD_SIZE;
+    float mg = red_m[0][h];
+#pragma unroll
+    for (int ww = 1; ww < PA_WAVES; ++ww) mg = fmaxf(mg, red_m[ww][h]);
+    float lg = 0.f, o = 0.f;
+#pragma unroll
+    for (int ww = 0; ww < PA_WAVES; ++ww) {
+      lg += red_l[ww][h] * __expf(red_m[ww][h] - mg);
+      o += out_red[ww][h][d];
+    }
+    const float inv = __fdividef(1.f, lg + 1e-6f);  // attention_kernels.cu:342
+    const int head = head0 + h;
+    if (partition_size) {
+      const int64_t pidx = ((int64_t)seq_idx * num_heads + head) * max_num_partitions + part_idx;
+      out[pidx * HEAD_SIZE + d] = T::from_float(o * inv);
+      if (d == 0) {
+        exp_sums[pidx] = lg;
+        max_logits[pidx] = mg;
+      }
+    } else {
+      out[((int64_t)seq_idx * num_heads + head) * HEAD_SIZE + d] = T::from_float(o * inv);
+    }
+  }
+}
+
+// v2 second pass: merge the partitions of one (seq, head).  Mirrors attention_kernels.cu:564-669.
+// One wave per (seq, head): partitions are few (max_seq_len/512) and the work is tiny.
+template <typename T, int HEAD_SIZE>
+__global__ __launch_bounds__(WAVE) void paged_attention_v2_reduce_kernel(
+    uint16_t* __restrict__ out, const float* __restrict__ exp_sums,
+    const float* __restrict__ max_logits, const uint16_t* __restrict__ tmp_out,
+    const int* __restrict__ seq_lens, int max_num_partitions) {
+  const int num_heads = gridDim.x;
+  const int head_idx = blockIdx.x;
+  const int seq_idx = blockIdx.y;
+  const int seq_len = seq_lens[seq_idx];
+  const int num_partitions = (seq_len + PA_PARTITION - 1) / PA_PARTITION;
+  const int lane = threadIdx.x;
+  const int64_t base = ((int64_t)seq_idx * num_heads + head_idx) * max_num_partitions;
+  uint16_t* out_ptr = out + ((int64_t)seq_idx * num_heads + head_idx) * HEAD_SIZE;
+  const uint16_t* tmp_ptr = tmp_out + base * HEAD_SIZE;
+  if (num_partitions <= 1) {
+    if (num_partitions == 1)
+      for (int i = lane; i < HEAD_SIZE; i += WAVE) out_ptr[i] = tmp_ptr[i];
+    return;
+  }
+  extern __shared__ float w_s[];  // [num_partitions] rescaled exp sums
+  float mx = -FLT_MAX;
+  for (int i = lane; i < num_partitions; i += WAVE) mx = fmaxf(mx, max_logits[base + i]);
+  mx = wave_max(mx);
+  float gs = 0.f;
+  for (int i = lane; i < num_partitions; i += WAVE) {
+    const float r = exp_sums[base + i] * expf(max_logits[base + i] - mx);
+    w_s[i] = r;
+    gs += r;
+  }
+  gs = wave_sum(gs);
+  __syncthreads();
+  const float inv = __fdividef(1.f, gs + 1e-6f);
+  for (int i = lane; i < HEAD_SIZE; i += WAVE) {
+    float a = 0.f;
+    for (int j = 0; j < num_partitions; ++j)
+      a += T::to_float(tmp_ptr[(int64_t)j * HEAD_SIZE + i]) * w_s[j] * inv;
+    out_ptr[i] = T::from_float(a);
+  }
+}
+
+struct PAArgs {
+  float* exp_sums; float* max_logits; void* out; void* tmp_out;
+  const void* query; const void* key_cache; const void* value_cache;
+  int num_seqs, num_heads, head_size, num_kv_heads; float scale;
+  const int32_t* block_tables; const int32_t* seq_lens;
+  int block_size, max_seq_len, max_num_blocks_per_seq;
+  const float* alibi_slopes; int64_t q_stride, kv_block_stride, kv_head_stride;
+  float kv_scale; bool partitioned; hipStream_t stream;
+};
+
+template <typename T, bool FP8, int HEAD_SIZE, int BLOCK_SIZE, int HG>
+static void launch_pa(const PAArgs& a) {
+  const int parts = a.partitioned ? (a.max_seq_len + PA_PARTITION - 1) / PA_PARTITION : 1;
+  dim3 grid(a.num_heads / HG, a.num_seqs, parts);
+  hipLaunchKernelGGL((paged_attention_kernel<T, FP8, HEAD_SIZE, BLOCK_SIZE, HG>), grid,
+                     dim3(PA_THREADS), 0, a.stream, a.exp_sums, a.max_logits,
+                     (uint16_t*)(a.partitioned ? a.tmp_out : a.out), (const uint16_t*)a.query,
+                     (const uint8_t*)a.key_cache, (const uint8_t*)a.value_cache, a.num_heads,
+                     a.num_kv_heads, a.scale, a.block_tables, a.seq_lens,
+                     a.max_num_blocks_per_seq, a.alibi_slopes, a.q_stride, a.kv_block_stride,
+                     a.kv_head_stride, a.kv_scale, a.partitioned ? PA_PARTITION : 0);
+  if (a.partitioned) {
+    dim3 rgrid(a.num_heads, a.num_seqs);
+    hipLaunchKernelGGL((paged_attention_v2_reduce_kernel<T, HEAD_SIZE>), rgrid, dim3(WAVE),
+                       parts * sizeof(float), a.stream, (uint16_t*)a.out, a.exp_sums,
+                       a.max_logits, (const uint16_t*)a.tmp_out, a.seq_lens, parts);
+  }
+}
+
+template <typename T, bool FP8, int HEAD_SIZE, int BLOCK_SIZE>
+static int dispatch_hg(const PAArgs& a) {
+  const int g = a.num_heads / a.num_kv_heads;
+  if (g % 8 == 0) launch_pa<T, FP8, HEAD_SIZE, BLOCK_SIZE, 8>(a);
+  else if (g % 4 == 0) launch_pa<T, FP8, HEAD_SIZE, BLOCK_SIZE, 4>(a);
+  else if (g % 2 == 0) launch_pa<T, FP8, HEAD_SIZE, BLOCK_SIZE, 2>(a);
+  else launch_pa<T, FP8, HEAD_SIZE, BLOCK_SIZE, 1>(a);
+  return 0;
+}
+
+template <typename T, bool FP8, int HEAD_SIZE>
+static int dispatch_bs(const PAArgs& a) {
+  switch (a.block_size) {
+    case 8: return dispatch_hg<T, FP8, HEAD_SIZE, 8>(a);
+    case 16: return dispatch_hg<T, FP8, HEAD_SIZE, 16>(a);
+    case 32: return dispatch_hg<T, FP8, HEAD_SIZE, 32>(a);
+    default: return -1;
+  }
+}
+
+template <int HEAD_SIZE>
+int pa_dispatch_head(const PAArgs& a, nmv_dtype_t dtype, nmv_kv_dtype_t kv) {
+  if (dtype == NMV_F16) return kv == NMV_KV_AUTO ? dispatch_bs<F16, false, HEAD_SIZE>(a)
+                                                  : dispatch_bs<F16, true, HEAD_SIZE>(a);
+  return kv == NMV_KV_AUTO ? dispatch_bs<BF16, false, HEAD_SIZE>(a)
+                           : dispatch_bs<BF16, true, HEAD_SIZE>(a);
+}
+
+#ifdef NMV_PA_HEAD_SIZE
+// one translation unit per head size keeps the build parallel
+template int pa_dispatch_head<NMV_PA_HEAD_SIZE>(const PAArgs&, nmv_dtype_t, nmv_kv_dtype_t);
+#endif
+
+}  // namespace nmv
+
+#ifndef NMV_PA_HEAD_SIZE
+// ------------------------------- C ABI (compiled once) -------------------------------
+using namespace nmv;
+namespace nmv {
+extern template int pa_dispatch_head<64>(const PAArgs&, nmv_dtype_t, nmv_kv_dtype_t);
+extern template int pa_dispatch_head<80>(const PAArgs&, nmv_dtype_t, nmv_kv_dtype_t);
+extern template int pa_dispatch_head<96>(const PAArgs&, nmv_dtype_t, nmv_kv_dtype_t);
+extern template int pa_dispatch_head<112>(const PAArgs&, nmv_dtype_t, nmv_kv_dtype_t);
+extern template int pa_dispatch_head<128>(const PAArgs&, nmv_dtype_t, nmv_kv_dtype_t);
+extern template int pa_dispatch_head<192>(const PAArgs&, nmv_dtype_t, nmv_kv_dtype_t);
+extern template int pa_dispatch_head<256>(const PAArgs&, nmv_dtype_t, nmv_kv_dtype_t);
+}
+
+static int pa_entry(PAArgs& a, nmv_dtype_t dtype, nmv_kv_dtype_t kv_dtype, const char* name) {
+  NMV_CHECK(dtype == NMV_F16 || dtype == NMV_BF16, "%s: unsupported data type %d", name, (int)dtype);
+  NMV_CHECK(kv_dtype == NMV_KV_AUTO || kv_dtype == NMV_KV_FP8_E4M3,
+            "%s: unsupported kv cache dtype %d", name, (int)kv_dtype);
+  NMV_CHECK(a.num_kv_heads > 0 && a.num_heads % a.num_kv_heads == 0,
+            "%s: num_heads %d not divisible by num_kv_heads %d", name, a.num_heads, a.num_kv_heads);
+  NMV_CHECK(a.block_size == 8 || a.block_size == 16 || a.block_size == 32,
+            "%s: Unsupported block size: %d", name, a.block_size);
+  NMV_CHECK(a.q_stride % 2 == 0, "%s: query row stride must be even", name);
+  if (a.num_seqs == 0) return NMV_OK;
+  int rc;
+  switch (a.head_size) {
+    case 64: rc = pa_dispatch_head<64>(a, dtype, kv_dtype); break;
+    case 80: rc = pa_dispatch_head<80>(a, dtype, kv_dtype); break;
+    case 96: rc = pa_dispatch_head<96>(a, dtype, kv_dtype); break;
+    case 112: rc = pa_dispatch_head<112>(a, dtype, kv_dtype); break;
+    case 128: rc = pa_dispatch_head<128>(a, dtype, kv_dtype); break;
+    case 192: rc = pa_dispatch_head<192>(a, dtype, kv_dtype); break;
+    case 256: rc = pa_dispatch_head<256>(a, dtype, kv_dtype); break;
+    default:
+      set_error("%s: Unsupported head size: %d", name, a.head_size);
+      return NMV_ERR_INVALID;
+  }
+  if (rc != 0) {
+    set_error("%s: unsupported configuration", name);
+    return NMV_ERR_INVALID;
+  }
+  NMV_LAUNCH_CHECK();
+  return NMV_OK;
+}
+
+extern "C" int nmv_paged_attention_v1(void* out, const void* query, const void* key_cache,
+                                      const void* value_cache, int num_seqs, int num_heads,
+                                      int head_size, int num_kv_heads, float scale,
+                                      const int32_t* block_tables, const int32_t* seq_lens,
+                                      int block_size, int max_seq_len, int max_num_blocks_per_seq,
+                                      const float* alibi_slopes, int64_t q_stride,
+                                      int64_t kv_block_stride, int64_t kv_head_stride,
+                                      nmv_dtype_t dtype, nmv_kv_dtype_t kv_dtype, float kv_scale,
+                                      void* stream) {
+  PAArgs a{nullptr, nullptr, out, nullptr, query, key_cache, value_cache, num_seqs, num_heads,
+           head_size, num_kv_heads, scale, block_tables, seq_lens, block_size, max_seq_len,
+           max_num_blocks_per_seq, alibi_slopes, q_stride, kv_block_stride, kv_head_stride,
+           kv_scale, false, (hipStream_t)stream};
+  return pa_entry(a, dtype, kv_dtype, "paged_attention_v1");
+}
+
+extern "C" int nmv_paged_attention_v2(void* out, float* exp_sums, float* max_logits,
+                                      void* tmp_out, const void* query, const void* key_cache,
+                                      const void* value_cache, int num_seqs, int num_heads,
+                                      int head_size, int num_kv_heads, float scale,
+                                      const int32_t* block_tables, const int32_t* seq_lens,
+                                      int block_size, int max_seq_len, int max_num_blocks_per_seq,
+                                      const float* alibi_slopes, int64_t q_stride,
+                                      int64_t kv_block_stride, int64_t kv_head_stride,
+                                      nmv_dtype_t dtype, nmv_kv_dtype_t kv_dtype, float kv_scale,
+                                      void* stream) {
+  NMV_CHECK(exp_sums && max_logits && tmp_out, "paged_attention_v2: null partition buffers");
+  PAArgs a{exp_sums, max_logits, out, tmp_out, query, key_cache, value_cache, num_seqs,
+           num_heads, head_size, num_kv_heads, scale, block_tables, seq_lens, block_size,
+           max_seq_len, max_num_blocks_per_seq, alibi_slopes, q_stride, kv_block_stride,
+           kv_head_stride, kv_scale, true, (hipStream_t)stream};
+  return pa_entry(a, dtype, kv_dtype, "paged_attention_v2");
+}
+#endif

@@ -1,0 +1,79 @@
+"""CPU: the C-ABI library loads and exports every symbol include/nmvllm_hip.h declares, and the
+ctypes table in _lib.py covers exactly that set (no compute calls -- there is no GPU here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "nmvllm_hip.h")
+
+
+def declared_symbols():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(nmv_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_declares_symbols():
+    syms = declared_symbols()
+    assert "nmv_paged_attention_v1" in syms and "nmv_gptq_marlin_gemm" in syms
+    assert len(syms) >= 20
+
+
+def test_library_exports_every_declared_symbol():
+    from neural_magic_vllm_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    missing = [s for s in declared_symbols() if not hasattr(lib, s)]
+    assert not missing, f"not exported: {missing}"
+
+
+def test_ctypes_table_matches_header():
+    from neural_magic_vllm_amd import _lib
+    assert sorted(_lib.SIGNATURES) == declared_symbols()
+    lib = _lib.load()
+    assert lib.nmv_abi_version() >= 1
+    assert lib.nmv_last_error() is not None
+
+
+def test_argument_counts_match_header():
+    """crude C parser: number of parameters per prototype == len(argtypes)"""
+    from neural_magic_vllm_amd import _lib
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    for name, (_, argtypes) in _lib.SIGNATURES.items():
+        m = re.search(r"\b" + name + r"\s*\(([^;]*?)\)\s*;", src, flags=re.S)
+        assert m, name
+        params = m.group(1).strip()
+        n = 0 if params in ("", "void") else params.count(",") + 1
+        assert n == len(argtypes), f"{name}: header has {n} params, ctypes table {len(argtypes)}"
+
+
+def test_ops_registered_with_reference_schemas():
+    import torch
+    import neural_magic_vllm_amd  # noqa: F401
+    s = str(torch.ops._C.paged_attention_v1.default._schema)
+    assert "Tensor(a0! -> ) out" in s or "Tensor($0! -> ) out" in s or "Tensor(a!) out" in s
+    assert "str kv_cache_dtype, float kv_scale, int tp_rank" in s
+    for ns, names in (("_C", ["paged_attention_v2", "rms_norm", "fused_add_rms_norm",
+                              "rotary_embedding", "silu_and_mul", "gptq_marlin_gemm",
+                              "gptq_marlin_repack"]),
+                      ("_C_cache_ops", ["reshape_and_cache", "copy_blocks", "swap_blocks",
+                                        "convert_fp8", "reshape_and_cache_flash"]),
+                      ("_C_cuda_utils", ["get_device_attribute",
+                                         "get_max_shared_memory_per_block_device_attribute"])):
+        for n in names:
+            assert hasattr(getattr(torch.ops, ns), n), f"{ns}::{n}"
+
+
+def test_no_cpu_fallback():
+    """the product has no CPU path: CPU tensors are rejected by the dispatcher"""
+    import torch
+    from neural_magic_vllm_amd import _custom_ops as ops
+    x = torch.zeros(2, 8, dtype=torch.bfloat16)
+    with pytest.raises((NotImplementedError, RuntimeError)):
+        ops.rms_norm(torch.empty_like(x), x, torch.ones(8, dtype=torch.bfloat16), 1e-5)

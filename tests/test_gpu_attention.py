@@ -1,0 +1,181 @@
+"""GPU parity: paged_attention_v1/v2 (HIP, through torch.ops._C -> C ABI) vs the CPU oracle and
+the golden vectors of the reference.  Recipe and tolerances follow the reference's
+tests/kernels/test_attention.py:119-284 (atol 1e-3 / rtol 1e-5; fp8 KV: atol 1e-2)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import helpers
+import oracle
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def run_hip(inp, version, dev, kv_cache_dtype="auto", kv_scale=1.0, query=None):
+    from neural_magic_vllm_amd import _custom_ops as ops
+    q = inp["query"].to(dev) if query is None else query
+    kc, vc = inp["key_cache"].to(dev), inp["value_cache"].to(dev)
+    bt, sl = inp["block_tables"].to(dev), inp["seq_lens"].to(dev)
+    al = None if inp["alibi_slopes"] is None else inp["alibi_slopes"].to(dev)
+    out = torch.full(tuple(q.shape), float("nan"), dtype=q.dtype, device=dev)
+    nkv, bs, msl = inp["num_kv_heads"], inp["block_size"], inp["max_seq_len"]
+    if version == "v1":
+        ops.paged_attention_v1(out, q, kc, vc, nkv, inp["scale"], bt, sl, bs, msl, al,
+                               kv_cache_dtype, kv_scale)
+        return out.cpu(), None
+    ns, nh, hs = q.shape
+    mp = (msl + 511) // 512
+    tmp = torch.empty((ns, nh, mp, hs), dtype=q.dtype, device=dev)
+    es = torch.empty((ns, nh, mp), dtype=torch.float32, device=dev)
+    ml = torch.empty_like(es)
+    ops.paged_attention_v2(out, es, ml, tmp, q, kc, vc, nkv, inp["scale"], bt, sl, bs, msl, al,
+                           kv_cache_dtype, kv_scale)
+    return out.cpu(), (es.cpu(), ml.cpu(), tmp.cpu())
+
+
+def run_oracle(inp, kv_cache_dtype="auto", kv_scale=1.0, partition_size=0):
+    return oracle.paged_attention(inp["query"], inp["key_cache"], inp["value_cache"],
+                                  inp["num_kv_heads"], inp["scale"], inp["block_tables"],
+                                  inp["seq_lens"], inp["block_size"],
+                                  alibi_slopes=inp["alibi_slopes"], kv_cache_dtype=kv_cache_dtype,
+                                  kv_scale=kv_scale, partition_size=partition_size)
+
+
+def check(out, ref, atol=1e-3, rtol=1e-5):
+    out, ref = out.float(), ref.float()
+    assert not torch.isnan(out).any(), "NaN / unwritten output"
+    err = (out - ref).abs().max().item()
+    assert torch.allclose(out, ref, atol=atol, rtol=rtol), f"max abs err {err}"
+    # systematic-error guard, much tighter than the elementwise tolerance
+    rel = ((out - ref).abs().mean() / ref.abs().mean().clamp_min(1e-9)).item()
+    assert rel < 2e-2, f"mean relative error {rel}"
+
+
+@pytest.mark.parametrize("version", ["v1", "v2"])
+@pytest.mark.parametrize("num_heads", [(40, 40), (64, 8), (32, 8)])
+@pytest.mark.parametrize("head_size", [64, 80, 96, 112, 128, 192, 256])
+@pytest.mark.parametrize("block_size", [16, 32])
+@pytest.mark.parametrize("dtype", [torch.half, torch.bfloat16])
+def test_paged_attention(gpu_device, version, num_heads, head_size, block_size, dtype):
+    inp = helpers.make_paged_attention_inputs(0, 7, num_heads, head_size, block_size, dtype,
+                                              max_seq_len=1800, num_blocks=512)
+    out, _ = run_hip(inp, version, gpu_device)
+    check(out, run_oracle(inp))
+
+
+@pytest.mark.parametrize("version", ["v1", "v2"])
+@pytest.mark.parametrize("num_heads", [(40, 40), (64, 8), (12, 6)])
+@pytest.mark.parametrize("head_size", [64, 128])
+@pytest.mark.parametrize("dtype", [torch.half, torch.bfloat16])
+def test_paged_attention_alibi(gpu_device, version, num_heads, head_size, dtype):
+    inp = helpers.make_paged_attention_inputs(1, 7, num_heads, head_size, 16, dtype,
+                                              max_seq_len=1300, num_blocks=512, use_alibi=True)
+    out, _ = run_hip(inp, version, gpu_device)
+    check(out, run_oracle(inp))
+
+
+@pytest.mark.parametrize("version", ["v1", "v2"])
+@pytest.mark.parametrize("num_heads", [(40, 40), (64, 8), (32, 8)])
+@pytest.mark.parametrize("head_size", [64, 80, 128, 256])
+@pytest.mark.parametrize("block_size", [8, 16, 32])
+@pytest.mark.parametrize("dtype", [torch.half, torch.bfloat16])
+def test_paged_attention_fp8_kv(gpu_device, version, num_heads, head_size, block_size, dtype):
+    inp = helpers.make_paged_attention_inputs(2, 5, num_heads, head_size, block_size, dtype,
+                                              max_seq_len=1100, num_blocks=384,
+                                              kv_cache_dtype="fp8")
+    out, _ = run_hip(inp, version, gpu_device, kv_cache_dtype="fp8", kv_scale=1.5)
+    # same fp8 bytes on both sides: only accumulation order differs
+    check(out, run_oracle(inp, kv_cache_dtype="fp8", kv_scale=1.5), atol=2e-3)
+
+
+@pytest.mark.parametrize("version", ["v1", "v2"])
+@pytest.mark.parametrize("head_size", [64, 128])
+def test_paged_attention_block8(gpu_device, version, head_size):
+    inp = helpers.make_paged_attention_inputs(3, 6, (32, 8), head_size, 8, torch.bfloat16,
+                                              max_seq_len=900, num_blocks=768)
+    out, _ = run_hip(inp, version, gpu_device)
+    check(out, run_oracle(inp))
+
+
+@pytest.mark.parametrize("seq_lens", [[1], [1, 2, 3], [15, 16, 17], [63, 64, 65], [511, 512, 513],
+                                      [1024, 1025, 1], [256] * 9])
+@pytest.mark.parametrize("version", ["v1", "v2"])
+def test_paged_attention_edges(gpu_device, version, seq_lens):
+    inp = helpers.make_paged_attention_inputs(4, len(seq_lens), (32, 8), 128, 16, torch.bfloat16,
+                                              seq_lens=seq_lens, num_blocks=256)
+    out, _ = run_hip(inp, version, gpu_device)
+    check(out, run_oracle(inp))
+
+
+@pytest.mark.parametrize("version", ["v1", "v2"])
+def test_paged_attention_long_context(gpu_device, version):
+    """v1 has no shared-memory limit here (the reference caps it at 8192 via smem)."""
+    inp = helpers.make_paged_attention_inputs(5, 2, (32, 8), 128, 16, torch.bfloat16,
+                                              seq_lens=[12000, 9001], num_blocks=1400)
+    out, _ = run_hip(inp, version, gpu_device)
+    check(out, run_oracle(inp))
+
+
+def test_paged_attention_strided_query(gpu_device):
+    """q is a slice of the fused qkv output (query.stride(0) != heads*head_size)."""
+    inp = helpers.make_paged_attention_inputs(6, 5, (32, 8), 128, 16, torch.bfloat16,
+                                              max_seq_len=700, num_blocks=256)
+    ns, nh, hs = inp["query"].shape
+    qkv = torch.zeros((ns, (nh + 16) * hs), dtype=torch.bfloat16, device=gpu_device)
+    qkv[:, :nh * hs] = inp["query"].reshape(ns, -1).to(gpu_device)
+    q = qkv[:, :nh * hs].view(ns, nh, hs)
+    assert q.stride(0) != nh * hs
+    out, _ = run_hip(inp, "v1", gpu_device, query=q)
+    check(out, run_oracle(inp))
+
+
+def test_v2_partition_outputs(gpu_device):
+    """exp_sums / max_logits / tmp_out keep the reference's meaning (attention_kernels.cu:350-361)."""
+    inp = helpers.make_paged_attention_inputs(7, 3, (8, 2), 128, 16, torch.bfloat16,
+                                              seq_lens=[1500, 513, 40], num_blocks=256)
+    out, (es, ml, tmp) = run_hip(inp, "v2", gpu_device)
+    o_ref, es_ref, ml_ref, tmp_ref = run_oracle(inp, partition_size=512)
+    check(out, o_ref)
+    for s, L in enumerate([1500, 513, 40]):
+        npart = (L + 511) // 512
+        assert torch.allclose(ml[s, :, :npart], ml_ref[s, :, :npart], atol=1e-4, rtol=1e-3)
+        assert torch.allclose(es[s, :, :npart], es_ref[s, :, :npart], atol=1e-3, rtol=2e-3)
+        assert torch.allclose(tmp[s, :, :npart].float(), tmp_ref[s, :, :npart].float(), atol=1e-3,
+                              rtol=1e-2)
+
+
+@pytest.mark.parametrize("name", ["pa_bf16_gqa4_ragged", "pa_bf16_mha_alibi", "pa_f32path_gqa8"])
+@pytest.mark.parametrize("version", ["v1", "v2"])
+def test_paged_attention_golden(gpu_device, name, version):
+    """directly against what the reference's own CPU kernels produced (tests/golden)."""
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    inp = helpers.make_paged_attention_inputs(
+        int(g["seed"]), int(g["num_seqs"]), (int(g["num_q_heads"]), int(g["num_kv_heads"])),
+        int(g["head_size"]), int(g["block_size"]), torch.bfloat16,
+        seq_lens=[int(v) for v in g["seq_lens"]], num_blocks=256, use_alibi=bool(g["use_alibi"]))
+    assert helpers.tensor_sha(inp["query"], inp["key_cache"], inp["value_cache"],
+                              inp["block_tables"]) == str(g["input_sha"])
+    out, _ = run_hip(inp, version, gpu_device)
+    ref = helpers.from_np(g["out_" + version], torch.bfloat16)
+    check(out, ref, atol=1e-3, rtol=1e-2)
+
+
+def test_unsupported_configs_raise(gpu_device):
+    from neural_magic_vllm_amd import _custom_ops as ops
+    inp = helpers.make_paged_attention_inputs(0, 2, (4, 4), 128, 16, torch.bfloat16,
+                                              seq_lens=[10, 20], num_blocks=16)
+    q = inp["query"].to(gpu_device)
+    kc, vc = inp["key_cache"].to(gpu_device), inp["value_cache"].to(gpu_device)
+    bt, sl = inp["block_tables"].to(gpu_device), inp["seq_lens"].to(gpu_device)
+    out = torch.empty_like(q)
+    with pytest.raises(RuntimeError, match="kv cache"):
+        ops.paged_attention_v1(out, q, kc, vc, 4, 0.1, bt, sl, 16, 20, None, "fp8_e5m2", 1.0)
+    with pytest.raises(RuntimeError, match="block size"):
+        ops.paged_attention_v1(out, q, kc, vc, 4, 0.1, bt, sl, 24, 20, None, "auto", 1.0)
+    q72 = torch.zeros((2, 4, 72), dtype=torch.bfloat16, device=gpu_device)
+    with pytest.raises(RuntimeError, match="head size"):
+        ops.paged_attention_v1(torch.empty_like(q72), q72, kc, vc, 4, 0.1, bt, sl, 16, 20, None,
+                               "auto", 1.0)
