@@ -7,6 +7,11 @@
 // (e.g. rms_norm rounds x*rsqrt(var) to the model dtype BEFORE multiplying by the weight).
 #include "common.h"
 
+// The reference rounds every intermediate to the model dtype (c10::Half / c10::BFloat16
+// operators).  With contraction on, hipcc folds the fp16 paths into v_fma_f16 and skips one of
+// those roundings -- keep the arithmetic exactly as written.
+#pragma clang fp contract(off)
+
 namespace nmv {
 
 template <typename T>

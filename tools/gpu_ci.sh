@@ -1,0 +1,26 @@
+#!/bin/bash
+# Runs the GPU steps one after another on the gpurun box, each under its own timeout, logging to
+# gpurun_out/.  A step that times out or is killed stops the chain (no further GPU step);
+# ordinary test failures do not.
+mkdir -p gpurun_out
+TMO=${TMO:-900}
+run() {
+  name=$1; shift
+  timeout -k 10 "$TMO" "$@" > "gpurun_out/$name.log" 2>&1
+  rc=$?
+  echo "== $name rc=$rc"; tail -n "${TAILN:-4}" "gpurun_out/$name.log"
+  if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "STOP: $name timed out / was killed"; exit 1; fi
+}
+for step in "$@"; do
+  case "$step" in
+    info)   run info bash -c 'rocminfo | grep -E "Marketing|Compute Unit|Max Clock" | head -8; nproc; lscpu | grep "Model name"; free -g | head -2' ;;
+    smoke)  run smoke python -c 'import __graft_entry__ as g; g.smoke()' ;;
+    cache)  run t_cache python -m pytest tests/test_gpu_cache.py -q -m gpu -x --timeout 120 ;;
+    glue)   run t_glue python -m pytest tests/test_gpu_glue.py -q -m gpu --timeout 120 ;;
+    attn)   run t_attn python -m pytest tests/test_gpu_attention.py -q -m gpu --timeout 180 ;;
+    w4)     run t_w4 python -m pytest tests/test_gpu_w4a16.py -q -m gpu --timeout 300 ;;
+    all)    run t_all python -m pytest tests -q -m gpu --timeout 300 ;;
+    bench)  run bench python bench.py ;;
+    *)      echo "unknown step $step" ;;
+  esac
+done
