@@ -1,0 +1,215 @@
+"""bench.py -- decode tokens/s of Llama-3-8B w4a16 (GPTQ g128, marlin format) on MI355X.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched
+through torch.distributed.run with one rank per GPU (tensor parallel over RCCL/xGMI).  Rank 0
+prints ONE JSON line.  A "step" is one decode step of the whole model for a batch of B
+sequences (embedding, 32 decoder layers through the HIP kernels, bf16 lm_head, greedy sample),
+replayed from a captured hipGraph; inputs (weights, KV cache with `context` tokens per
+sequence) are resident in HBM before the timed region.
+
+Extra objects on the line:
+  roofline     -- dominant kernel = the W4A16 GEMM (w4a16_gemm_kernel): algorithmic bytes of the
+                  4 GEMMs of a layer / mean device time of those launches, measured with HIP
+                  events on the launch stream in a separate loop of the same kernels.
+  cpu_baseline -- the oracle (oracle/oracle.c, OpenMP) on the host cores: one decoder layer's
+                  dequant+GEMMs and paged attention for the same batch, scaled to a full step.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("NMV_BENCH_BATCH", 64)))
+    ap.add_argument("--context", type=int, default=512)
+    ap.add_argument("--model", default="llama3-8b")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sweep", action="store_true")
+    ap.add_argument("--kv-cache-dtype", default="auto")
+    return ap.parse_args()
+
+
+def gemm_roofline(runner, batch, dev, iters=30):
+    """HIP-event timing of the dominant kernel on its launch stream: the 4 quantised GEMMs of
+    one decoder layer at M = batch, back to back (each call = GEMM kernel [+ split-K reduce])."""
+    from neural_magic_vllm_amd import _custom_ops as ops
+    layer = runner.model.model.layers[0]
+    mods = [layer.self_attn.qkv_proj, layer.self_attn.o_proj, layer.mlp.gate_up_proj,
+            layer.mlp.down_proj]
+    xs = [torch.randn((batch, m.input_size_per_partition), device=dev, dtype=runner.dtype)
+          for m in mods]
+    # rotate over all layers so that weights come from HBM, not from the 256 MiB Infinity Cache
+    layers = runner.model.model.layers
+
+    def run(li):
+        L = layers[li % len(layers)]
+        for m, x in zip([L.self_attn.qkv_proj, L.self_attn.o_proj, L.mlp.gate_up_proj,
+                         L.mlp.down_proj], xs):
+            ops.gptq_marlin_gemm(x, m.qweight, m.scales, m.g_idx, m.g_idx_sort_indices,
+                                 m.workspace, 4, batch, m.output_size_per_partition,
+                                 m.input_size_per_partition, m.is_k_full)
+
+    alg = 0
+    for m in mods:
+        k, n = m.input_size_per_partition, m.output_size_per_partition
+        alg += k * n // 2 + m.scales.numel() * 2 + 2 * batch * k + 2 * batch * n
+    for i in range(len(layers)):
+        run(i)
+    torch.cuda.synchronize(dev)
+    stream = torch.cuda.current_stream(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for i in range(iters):
+        run(i)
+    e1.record(stream)
+    torch.cuda.synchronize(dev)
+    ms = e0.elapsed_time(e1) / iters
+    achieved = alg / (ms * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": "w4a16_gemm_kernel (4 GEMMs of one decoder layer)",
+            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+            "algorithmic_bytes_per_launch_group": alg, "avg_us_per_launch_group": round(ms * 1e3, 2)}
+
+
+def cpu_baseline(arch, batch, context, budget_s=20.0):
+    """the CPU oracle on the host cores: one decoder layer (4 dequant+GEMMs at M=batch and paged
+    attention over `context` tokens), extrapolated to the whole step (layers x + lm_head)."""
+    import helpers
+    import oracle
+    from oracle import ref_math
+    cores = os.cpu_count() or 1
+    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    oracle.build()
+    h, inter, hd = arch.hidden_size, arch.intermediate_size, arch.head_dim
+    nq, nkv = arch.num_attention_heads, arch.num_key_value_heads
+    shapes = [(h, (nq + 2 * nkv) * hd), (nq * hd, h), (h, 2 * inter), (inter, h)]
+    g = torch.Generator().manual_seed(0)
+    t_layer = 0.0
+    for k, n in shapes:
+        q_w = torch.randint(0, 16, (k, n), generator=g, dtype=torch.int32)
+        mq = ref_math.marlin_weights(q_w, k, n, 4)
+        s = (torch.rand((k // 128, n), generator=g) * 0.01 + 0.001).to(torch.bfloat16)
+        ms = ref_math.marlin_permute_scales(s, k, n, 128)
+        a = torch.randn((batch, k), generator=g).to(torch.bfloat16)
+        t0 = time.perf_counter()
+        oracle.gptq_marlin_gemm(a, mq, ms, None, None, 4, batch, n, k)
+        t_layer += time.perf_counter() - t0
+        if t_layer > budget_s:
+            break
+    nblk = batch * ((context + 15) // 16) + 8
+    inp = helpers.make_paged_attention_inputs(0, batch, (nq, nkv), hd, 16, torch.bfloat16,
+                                              seq_lens=[context] * batch, num_blocks=nblk)
+    t0 = time.perf_counter()
+    oracle.paged_attention(inp["query"], inp["key_cache"], inp["value_cache"], nkv, inp["scale"],
+                           inp["block_tables"], inp["seq_lens"], 16)
+    t_attn = time.perf_counter() - t0
+    step_s = (t_layer + t_attn) * arch.num_hidden_layers
+    return {"value": round(batch / step_s, 3), "unit": "tokens/s", "cores": cores, "kind": "port",
+            "sample": (f"oracle.c (OpenMP) timed on ONE decoder layer: 4 dequant+GEMMs at M={batch} "
+                       f"and paged attention over {context} tokens x {batch} seqs "
+                       f"({t_layer:.2f}s + {t_attn:.2f}s), x{arch.num_hidden_layers} layers; "
+                       "lm_head and glue not included")}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device(f"cuda:{local_rank}")
+    import torch.distributed as dist
+    from neural_magic_vllm_amd import distributed as nd
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl", device_id=dev)
+        nd.initialize_model_parallel(world, backend="nccl", local_rank=local_rank)
+    from neural_magic_vllm_amd.worker import decode_runner as dr
+    arch = {"llama3-8b": dr.LLAMA3_8B, "llama3-70b": dr.LLAMA3_70B, "tiny": dr.TINY}[args.model]
+    quant = dict(method="gptq_marlin", bits=4, group_size=128)
+    runner = dr.DecodeRunner(arch, dev, torch.bfloat16, quant,
+                             dr.CacheConfig(16, args.kv_cache_dtype))
+
+    def measure(batch, steps, warmup):
+        runner.setup_batch(batch, args.context, steps + warmup + 8)
+        runner.fill_context()
+        graphed = False if args.no_graph else runner.capture()
+        for _ in range(warmup):
+            runner.decode_step()
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            runner.decode_step()
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, graphed
+
+    dt, graphed = measure(args.batch, args.steps, args.warmup)
+    ms_per_step = dt / args.steps * 1e3
+    value = args.batch * args.steps / dt
+
+    out = {
+        "metric": "decode tokens/sec, Llama-3-8B w4a16 (GPTQ-marlin g128), bf16 activations",
+        "value": round(value, 1), "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "bf16",
+        "data": "synthetic (random-init N(0,0.02) weights quantised to int4 g128, random KV context)",
+        "config": {"workload": f"{args.model} w4a16 decode step, batch {args.batch}, "
+                               f"context {args.context} tokens/seq, block 16, kv {args.kv_cache_dtype}",
+                   "global_batch": args.batch, "context_len": args.context,
+                   "parallelism": f"tp{world}", "hip_graph": graphed},
+    }
+    if rank == 0:
+        wb = runner.weight_bytes_per_step()
+        kvb = 2 * args.context * runner.num_kv_heads * arch.head_dim * 2 * args.batch * arch.num_hidden_layers
+        out["step_roofline"] = {"weight_bytes": wb, "kv_bytes": kvb,
+                                "hbm_bound_ms": round((wb + kvb) / (HBM_PEAK_GBS * 1e9) * 1e3, 4),
+                                "frac_of_hbm_bound": round((wb + kvb) / (HBM_PEAK_GBS * 1e9) / (ms_per_step * 1e-3), 4)}
+        out["roofline"] = gemm_roofline(runner, args.batch, dev)
+    if world == 1 and not args.no_sweep:
+        sweep = {}
+        for b in (1, 8, 32):
+            d, _ = measure(b, max(16, args.steps // 2), 4)
+            sweep[str(b)] = round(b * max(16, args.steps // 2) / d, 1)
+        sweep[str(args.batch)] = round(value, 1)
+        out["batch_sweep_tokens_per_s"] = sweep
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            out["cpu_baseline"] = cpu_baseline(arch, args.batch, args.context)
+        except Exception as e:  # the baseline must never take the GPU number down with it
+            out["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": os.cpu_count(),
+                                   "kind": "port", "sample": f"failed: {e!r}"}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        nd.destroy_model_parallel()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,205 @@
+"""The gfx950 attention backend: KV-cache write + decode on the HIP paged-attention kernels.
+
+Mirror of the ROCm backend of the reference, vllm/attention/backends/rocm_flash_attn.py
+(backend :21-54, metadata :57-163, impl :166-456): identical metadata fields, the same
+prefill / decode token split (:333-347) and the same call sequence
+reshape_and_cache -> prefill attention -> PagedAttention.forward_decode (:441).
+Prefill runs the reference's "naive" option (torch SDPA per sequence, :379-403 / :459-491):
+the reference's default there is a Triton kernel, which this build does not ship; a gfx950
+flash-prefill kernel is row (f)-2 of SURVEY.md section 8 (next).
+"""
+from dataclasses import dataclass
+from typing import Any, Dict, List, Optional, Tuple, Type
+
+import torch
+
+from ..ops.paged_attn import PagedAttention, PagedAttentionMetadata
+from .abstract import AttentionBackend, AttentionImpl, AttentionMetadata
+
+
+class ROCmHipAttentionBackend(AttentionBackend):
+
+    @staticmethod
+    def get_name() -> str:
+        return "rocm-hip-attn"
+
+    @staticmethod
+    def get_impl_cls() -> Type["ROCmHipAttentionImpl"]:
+        return ROCmHipAttentionImpl
+
+    @staticmethod
+    def make_metadata(*args, **kwargs) -> "ROCmHipAttentionMetadata":
+        return ROCmHipAttentionMetadata(*args, **kwargs)
+
+    @staticmethod
+    def get_kv_cache_shape(num_blocks: int, block_size: int, num_kv_heads: int,
+                           head_size: int) -> Tuple[int, ...]:
+        return PagedAttention.get_kv_cache_shape(num_blocks, block_size, num_kv_heads, head_size)
+
+    @staticmethod
+    def swap_blocks(src_kv_cache: torch.Tensor, dst_kv_cache: torch.Tensor,
+                    src_to_dst: torch.Tensor) -> None:
+        PagedAttention.swap_blocks(src_kv_cache, dst_kv_cache, src_to_dst)
+
+    @staticmethod
+    def copy_blocks(kv_caches: List[torch.Tensor], src_to_dists: torch.Tensor) -> None:
+        PagedAttention.copy_blocks(kv_caches, src_to_dists)
+
+
+@dataclass
+class ROCmHipAttentionMetadata(AttentionMetadata, PagedAttentionMetadata):
+    """Same fields as ROCmFlashAttentionMetadata (rocm_flash_attn.py:57-108).  Python values here
+    are frozen into a captured HIP graph; anything that changes per step lives in tensors."""
+    seq_lens: Optional[List[int]]
+    seq_lens_tensor: Optional[torch.Tensor]
+    max_query_len: Optional[int]
+    max_prefill_seq_len: int
+    max_decode_seq_len: int
+    query_start_loc: Optional[torch.Tensor]
+    seq_start_loc: Optional[torch.Tensor]
+    use_cuda_graph: bool
+    context_lens_tensor: Optional[torch.Tensor]
+    _cached_prefill_metadata: Optional["ROCmHipAttentionMetadata"] = None
+    _cached_decode_metadata: Optional["ROCmHipAttentionMetadata"] = None
+
+    @property
+    def prefill_metadata(self) -> Optional["ROCmHipAttentionMetadata"]:
+        if self.num_prefills == 0:
+            return None
+        if self._cached_prefill_metadata is None:
+            n = self.num_prefills
+            self._cached_prefill_metadata = ROCmHipAttentionMetadata(
+                num_prefills=n, num_prefill_tokens=self.num_prefill_tokens, num_decode_tokens=0,
+                slot_mapping=self.slot_mapping[:self.num_prefill_tokens],
+                seq_lens=self.seq_lens[:n], seq_lens_tensor=self.seq_lens_tensor[:n],
+                max_query_len=self.max_query_len, max_prefill_seq_len=self.max_prefill_seq_len,
+                max_decode_seq_len=0,
+                query_start_loc=None if self.query_start_loc is None else self.query_start_loc[:n + 1],
+                seq_start_loc=None if self.seq_start_loc is None else self.seq_start_loc[:n + 1],
+                context_lens_tensor=None if self.context_lens_tensor is None
+                else self.context_lens_tensor[:n],
+                block_tables=None if self.block_tables is None else self.block_tables[:n],
+                use_cuda_graph=False)
+        return self._cached_prefill_metadata
+
+    @property
+    def decode_metadata(self) -> Optional["ROCmHipAttentionMetadata"]:
+        if self.num_decode_tokens == 0:
+            return None
+        if self._cached_decode_metadata is None:
+            n = self.num_prefills
+            self._cached_decode_metadata = ROCmHipAttentionMetadata(
+                num_prefills=0, num_prefill_tokens=0, num_decode_tokens=self.num_decode_tokens,
+                slot_mapping=self.slot_mapping[self.num_prefill_tokens:], seq_lens=None,
+                seq_lens_tensor=self.seq_lens_tensor[n:], max_query_len=None,
+                max_prefill_seq_len=0, max_decode_seq_len=self.max_decode_seq_len,
+                query_start_loc=None, seq_start_loc=None, context_lens_tensor=None,
+                block_tables=self.block_tables[n:], use_cuda_graph=self.use_cuda_graph)
+        return self._cached_decode_metadata
+
+
+class ROCmHipAttentionImpl(AttentionImpl):
+    """Layout: |<-- prefill tokens -->|<-- decode tokens -->| in one flattened batch."""
+
+    def __init__(self, num_heads: int, head_size: int, scale: float,
+                 num_kv_heads: Optional[int] = None, alibi_slopes: Optional[List[float]] = None,
+                 sliding_window: Optional[int] = None, kv_cache_dtype: str = "auto",
+                 blocksparse_params: Optional[Dict[str, Any]] = None) -> None:
+        assert blocksparse_params is None, "the gfx950 backend does not support block-sparse attention"
+        if sliding_window is not None:
+            raise NotImplementedError("sliding-window attention is outside the hot-path scope")
+        self.num_heads = num_heads
+        self.head_size = head_size
+        self.scale = float(scale)
+        self.num_kv_heads = num_heads if num_kv_heads is None else num_kv_heads
+        self.alibi_slopes = None if alibi_slopes is None else torch.tensor(alibi_slopes,
+                                                                           dtype=torch.float32)
+        self.kv_cache_dtype = kv_cache_dtype
+        assert self.num_heads % self.num_kv_heads == 0
+        self.num_queries_per_kv = self.num_heads // self.num_kv_heads
+        supported = PagedAttention.get_supported_head_sizes()
+        if head_size not in supported:
+            raise ValueError(f"Head size {head_size} is not supported by PagedAttention. "
+                             f"Supported head sizes are: {supported}.")
+
+    def forward(self, query: torch.Tensor, key: torch.Tensor, value: torch.Tensor,
+                kv_cache: Optional[torch.Tensor], attn_metadata: ROCmHipAttentionMetadata,
+                kv_scale: float = 1.0) -> torch.Tensor:
+        """query [num_tokens, num_heads*head_size], key/value [num_tokens, num_kv_heads*head_size],
+        kv_cache [2, num_blocks, block_size*num_kv_heads*head_size] -> [num_tokens, hidden]"""
+        num_tokens, hidden_size = query.shape
+        query = query.view(-1, self.num_heads, self.head_size)
+        key = key.view(-1, self.num_kv_heads, self.head_size)
+        value = value.view(-1, self.num_kv_heads, self.head_size)
+        if self.alibi_slopes is not None and self.alibi_slopes.device != query.device:
+            self.alibi_slopes = self.alibi_slopes.to(query.device)
+
+        key_cache = value_cache = None
+        if kv_cache is not None:
+            key_cache, value_cache = PagedAttention.split_kv_cache(kv_cache, self.num_kv_heads,
+                                                                   self.head_size)
+            PagedAttention.write_to_paged_cache(key, value, key_cache, value_cache,
+                                                attn_metadata.slot_mapping, self.kv_cache_dtype,
+                                                kv_scale)
+
+        num_prefill_tokens = attn_metadata.num_prefill_tokens
+        num_decode_tokens = attn_metadata.num_decode_tokens
+        assert key.shape[0] == num_prefill_tokens + num_decode_tokens
+
+        if attn_metadata.prefill_metadata is None and num_decode_tokens == num_tokens:
+            # decode-only batch (the hot path): no scatter into a separate output buffer
+            dm = attn_metadata.decode_metadata
+            out = PagedAttention.forward_decode(query, key_cache, value_cache, dm.block_tables,
+                                                dm.seq_lens_tensor, dm.max_decode_seq_len,
+                                                self.kv_cache_dtype, self.num_kv_heads, self.scale,
+                                                self.alibi_slopes, kv_scale)
+            return out.view(num_tokens, hidden_size)
+
+        output = torch.empty((num_tokens, self.num_heads, self.head_size), dtype=query.dtype,
+                             device=query.device)
+        decode_query = query[num_prefill_tokens:]
+        if (pm := attn_metadata.prefill_metadata) is not None:
+            assert pm.seq_lens is not None
+            if pm.context_lens_tensor is not None and kv_cache is not None \
+                    and pm.block_tables is not None and pm.block_tables.numel() > 0 \
+                    and bool((pm.context_lens_tensor > 0).any()):
+                raise NotImplementedError("prefix-enabled prefill is outside the hot-path scope")
+            output[:num_prefill_tokens] = _sdpa_prefill(query[:num_prefill_tokens],
+                                                        key[:num_prefill_tokens],
+                                                        value[:num_prefill_tokens], pm.seq_lens,
+                                                        self.num_queries_per_kv, self.scale,
+                                                        self.alibi_slopes)
+        if (dm := attn_metadata.decode_metadata) is not None:
+            output[num_prefill_tokens:] = PagedAttention.forward_decode(
+                decode_query, key_cache, value_cache, dm.block_tables, dm.seq_lens_tensor,
+                dm.max_decode_seq_len, self.kv_cache_dtype, self.num_kv_heads, self.scale,
+                self.alibi_slopes, kv_scale)
+        return output.view(num_tokens, hidden_size)
+
+
+def _sdpa_prefill(query: torch.Tensor, key: torch.Tensor, value: torch.Tensor,
+                  seq_lens: List[int], num_queries_per_kv: int, scale: float,
+                  alibi_slopes: Optional[torch.Tensor]) -> torch.Tensor:
+    """causal attention per prompt with torch SDPA (rocm_flash_attn.py:459-491)"""
+    out = torch.empty_like(query)
+    start = 0
+    for seq_len in seq_lens:
+        end = start + seq_len
+        q = query[start:end].movedim(0, 1)  # [H, L, D]
+        k = key[start:end].movedim(0, 1)
+        v = value[start:end].movedim(0, 1)
+        if num_queries_per_kv > 1:
+            k = k.repeat_interleave(num_queries_per_kv, dim=0)
+            v = v.repeat_interleave(num_queries_per_kv, dim=0)
+        mask = None
+        if alibi_slopes is not None:
+            pos = torch.arange(seq_len, device=query.device)
+            bias = (pos[None, :] - pos[:, None]).to(query.dtype)
+            mask = alibi_slopes.to(query.dtype)[:, None, None] * bias[None]
+            mask = mask + torch.full((seq_len, seq_len), float("-inf"), device=query.device,
+                                     dtype=query.dtype).triu(1)[None]
+        o = torch.nn.functional.scaled_dot_product_attention(q, k, v, attn_mask=mask,
+                                                             is_causal=mask is None, scale=scale)
+        out[start:end] = o.movedim(0, 1)
+        start = end
+    return out

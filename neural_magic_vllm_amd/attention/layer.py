@@ -1,0 +1,45 @@
+"""Attention layer (reference: vllm/attention/layer.py:16-103)."""
+from typing import Any, Dict, List, Optional
+
+import torch
+import torch.nn as nn
+
+from .backends.abstract import AttentionMetadata
+from .selector import get_attn_backend
+
+
+class Attention(nn.Module):
+    """Multi-head / grouped-query attention over the paged KV cache:
+    1. store the new keys/values in the cache, 2. attend, 3. return the output."""
+
+    def __init__(self, num_heads: int, head_size: int, scale: float,
+                 num_kv_heads: Optional[int] = None, alibi_slopes: Optional[List[float]] = None,
+                 cache_config: Optional[Any] = None, quant_config: Optional[Any] = None,
+                 blocksparse_params: Optional[Dict[str, Any]] = None) -> None:
+        super().__init__()
+        kv_cache_dtype = getattr(cache_config, "cache_dtype", "auto") if cache_config else "auto"
+        block_size = getattr(cache_config, "block_size", 16) if cache_config else 16
+        sliding_window = getattr(cache_config, "sliding_window", None) if cache_config else None
+        if num_kv_heads is None:
+            num_kv_heads = num_heads
+        # The scaling factor of an fp8 KV cache; loaded from the checkpoint when present
+        # (reference: layer.py:49-68, fp8.py Fp8KVCacheMethod).  gfx950 uses OCP e4m3, so there
+        # is no x2 correction as on MI300 (llama.py:503-508 of the reference).
+        self.kv_cache_dtype = kv_cache_dtype
+        self._kv_scale = 1.0
+        dtype = torch.get_default_dtype()
+        attn_backend = get_attn_backend(num_heads, head_size, num_kv_heads, sliding_window, dtype,
+                                        kv_cache_dtype, block_size, blocksparse_params is not None)
+        impl_cls = attn_backend.get_impl_cls()
+        self.backend = attn_backend
+        self.impl = impl_cls(num_heads, head_size, scale, num_kv_heads, alibi_slopes,
+                             sliding_window, kv_cache_dtype, blocksparse_params)
+
+    def forward(self, query: torch.Tensor, key: torch.Tensor, value: torch.Tensor,
+                kv_cache: Optional[torch.Tensor], attn_metadata: AttentionMetadata) -> torch.Tensor:
+        return self.impl.forward(query, key, value, kv_cache, attn_metadata, self._kv_scale)
+
+    def extra_repr(self) -> str:
+        return (f"head_size={self.impl.head_size}, num_heads={self.impl.num_heads}, "
+                f"num_kv_heads={self.impl.num_kv_heads}, scale={self.impl.scale}, "
+                f"backend={self.impl.__class__.__name__}")

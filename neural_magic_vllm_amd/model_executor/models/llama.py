@@ -1,0 +1,208 @@
+"""Llama decoder on the gfx950 hot path -- the harness that drives the kernels end to end.
+
+Structure follows vllm/model_executor/models/llama.py of the reference: LlamaMLP (:51-85),
+LlamaAttention (:88-166), LlamaDecoderLayer (:169-241), LlamaModel (:244-321),
+LlamaForCausalLM (:324-515): fused qkv / gate_up projections through the LinearMethod plugin
+surface, rope in place on the q/k slices, attention through the Attention layer, residual
+carried through fused_add_rms_norm.  Checkpoint name mapping, LoRA, pipeline parallelism and
+rope scaling are outside the hot-path scope.
+"""
+from typing import Any, Iterable, List, Optional, Tuple
+
+import torch
+from torch import nn
+
+from ...attention import Attention, AttentionMetadata
+from ...distributed import get_tensor_model_parallel_world_size
+from ..layers.activation import SiluAndMul
+from ..layers.layernorm import RMSNorm
+from ..layers.linear import MergedColumnParallelLinear, QKVParallelLinear, RowParallelLinear
+from ..layers.logits_processor import LogitsProcessor
+from ..layers.quantization.base_config import QuantizationConfig
+from ..layers.rotary_embedding import get_rope
+from ..layers.vocab_parallel_embedding import ParallelLMHead, VocabParallelEmbedding
+
+
+class LlamaMLP(nn.Module):
+
+    def __init__(self, hidden_size: int, intermediate_size: int, hidden_act: str,
+                 quant_config: Optional[QuantizationConfig] = None, bias: bool = False) -> None:
+        super().__init__()
+        self.gate_up_proj = MergedColumnParallelLinear(input_size=hidden_size,
+                                                       output_sizes=[intermediate_size] * 2,
+                                                       bias=bias, quant_config=quant_config)
+        self.down_proj = RowParallelLinear(input_size=intermediate_size, output_size=hidden_size,
+                                           bias=bias, quant_config=quant_config)
+        if hidden_act != "silu":
+            raise ValueError(f"Unsupported activation: {hidden_act}. Only silu is supported for now.")
+        self.act_fn = SiluAndMul()
+
+    def forward(self, x):
+        gate_up, _ = self.gate_up_proj(x)
+        x = self.act_fn(gate_up)
+        x, _ = self.down_proj(x)
+        return x
+
+
+class LlamaAttention(nn.Module):
+
+    def __init__(self, config, hidden_size: int, num_heads: int, num_kv_heads: int,
+                 rope_theta: float = 10000, rope_scaling: Optional[dict] = None,
+                 max_position_embeddings: int = 8192,
+                 quant_config: Optional[QuantizationConfig] = None, bias: bool = False,
+                 cache_config: Optional[Any] = None) -> None:
+        super().__init__()
+        self.hidden_size = hidden_size
+        tp_size = get_tensor_model_parallel_world_size()
+        self.total_num_heads = num_heads
+        assert self.total_num_heads % tp_size == 0
+        self.num_heads = self.total_num_heads // tp_size
+        self.total_num_kv_heads = num_kv_heads
+        if self.total_num_kv_heads >= tp_size:
+            assert self.total_num_kv_heads % tp_size == 0
+        else:
+            # fewer KV heads than ranks: replicate them (llama.py:109-117)
+            assert tp_size % self.total_num_kv_heads == 0
+        self.num_kv_heads = max(1, self.total_num_kv_heads // tp_size)
+        self.head_dim = getattr(config, "head_dim", None) or self.hidden_size // self.total_num_heads
+        self.q_size = self.num_heads * self.head_dim
+        self.kv_size = self.num_kv_heads * self.head_dim
+        self.scaling = self.head_dim**-0.5
+        self.qkv_proj = QKVParallelLinear(hidden_size=hidden_size, head_size=self.head_dim,
+                                          total_num_heads=self.total_num_heads,
+                                          total_num_kv_heads=self.total_num_kv_heads, bias=bias,
+                                          quant_config=quant_config)
+        self.o_proj = RowParallelLinear(input_size=self.total_num_heads * self.head_dim,
+                                        output_size=hidden_size, bias=bias,
+                                        quant_config=quant_config)
+        self.rotary_emb = get_rope(self.head_dim, rotary_dim=self.head_dim,
+                                   max_position=max_position_embeddings, base=rope_theta,
+                                   rope_scaling=rope_scaling)
+        self.attn = Attention(self.num_heads, self.head_dim, self.scaling,
+                              num_kv_heads=self.num_kv_heads, cache_config=cache_config,
+                              quant_config=quant_config)
+
+    def forward(self, positions: torch.Tensor, hidden_states: torch.Tensor,
+                kv_cache: Optional[torch.Tensor], attn_metadata: AttentionMetadata) -> torch.Tensor:
+        qkv, _ = self.qkv_proj(hidden_states)
+        q, k, v = qkv.split([self.q_size, self.kv_size, self.kv_size], dim=-1)
+        q, k = self.rotary_emb(positions, q, k)
+        attn_output = self.attn(q, k, v, kv_cache, attn_metadata)
+        output, _ = self.o_proj(attn_output)
+        return output
+
+
+class LlamaDecoderLayer(nn.Module):
+
+    def __init__(self, config, cache_config: Optional[Any] = None,
+                 quant_config: Optional[QuantizationConfig] = None) -> None:
+        super().__init__()
+        self.hidden_size = config.hidden_size
+        rope_theta = getattr(config, "rope_theta", 10000)
+        rope_scaling = getattr(config, "rope_scaling", None)
+        max_position_embeddings = getattr(config, "max_position_embeddings", 8192)
+        attention_bias = getattr(config, "attention_bias", False) or getattr(config, "bias", False)
+        self.self_attn = LlamaAttention(
+            config=config, hidden_size=self.hidden_size, num_heads=config.num_attention_heads,
+            num_kv_heads=getattr(config, "num_key_value_heads", config.num_attention_heads),
+            rope_theta=rope_theta, rope_scaling=rope_scaling,
+            max_position_embeddings=max_position_embeddings, quant_config=quant_config,
+            bias=attention_bias, cache_config=cache_config)
+        self.mlp = LlamaMLP(hidden_size=self.hidden_size,
+                            intermediate_size=config.intermediate_size,
+                            hidden_act=config.hidden_act, quant_config=quant_config,
+                            bias=getattr(config, "mlp_bias", False))
+        self.input_layernorm = RMSNorm(config.hidden_size, eps=config.rms_norm_eps)
+        self.post_attention_layernorm = RMSNorm(config.hidden_size, eps=config.rms_norm_eps)
+
+    def forward(self, positions: torch.Tensor, hidden_states: torch.Tensor,
+                kv_cache: Optional[torch.Tensor], attn_metadata: AttentionMetadata,
+                residual: Optional[torch.Tensor]) -> Tuple[torch.Tensor, torch.Tensor]:
+        if residual is None:
+            residual = hidden_states
+            hidden_states = self.input_layernorm(hidden_states)
+        else:
+            hidden_states, residual = self.input_layernorm(hidden_states, residual)
+        hidden_states = self.self_attn(positions=positions, hidden_states=hidden_states,
+                                       kv_cache=kv_cache, attn_metadata=attn_metadata)
+        hidden_states, residual = self.post_attention_layernorm(hidden_states, residual)
+        hidden_states = self.mlp(hidden_states)
+        return hidden_states, residual
+
+
+class LlamaModel(nn.Module):
+
+    def __init__(self, config, cache_config: Optional[Any] = None,
+                 quant_config: Optional[QuantizationConfig] = None) -> None:
+        super().__init__()
+        self.config = config
+        self.vocab_size = config.vocab_size
+        self.embed_tokens = VocabParallelEmbedding(self.vocab_size, config.hidden_size,
+                                                   org_num_embeddings=config.vocab_size)
+        self.layers = nn.ModuleList([LlamaDecoderLayer(config, cache_config, quant_config)
+                                     for _ in range(config.num_hidden_layers)])
+        self.norm = RMSNorm(config.hidden_size, eps=config.rms_norm_eps)
+
+    def forward(self, input_ids: Optional[torch.Tensor], positions: torch.Tensor,
+                kv_caches: List[Optional[torch.Tensor]], attn_metadata: AttentionMetadata,
+                inputs_embeds: Optional[torch.Tensor] = None) -> torch.Tensor:
+        hidden_states = inputs_embeds if inputs_embeds is not None else self.embed_tokens(input_ids)
+        residual = None
+        for i, layer in enumerate(self.layers):
+            hidden_states, residual = layer(positions, hidden_states, kv_caches[i], attn_metadata,
+                                            residual)
+        hidden_states, _ = self.norm(hidden_states, residual)
+        return hidden_states
+
+
+class LlamaForCausalLM(nn.Module):
+
+    def __init__(self, config, cache_config: Optional[Any] = None,
+                 quant_config: Optional[QuantizationConfig] = None) -> None:
+        super().__init__()
+        self.config = config
+        self.model = LlamaModel(config, cache_config, quant_config)
+        self.unpadded_vocab_size = config.vocab_size
+        # bf16 unless quant_config.lm_head_quantized (gptq_marlin.py:151-157)
+        self.lm_head = ParallelLMHead(self.unpadded_vocab_size, config.hidden_size,
+                                      org_num_embeddings=config.vocab_size)
+        self.logits_processor = LogitsProcessor(self.unpadded_vocab_size, config.vocab_size,
+                                                getattr(config, "logit_scale", 1.0))
+
+    def forward(self, input_ids: torch.Tensor, positions: torch.Tensor,
+                kv_caches: List[Optional[torch.Tensor]],
+                attn_metadata: AttentionMetadata) -> torch.Tensor:
+        return self.model(input_ids, positions, kv_caches, attn_metadata)
+
+    def compute_logits(self, hidden_states: torch.Tensor) -> Optional[torch.Tensor]:
+        return self.logits_processor(self.lm_head.weight, hidden_states)
+
+    def load_weights(self, weights: Iterable[Tuple[str, torch.Tensor]]):
+        """stacked-parameter mapping of the reference (llama.py:391-460): q/k/v -> qkv_proj,
+        gate/up -> gate_up_proj; everything else by name."""
+        stacked = [(".qkv_proj", ".q_proj", "q"), (".qkv_proj", ".k_proj", "k"),
+                   (".qkv_proj", ".v_proj", "v"), (".gate_up_proj", ".gate_proj", 0),
+                   (".gate_up_proj", ".up_proj", 1)]
+        params = dict(self.named_parameters())
+        for name, loaded in weights:
+            if "rotary_emb.inv_freq" in name:
+                continue
+            for pname, wname, shard_id in stacked:
+                if wname not in name:
+                    continue
+                name = name.replace(wname, pname)
+                if name not in params:
+                    break
+                param = params[name]
+                param.weight_loader(param, loaded, shard_id)
+                break
+            else:
+                if name not in params:
+                    continue
+                param = params[name]
+                loader = getattr(param, "weight_loader", None)
+                if loader is not None:
+                    loader(param, loaded)
+                else:
+                    assert param.shape == loaded.shape, name
+                    param.data.copy_(loaded)

@@ -1,0 +1,297 @@
+"""Decode-loop harness: the minimum of the reference's worker / model-runner / cache-engine that is
+needed to drive the hot path end to end with synthetic weights.
+
+What it reproduces (and nothing more):
+  * KV-cache allocation per layer, shape [2, num_blocks, block_size*kv_heads*head_size]
+    (vllm/worker/cache_engine.py:70-88, PagedAttention.get_kv_cache_shape);
+  * the per-step inputs of ModelRunner._prepare_model_input_tensors (vllm/worker/model_runner.py:
+    332-640): input_ids, positions, slot_mapping (slot = block_table[pos // bs] * bs + pos % bs,
+    :572-580), seq_lens, block_tables and the attention metadata;
+  * greedy sampling of the next token (argmax of the logits);
+  * hipGraph capture of one decode step (the reference captures decode batches in
+    CUDAGraphRunner, model_runner.py:910-1118; torch.cuda.CUDAGraph is hipGraph on ROCm).
+    The captured step also advances positions / seq_lens / slot_mapping ON DEVICE, so a whole
+    decode loop replays without host work.
+There is no scheduler, block manager, tokenizer or checkpoint loader: those sit above the
+drop-in boundary and stay the reference's own.
+"""
+import time
+from dataclasses import dataclass
+from typing import List, Optional
+
+import torch
+
+from ..attention.backends.rocm_hip_attn import ROCmHipAttentionMetadata
+from ..distributed import (get_tensor_model_parallel_rank, get_tensor_model_parallel_world_size,
+                           tensor_model_parallel_all_gather)
+from ..model_executor.layers.quantization import get_quantization_config
+from ..model_executor.models.llama import LlamaForCausalLM
+
+
+@dataclass
+class LlamaArch:
+    hidden_size: int
+    intermediate_size: int
+    num_hidden_layers: int
+    num_attention_heads: int
+    num_key_value_heads: int
+    vocab_size: int
+    rms_norm_eps: float = 1e-5
+    rope_theta: float = 500000.0
+    max_position_embeddings: int = 8192
+    hidden_act: str = "silu"
+    rope_scaling: Optional[dict] = None
+
+    @property
+    def head_dim(self):
+        return self.hidden_size // self.num_attention_heads
+
+
+LLAMA3_8B = LlamaArch(4096, 14336, 32, 32, 8, 128256)
+LLAMA3_70B = LlamaArch(8192, 28672, 80, 64, 8, 128256)
+TINY = LlamaArch(512, 1024, 2, 8, 2, 2048)
+
+
+@dataclass
+class CacheConfig:
+    block_size: int = 16
+    cache_dtype: str = "auto"
+    sliding_window: Optional[int] = None
+
+
+def gptq_quantize_on_device(w: torch.Tensor, bits: int, group_size: int):
+    """Symmetric group quantisation + GPTQ packing with torch ops on the weight's device
+    (the semantics of the reference's quantize_weights / gptq_pack, quant_utils.py:39-146).
+    Host-side setup of synthetic checkpoints: plumbing, not the measured path."""
+    k, n = w.shape
+    gs = k if group_size == -1 else group_size
+    maxq = 2**bits - 1
+    half = (maxq + 1) // 2
+    wg = w.float().reshape(k // gs, gs, n)
+    s = wg.abs().amax(dim=1, keepdim=True).clamp_min(1e-8) * (2.0 / maxq)
+    q = torch.clamp(torch.round(wg / s) + half, 0, maxq).to(torch.int64).reshape(k, n)
+    pf = 32 // bits
+    shifts = (torch.arange(pf, device=w.device, dtype=torch.int64) * bits).view(1, pf, 1)
+    packed = (q.view(k // pf, pf, n) << shifts).sum(dim=1)
+    packed = torch.where(packed >= 2**31, packed - 2**32, packed).to(torch.int32)
+    g_idx = (torch.arange(k, device=w.device, dtype=torch.int32) // gs)
+    return packed, s.reshape(k // gs, n).to(w.dtype), g_idx
+
+
+def synthetic_llama_weights(arch: LlamaArch, dtype: torch.dtype, device, quant: Optional[dict],
+                            seed: int = 0):
+    """Yields (checkpoint-style name, tensor) for a random-init Llama: W ~ N(0, 0.02^2)
+    (BASELINE.md section 3), quantised to GPTQ int4 when `quant` is given.  Every TP rank
+    generates the same full tensors (same seeds) and keeps its shard through the weight loaders."""
+    gen = torch.Generator(device=device)
+    h, inter, hd = arch.hidden_size, arch.intermediate_size, arch.head_dim
+    nq, nkv = arch.num_attention_heads, arch.num_key_value_heads
+
+    def dense(name, out_f, in_f, sd):
+        gen.manual_seed(seed * 100003 + sd)
+        w = torch.randn((out_f, in_f), generator=gen, device=device, dtype=torch.float32) * 0.02
+        return name, w.to(dtype)
+
+    def linear(prefix, out_f, in_f, sd):
+        gen.manual_seed(seed * 100003 + sd)
+        # GPTQ stores W^T: [in_features, out_features]
+        w = (torch.randn((in_f, out_f), generator=gen, device=device, dtype=torch.float32) * 0.02)
+        if quant is None:
+            yield prefix + ".weight", w.t().contiguous().to(dtype)
+            return
+        qw, s, g_idx = gptq_quantize_on_device(w.to(dtype), quant["bits"], quant["group_size"])
+        yield prefix + ".qweight", qw
+        yield prefix + ".scales", s
+        yield prefix + ".g_idx", g_idx
+
+    yield dense("model.embed_tokens.weight", arch.vocab_size, h, 1)
+    for i in range(arch.num_hidden_layers):
+        p = f"model.layers.{i}."
+        yield from linear(p + "self_attn.q_proj", nq * hd, h, 10 + 16 * i)
+        yield from linear(p + "self_attn.k_proj", nkv * hd, h, 11 + 16 * i)
+        yield from linear(p + "self_attn.v_proj", nkv * hd, h, 12 + 16 * i)
+        yield from linear(p + "self_attn.o_proj", h, nq * hd, 13 + 16 * i)
+        yield from linear(p + "mlp.gate_proj", inter, h, 14 + 16 * i)
+        yield from linear(p + "mlp.up_proj", inter, h, 15 + 16 * i)
+        yield from linear(p + "mlp.down_proj", h, inter, 16 + 16 * i)
+        yield p + "input_layernorm.weight", torch.ones(h, dtype=dtype, device=device)
+        yield p + "post_attention_layernorm.weight", torch.ones(h, dtype=dtype, device=device)
+    yield "model.norm.weight", torch.ones(h, dtype=dtype, device=device)
+    yield dense("lm_head.weight", arch.vocab_size, h, 2)
+
+
+class DecodeRunner:
+    """One model replica (or TP shard) + its KV cache + a captured decode step."""
+
+    def __init__(self, arch: LlamaArch, device: torch.device, dtype: torch.dtype = torch.bfloat16,
+                 quant: Optional[dict] = None, cache_config: Optional[CacheConfig] = None,
+                 seed: int = 0, weights=None):
+        self.arch = arch
+        self.device = device
+        self.dtype = dtype
+        self.cache_config = cache_config or CacheConfig()
+        self.tp_size = get_tensor_model_parallel_world_size()
+        self.tp_rank = get_tensor_model_parallel_rank()
+        quant_config = None
+        if quant is not None:
+            quant_config = get_quantization_config(quant.get("method", "gptq_marlin")).from_config(
+                dict(bits=quant["bits"], group_size=quant["group_size"],
+                     desc_act=quant.get("desc_act", False), sym=True))
+        prev = torch.get_default_dtype()
+        torch.set_default_dtype(dtype)
+        try:
+            with torch.device(device):
+                self.model = LlamaForCausalLM(arch, self.cache_config, quant_config)
+        finally:
+            torch.set_default_dtype(prev)
+        if weights is None:
+            weights = synthetic_llama_weights(arch, dtype, device, quant, seed)
+        self.model.load_weights(weights)
+        for m in self.model.modules():
+            qm = getattr(m, "quant_method", None)
+            if qm is not None:
+                qm.process_weights_after_loading(m)
+        self.num_kv_heads = max(1, arch.num_key_value_heads // self.tp_size)
+        self.num_heads = arch.num_attention_heads // self.tp_size
+        self.kv_caches: List[torch.Tensor] = []
+        self.graph = None
+
+    # ------------------------------------------------------------------ KV cache
+    def allocate_kv_cache(self, num_blocks: int) -> None:
+        bs = self.cache_config.block_size
+        cdt = torch.uint8 if self.cache_config.cache_dtype != "auto" else self.dtype
+        shape = (2, num_blocks, bs * self.num_kv_heads * self.arch.head_dim)
+        self.kv_caches = [torch.zeros(shape, dtype=cdt, device=self.device)
+                          for _ in range(self.arch.num_hidden_layers)]
+        self.num_blocks = num_blocks
+
+    # ------------------------------------------------------------------ batch state
+    def setup_batch(self, batch: int, context_len: int, max_new_tokens: int, seed: int = 0) -> None:
+        """`batch` sequences that each already hold `context_len` tokens in the cache; block tables
+        are a random permutation of the block ids."""
+        bs = self.cache_config.block_size
+        self.batch = batch
+        self.max_seq_len = context_len + max_new_tokens
+        blocks_per_seq = (self.max_seq_len + bs - 1) // bs
+        need = batch * blocks_per_seq
+        if not self.kv_caches or self.num_blocks < need:
+            self.allocate_kv_cache(need + need // 4 + 1)
+        g = torch.Generator().manual_seed(seed)
+        perm = torch.randperm(self.num_blocks, generator=g)[:need].to(torch.int32)
+        self.block_tables = perm.view(batch, blocks_per_seq).to(self.device)
+        self.input_ids = torch.randint(0, self.arch.vocab_size, (batch, ), generator=g).to(self.device)
+        # the token being decoded sits at position context_len (0-based); its K/V is written first
+        self.positions = torch.full((batch, ), context_len, dtype=torch.int64, device=self.device)
+        self.seq_lens = torch.full((batch, ), context_len + 1, dtype=torch.int32, device=self.device)
+        self.slot_mapping = torch.empty((batch, ), dtype=torch.int64, device=self.device)
+        self._update_slots()
+        self.graph = None
+
+    def _update_slots(self) -> None:
+        bs = self.cache_config.block_size
+        blk = torch.gather(self.block_tables, 1, (self.positions // bs).view(-1, 1)).view(-1)
+        self.slot_mapping.copy_(blk.to(torch.int64) * bs + self.positions % bs)
+
+    def fill_context(self, seed: int = 1) -> None:
+        """random K/V for the context tokens (instead of running a prefill)"""
+        g = torch.Generator(device=self.device).manual_seed(seed)
+        scale = self.arch.head_dim**-0.5
+        for kv in self.kv_caches:
+            if kv.dtype == torch.uint8:
+                kv.copy_(torch.randint(0, 120, kv.shape, generator=g, device=self.device,
+                                       dtype=torch.uint8))
+            else:
+                kv.copy_(((torch.rand(kv.shape, generator=g, device=self.device) * 2 - 1) * scale
+                          ).to(kv.dtype))
+
+    def _decode_metadata(self) -> ROCmHipAttentionMetadata:
+        return ROCmHipAttentionMetadata(
+            num_prefills=0, num_prefill_tokens=0, num_decode_tokens=self.batch,
+            slot_mapping=self.slot_mapping, seq_lens=None, seq_lens_tensor=self.seq_lens,
+            max_query_len=None, max_prefill_seq_len=0, max_decode_seq_len=self.max_seq_len,
+            query_start_loc=None, seq_start_loc=None, context_lens_tensor=None,
+            block_tables=self.block_tables, use_cuda_graph=self.graph is not None)
+
+    # ------------------------------------------------------------------ steps
+    def _sample(self, hidden_states: torch.Tensor) -> torch.Tensor:
+        """greedy: argmax over the full vocabulary (logits of all TP shards gathered)"""
+        logits = torch.matmul(hidden_states, self.model.lm_head.weight.t())
+        if self.tp_size > 1:
+            logits = tensor_model_parallel_all_gather(logits)
+        return torch.argmax(logits[:, :self.arch.vocab_size], dim=-1)
+
+    def _step_body(self) -> torch.Tensor:
+        hidden = self.model(self.input_ids, self.positions, self.kv_caches, self._decode_metadata())
+        next_tokens = self._sample(hidden)
+        # advance the batch state on device so that a captured step can be replayed back to back
+        self.input_ids.copy_(next_tokens)
+        self.positions.add_(1)
+        self.seq_lens.add_(1)
+        self._update_slots()
+        return next_tokens
+
+    @torch.inference_mode()
+    def decode_step(self) -> torch.Tensor:
+        if self.graph is not None:
+            self.graph.replay()
+            return self._graph_out
+        return self._step_body()
+
+    @torch.inference_mode()
+    def capture(self, warmup: int = 2) -> bool:
+        """capture one decode step into a hipGraph; returns False (and stays eager) on failure"""
+        saved = [t.clone() for t in (self.input_ids, self.positions, self.seq_lens, self.slot_mapping)]
+        try:
+            s = torch.cuda.Stream(device=self.device)
+            s.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(s):
+                for _ in range(warmup):  # first touch: marlin repack, workspace moves, allocator
+                    self._step_body()
+            torch.cuda.current_stream(self.device).wait_stream(s)
+            torch.cuda.synchronize(self.device)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = self._step_body()
+            self.graph, self._graph_out = graph, out
+            ok = True
+        except Exception as e:  # pragma: no cover - depends on the runtime
+            print(f"[decode_runner] hipGraph capture failed, staying eager: {e!r}")
+            self.graph = None
+            ok = False
+        for dst, src in zip((self.input_ids, self.positions, self.seq_lens, self.slot_mapping), saved):
+            dst.copy_(src)
+        torch.cuda.synchronize(self.device)
+        return ok
+
+    @torch.inference_mode()
+    def prefill(self, prompt_len: int, seed: int = 0) -> torch.Tensor:
+        """one prompt step for `batch` prompts of `prompt_len` tokens (TTFT); K/V go to the cache"""
+        bs = self.cache_config.block_size
+        b = self.batch
+        g = torch.Generator().manual_seed(seed)
+        ids = torch.randint(0, self.arch.vocab_size, (b * prompt_len, ), generator=g).to(self.device)
+        pos = torch.arange(prompt_len, device=self.device).repeat(b)
+        blk = torch.gather(self.block_tables.long(), 1,
+                           (torch.arange(prompt_len, device=self.device) // bs).expand(b, -1))
+        slots = (blk * bs + (torch.arange(prompt_len, device=self.device) % bs)).view(-1)
+        cu = torch.arange(0, (b + 1) * prompt_len, prompt_len, dtype=torch.int32, device=self.device)
+        md = ROCmHipAttentionMetadata(
+            num_prefills=b, num_prefill_tokens=b * prompt_len, num_decode_tokens=0,
+            slot_mapping=slots, seq_lens=[prompt_len] * b,
+            seq_lens_tensor=torch.full((b, ), prompt_len, dtype=torch.int32, device=self.device),
+            max_query_len=prompt_len, max_prefill_seq_len=prompt_len, max_decode_seq_len=0,
+            query_start_loc=cu, seq_start_loc=cu,
+            context_lens_tensor=torch.zeros(b, dtype=torch.int32, device=self.device),
+            block_tables=self.block_tables[:, :0], use_cuda_graph=False)
+        hidden = self.model(ids, pos, self.kv_caches, md)
+        last = hidden.view(b, prompt_len, -1)[:, -1]
+        return self._sample(last)
+
+    def weight_bytes_per_step(self) -> int:
+        """bytes of parameters one decode step has to stream (this rank)"""
+        total = 0
+        for n, p in self.model.named_parameters():
+            if p.device.type == "meta" or n.endswith("g_idx") or "embed_tokens" in n:
+                continue
+            total += p.numel() * p.element_size()
+        return total
