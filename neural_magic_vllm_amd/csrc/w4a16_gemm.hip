@@ -74,6 +74,7 @@ struct GemmParams {
   const int* perm;        // [K] or null: A columns are gathered through it (act-order)
   uint16_t* c;            // [M, N] (used when splits == 1)
   float* slab;            // [splits, M, N] fp32 (used when splits > 1)
+  int* tickets;           // [n_blocks * m_blocks] zero on entry / exit (the Marlin `workspace`)
   int M, N, K;
   int group_size;         // 32/64/128, or 0 = channelwise (one scale row)
   int k_per_wg;           // k range of one workgroup (multiple of WK*STAGE_K)
@@ -81,9 +82,13 @@ struct GemmParams {
 };
 
 // ---------------------------------------------------------------------------------------------
-template <typename T, int MT, int WN, int WM, int WK>
+template <typename T, int MT, int WN, int WM, int WK, int GS /* 0 = channelwise */>
 __global__ __launch_bounds__(GT) void w4a16_gemm_kernel(const GemmParams p) {
   static_assert(WN * WM * WK == 4, "4 waves per workgroup");
+  static_assert(GS == 0 || GS == 32 || GS == 64 || GS == 128, "group size");
+  constexpr int FLUSH_EVERY = GS == 0 ? KSTEPS : GS / 32;  // k-steps per group
+  constexpr int NG = GS == 0 ? 0 : STAGE_K / GS;           // scale groups per stage
+  constexpr int NGA = NG > 0 ? NG : 1;
   constexpr int MP = 16 * MT * WM;          // activation rows staged per workgroup
   constexpr int A_STAGE_U4 = KSTEPS * 4 * MP;  // uint4 per (stage, k-group)
   // LDS: activation stages [2][WK][A_STAGE_U4]; re-used for the cross-wave reduction at the end
@@ -194,47 +199,51 @@ __global__ __launch_bounds__(GT) void w4a16_gemm_kernel(const GemmParams p) {
   const int out_chunk = chunk0 + (g >> 1);
   const bool out_ok = out_chunk < n_chunks;
   const uint16_t* sp = p.s + (int64_t)(out_ok ? out_chunk : 0) * 64 + (g & 1) * 32;
-  const int gs = p.group_size;  // 0 = channelwise
-  const int flush_every = gs == 0 ? KSTEPS : gs / 32;  // in k-steps (1, 2 or 4)
-
-  auto flush = [&](int k_abs) {
-    // k_abs: first k of the group that just ended
-    float sc[4][8];
-    if (gs != 0) {
-      const uint16_t* sg = sp + (int64_t)(k_abs / gs) * p.N;
+  // scales of one stage: NG groups x 4 x 16 B per lane, issued EARLY (with the weight prefetch
+  // for one group per stage, else at the start of the stage) so that no flush waits on memory
+  auto load_scales = [&](int st, uint4 (&sv)[NGA][4]) {
+    if constexpr (NG > 0) {
 #pragma unroll
-      for (int reg = 0; reg < 4; ++reg) {
-        const uint4 t = ld16(sg + reg * 8);
-        const uint32_t d[4] = {t.x, t.y, t.z, t.w};
+      for (int gi = 0; gi < NG; ++gi) {
+        const int k_abs = k_w0 + st * STAGE_K + gi * GS;
+        const uint16_t* sg = sp + (int64_t)(min(k_abs, p.K - 1) / GS) * p.N;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          sc[reg][2 * j] = lo_f<T>(d[j]);
-          sc[reg][2 * j + 1] = hi_f<T>(d[j]);
-        }
+        for (int reg = 0; reg < 4; ++reg) sv[gi][reg] = ld16(sg + reg * 8);
       }
     }
+  };
+
+  auto flush = [&](const uint4 (&sv)[NGA][4], int gi) {
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
       const float zs = -W4_ZP * accs[t][0];
 #pragma unroll
-      for (int v = 0; v < 8; ++v) {
+      for (int reg = 0; reg < 4; ++reg) {
+        const uint32_t d[4] = {sv[gi][reg].x, sv[gi][reg].y, sv[gi][reg].z, sv[gi][reg].w};
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-          const float d = accg[v][t][reg] + zs;
-          if (gs != 0) accm[v][t][reg] = fmaf(sc[reg][v], d, accm[v][t][reg]);
-          else accm[v][t][reg] += d;
+        for (int v = 0; v < 8; ++v) {
+          const float dlt = accg[v][t][reg] + zs;
+          if constexpr (GS != 0) {
+            const float scv = (v & 1) ? hi_f<T>(d[v >> 1]) : lo_f<T>(d[v >> 1]);
+            accm[v][t][reg] = fmaf(scv, dlt, accm[v][t][reg]);
+          } else {
+            accm[v][t][reg] += dlt;
+          }
         }
-        accg[v][t] = zero4;
       }
+#pragma unroll
+      for (int v = 0; v < 8; ++v) accg[v][t] = zero4;
       accs[t] = zero4;
     }
   };
 
   // ---- prologue ----
-  uint4 wcur[2 * KSTEPS], wnxt[2 * KSTEPS];
+  uint4 w0[2 * KSTEPS], w1[2 * KSTEPS];
+  uint4 s0[NGA][4], s1[NGA][4];
   uint4 areg[A_PER_THREAD];
   if (n_stages > 0) {
-    load_stage_w(0, wcur);
+    load_stage_w(0, w0);
+    if constexpr (NG == 1) load_scales(0, s0);
     load_stage_a(0, areg);
     store_stage_a(0, areg);
   }
@@ -243,11 +252,15 @@ __global__ __launch_bounds__(GT) void w4a16_gemm_kernel(const GemmParams p) {
   const uint4 ones = make_uint4(W4<T>::ONES, W4<T>::ONES, W4<T>::ONES, W4<T>::ONES);
   const int a_rd_base = (wm * MT) * 16 + r;  // row of M-tile 0 for this lane
 
-  for (int st = 0; st < n_stages; ++st) {
+  // one pipeline stage: prefetch stage st+1 into (wn, sn), consume stage st from (wc, sc)
+  auto stage = [&](int st, uint4 (&wc)[2 * KSTEPS], uint4 (&wn)[2 * KSTEPS], uint4 (&sc)[NGA][4],
+                   uint4 (&sn)[NGA][4]) {
     const int buf = st & 1;
     const bool more = st + 1 < n_stages;
+    if constexpr (NG > 1) load_scales(st, sc);  // before the prefetch: waits on it stay counted
     if (more) {
-      load_stage_w(st + 1, wnxt);
+      load_stage_w(st + 1, wn);
+      if constexpr (NG == 1) load_scales(st + 1, sn);
       load_stage_a(st + 1, areg);
     }
     const int kb = k_w0 + st * STAGE_K;
@@ -260,39 +273,40 @@ __global__ __launch_bounds__(GT) void w4a16_gemm_kernel(const GemmParams p) {
 #pragma unroll
         for (int t = 0; t < MT; ++t)
           af[t] = lds[(buf * WK + wk) * A_STAGE_U4 + (ks * 4 + g) * MP + a_rd_base + t * 16];
-        const uint4 x = wcur[2 * ks], y = wcur[2 * ks + 1];
+        const uint4 x = wc[2 * ks], y = wc[2 * ks + 1];
         const uint32_t xs[4] = {x.x, x.y, x.z, x.w};
         const uint32_t ys[4] = {y.x, y.y, y.z, y.w};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const uint4 w0 = make_uint4(W4<T>::lo0(xs[j]), W4<T>::hi0(xs[j]), W4<T>::lo0(ys[j]),
-                                      W4<T>::hi0(ys[j]));
-          const uint4 w1 = make_uint4(W4<T>::lo1(xs[j]), W4<T>::hi1(xs[j]), W4<T>::lo1(ys[j]),
-                                      W4<T>::hi1(ys[j]));
+          const uint4 wv0 = make_uint4(W4<T>::lo0(xs[j]), W4<T>::hi0(xs[j]), W4<T>::lo0(ys[j]),
+                                       W4<T>::hi0(ys[j]));
+          const uint4 wv1 = make_uint4(W4<T>::lo1(xs[j]), W4<T>::hi1(xs[j]), W4<T>::lo1(ys[j]),
+                                       W4<T>::hi1(ys[j]));
 #pragma unroll
           for (int t = 0; t < MT; ++t) {
-            accg[2 * j][t] = W4<T>::mfma(w0, af[t], accg[2 * j][t]);
-            accg[2 * j + 1][t] = W4<T>::mfma(w1, af[t], accg[2 * j + 1][t]);
+            accg[2 * j][t] = W4<T>::mfma(wv0, af[t], accg[2 * j][t]);
+            accg[2 * j + 1][t] = W4<T>::mfma(wv1, af[t], accg[2 * j + 1][t]);
           }
         }
 #pragma unroll
         for (int t = 0; t < MT; ++t) accs[t] = W4<T>::mfma(ones, af[t], accs[t]);
-        if ((ks + 1) % flush_every == 0) flush(k + 32 - flush_every * 32);
+        if ((ks + 1) % FLUSH_EVERY == 0) flush(sc, ks / FLUSH_EVERY);
       }
     }
-    if (more) {
-      store_stage_a(buf ^ 1, areg);
-#pragma unroll
-      for (int i = 0; i < 2 * KSTEPS; ++i) wcur[i] = wnxt[i];
-    }
+    if (more) store_stage_a(buf ^ 1, areg);
     __syncthreads();
+  };
+
+  for (int st = 0; st < n_stages; st += 2) {
+    stage(st, w0, w1, s0, s1);
+    if (st + 1 < n_stages) stage(st + 1, w1, w0, s1, s0);
   }
 
   // channelwise + a trailing partial stage (K % 128 != 0): fold what is still pending
-  if (gs == 0) flush(0);
+  if constexpr (GS == 0) flush(s0, 0);
 
   // ---- channelwise scales are applied once, on the fp32 result ----
-  if (gs == 0 && out_ok) {
+  if (GS == 0 && out_ok) {
 #pragma unroll
     for (int v = 0; v < 8; ++v) {
       const int j = v >> 1, blk = v & 1;
@@ -334,44 +348,92 @@ __global__ __launch_bounds__(GT) void w4a16_gemm_kernel(const GemmParams p) {
             for (int reg = 0; reg < 4; ++reg) accm[v][t][reg] += src[((v * MT + t) * 4 + reg) * 64 + lane];
       }
     }
-    if (wk != 0) return;
   }
+  const bool writer = (wk == 0) && out_ok;  // this wave/lane owns output fragments
 
   // ---- epilogue: lane holds, per variant, 4 consecutive columns of row m ----
-  if (!out_ok) return;
+  if (p.splits == 1) {
+    if (!writer) return;
 #pragma unroll
-  for (int t = 0; t < MT; ++t) {
-    const int m = m0 + (wm * MT + t) * 16 + r;
-    if (m >= p.M) continue;
+    for (int t = 0; t < MT; ++t) {
+      const int m = m0 + (wm * MT + t) * 16 + r;
+      if (m >= p.M) continue;
 #pragma unroll
-    for (int v = 0; v < 8; ++v) {
-      const int j = v >> 1, blk = v & 1;
-      const int n = out_chunk * 64 + j * 16 + blk * 8 + (g & 1) * 4;
-      const f32x4_t o = accm[v][t];
-      if (p.splits == 1) {
+      for (int v = 0; v < 8; ++v) {
+        const int n = out_chunk * 64 + (v >> 1) * 16 + (v & 1) * 8 + (g & 1) * 4;
+        const f32x4_t o = accm[v][t];
         uint2 pk;
         pk.x = T::pack2(o[0], o[1]);
         pk.y = T::pack2(o[2], o[3]);
         *reinterpret_cast<uint2*>(p.c + (int64_t)m * p.N + n) = pk;
-      } else {
-        *reinterpret_cast<f32x4_t*>(p.slab + ((int64_t)split * p.M + m) * p.N + n) = o;
+      }
+    }
+    return;
+  }
+
+  // ---- split-K across workgroups: slabs + "last arriver reduces", in one launch ----
+  // Hand-off per the CDNA4 rules for inter-workgroup data (per-CU L1 is never refreshed, XCD L2s
+  // are not coherent): every slab byte is stored WRITE-THROUGH (sc1), each storing wave drains
+  // vmcnt, the workgroup barrier orders them before ONE lane's agent-scope ticket add; the
+  // workgroup that draws the last ticket reads every slab with sc1 loads (L1 bypass) and sums
+  // them in split order -> the result is bit-reproducible, whichever workgroup arrives last.
+  const int64_t slab_bytes = (int64_t)p.splits * p.M * p.N * 4;
+  __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p.slab, 0, (int)slab_bytes, 0x00020000);
+  typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+  if (writer) {
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+      const int m = m0 + (wm * MT + t) * 16 + r;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int v = 0; v < 8; ++v) {
+        const int n = out_chunk * 64 + (v >> 1) * 16 + (v & 1) * 8 + (g & 1) * 4;
+        const int off = (int)((((int64_t)split * p.M + m) * p.N + n) * 4);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, accm[v][t]), rs, off, 0, 16);
       }
     }
   }
-}
-
-// sum the split-K slabs in a fixed order and round once to the output dtype
-template <typename T>
-__global__ void splitk_reduce_kernel(uint16_t* __restrict__ c, const float* __restrict__ slab,
-                                     int64_t mn, int splits) {
-  const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
-  if (i >= mn) return;
-  f32x4_t a = *reinterpret_cast<const f32x4_t*>(slab + i);
-  for (int s = 1; s < splits; ++s) a += *reinterpret_cast<const f32x4_t*>(slab + (int64_t)s * mn + i);
-  uint2 pk;
-  pk.x = T::pack2(a[0], a[1]);
-  pk.y = T::pack2(a[2], a[3]);
-  *reinterpret_cast<uint2*>(c + i) = pk;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its stores
+  __shared__ int ticket_s;
+  __syncthreads();
+  const int tile = blockIdx.z * gridDim.x + blockIdx.x;
+  if (threadIdx.x == 0)
+    ticket_s = __hip_atomic_fetch_add(p.tickets + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  if (ticket_s != p.splits - 1) return;  // uniform for the workgroup
+  if (threadIdx.x == 0)  // leave the ticket array zeroed for the next call
+    __hip_atomic_store(p.tickets + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // all 256 threads of the last workgroup sum the tile: float4 columns strided over threads,
+  // the split loop unrolled so that 8 independent sc1 loads are in flight per element
+  constexpr int TILE_COLS = WN * 128;
+  constexpr int TILE_ROWS = 16 * MT * WM;
+  constexpr int F4_PER_ROW = TILE_COLS / 4;
+  const int n_base = blockIdx.x * TILE_COLS;
+  const int64_t split_stride = (int64_t)p.M * p.N * 4;  // bytes
+  for (int e = threadIdx.x; e < TILE_ROWS * F4_PER_ROW; e += GT) {
+    const int m = m0 + e / F4_PER_ROW;
+    const int n = n_base + (e % F4_PER_ROW) * 4;
+    if (m >= p.M || n >= p.N) continue;
+    const int off0 = (int)(((int64_t)m * p.N + n) * 4);
+    f32x4_t sum = {0.f, 0.f, 0.f, 0.f};
+    int sidx = 0;
+    for (; sidx + 8 <= p.splits; sidx += 8) {
+      u32x4_t q[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        q[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, off0 + (int)((sidx + u) * split_stride), 0, 16);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) sum += __builtin_bit_cast(f32x4_t, q[u]);  // fixed order
+    }
+    for (; sidx < p.splits; ++sidx) {
+      const u32x4_t q = __builtin_amdgcn_raw_buffer_load_b128(rs, off0 + (int)(sidx * split_stride), 0, 16);
+      sum += __builtin_bit_cast(f32x4_t, q);
+    }
+    uint2 pk;
+    pk.x = T::pack2(sum[0], sum[1]);
+    pk.y = T::pack2(sum[2], sum[3]);
+    *reinterpret_cast<uint2*>(p.c + (int64_t)m * p.N + n) = pk;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -430,46 +492,45 @@ static int env_int(const char* name, int dflt) {
 // Pick the workgroup shape and the split-K factor.  Decode-sized GEMMs (M <= 64) last only a
 // few microseconds at HBM speed, so the plan aims at >= ~2 workgroups per CU while keeping the
 // fp32 partial traffic (splits * M * N * 4 B) well below the weight bytes (K * N / 2).
-static GemmPlan make_plan(int M, int N, int K) {
+static GemmPlan make_plan(int M, int N, int K, int64_t tickets_len) {
   GemmPlan pl;
   const int n_chunks = N / 64;
-  if (M <= 16) { pl.mt = 1; pl.wm = 1; }
-  else if (M <= 32) { pl.mt = 2; pl.wm = 1; }
-  else { pl.mt = 2; pl.wm = 2; }
-  const int rows_per_wg = 16 * pl.mt * pl.wm;
+  pl.wm = 1;
+  pl.mt = M <= 16 ? 1 : (M <= 32 ? 2 : 4);
+  const int rows_per_wg = 16 * pl.mt;
   pl.m_blocks = (M + rows_per_wg - 1) / rows_per_wg;
-  const int waves_nk = 4 / pl.wm;  // waves to distribute over n and k
-  // narrow N: let the waves of a workgroup split K instead of N
-  const int wide_cols = (n_chunks + 2 * waves_nk - 1) / (2 * waves_nk);
-  if (wide_cols * pl.m_blocks >= 48 || K < waves_nk * STAGE_K) { pl.wn = waves_nk; pl.wk = 1; }
-  else { pl.wn = 1; pl.wk = waves_nk; }
+  // waves of a workgroup split N when it is wide, K when it is narrow
+  const int cols4 = (n_chunks + 7) / 8;
+  if (cols4 * pl.m_blocks >= 48 || K < 4 * STAGE_K) pl.wn = 4;
+  else if (cols4 * pl.m_blocks >= 24 || pl.mt == 4 || K < 8 * STAGE_K) pl.wn = 2;
+  else pl.wn = 1;
   pl.wn = env_int("NMV_W4_WN", pl.wn);
-  pl.wk = waves_nk / pl.wn;
+  if (pl.mt == 4 && pl.wn == 1) pl.wn = 2;  // the 64-row tile keeps WK <= 2 (LDS / registers)
+  pl.wk = 4 / pl.wn;
   pl.n_blocks = (n_chunks + 2 * pl.wn - 1) / (2 * pl.wn);
   const int unit = pl.wk * STAGE_K;  // k granularity of a workgroup
   const int k_units = (K + unit - 1) / unit;
   const int base_wgs = pl.n_blocks * pl.m_blocks;
-  int splits = (512 + base_wgs - 1) / base_wgs;  // ~2 workgroups per CU
-  // partial traffic cap: splits * M * 8 <= K / 2  (write + read of fp32 vs 4-bit weights)
-  const int cap = std::max(1, K / (16 * std::max(M, 1)));
+  int splits = (512 + base_wgs - 1) / base_wgs;  // aim at ~2 workgroups per CU
+  // keep the fp32 partial traffic (splits * M * N * 8 B written + read) near the weight bytes
+  const int cap = std::max(1, K / (8 * std::max(M, 1)));
   splits = std::min(splits, cap);
-  splits = std::min(splits, k_units);
-  splits = std::max(splits, 1);
   splits = env_int("NMV_W4_SPLITS", splits);
   splits = std::max(1, std::min(splits, k_units));
+  if ((int64_t)base_wgs > tickets_len) splits = 1;  // no ticket per output tile available
   const int units_per_wg = (k_units + splits - 1) / splits;
   pl.k_per_wg = units_per_wg * unit;
   pl.splits = (K + pl.k_per_wg - 1) / pl.k_per_wg;
   return pl;
 }
 
-template <typename T>
-static int launch_gemm(const GemmPlan& pl, const GemmParams& p, hipStream_t s) {
+template <typename T, int GS>
+static int launch_gemm_gs(const GemmPlan& pl, const GemmParams& p, hipStream_t s) {
   dim3 grid(pl.n_blocks, pl.splits, pl.m_blocks), block(GT);
-#define NMV_W4_CASE(MT_, WN_, WM_, WK_)                                                        \
-  if (pl.mt == MT_ && pl.wn == WN_ && pl.wm == WM_ && pl.wk == WK_) {                          \
-    hipLaunchKernelGGL((w4a16_gemm_kernel<T, MT_, WN_, WM_, WK_>), grid, block, 0, s, p);      \
-    return 0;                                                                                  \
+#define NMV_W4_CASE(MT_, WN_, WM_, WK_)                                                         \
+  if (pl.mt == MT_ && pl.wn == WN_ && pl.wm == WM_ && pl.wk == WK_) {                           \
+    hipLaunchKernelGGL((w4a16_gemm_kernel<T, MT_, WN_, WM_, WK_, GS>), grid, block, 0, s, p);   \
+    return 0;                                                                                   \
   }
   NMV_W4_CASE(1, 4, 1, 1)
   NMV_W4_CASE(1, 2, 1, 2)
@@ -477,10 +538,21 @@ static int launch_gemm(const GemmPlan& pl, const GemmParams& p, hipStream_t s) {
   NMV_W4_CASE(2, 4, 1, 1)
   NMV_W4_CASE(2, 2, 1, 2)
   NMV_W4_CASE(2, 1, 1, 4)
-  NMV_W4_CASE(2, 2, 2, 1)
-  NMV_W4_CASE(2, 1, 2, 2)
+  NMV_W4_CASE(4, 4, 1, 1)
+  NMV_W4_CASE(4, 2, 1, 2)
 #undef NMV_W4_CASE
   return -1;
+}
+
+template <typename T>
+static int launch_gemm(const GemmPlan& pl, const GemmParams& p, hipStream_t s) {
+  switch (p.group_size) {
+    case 0: return launch_gemm_gs<T, 0>(pl, p, s);
+    case 32: return launch_gemm_gs<T, 32>(pl, p, s);
+    case 64: return launch_gemm_gs<T, 64>(pl, p, s);
+    case 128: return launch_gemm_gs<T, 128>(pl, p, s);
+    default: return -1;
+  }
 }
 
 }  // namespace nmv
@@ -510,7 +582,8 @@ extern "C" int64_t nmv_gptq_marlin_gemm_scratch_bytes(int size_m, int size_n, in
                                                       int has_act_order) {
   (void)has_act_order;  // the A gather is fused into the LDS staging: no a_tmp copy
   if (size_m <= 0 || size_n <= 0 || size_k <= 0) return 0;
-  const GemmPlan pl = make_plan(size_m, size_n, size_k);
+  // upper bound over every plan the entry point may pick (the ticket array only lowers splits)
+  const GemmPlan pl = make_plan(size_m, size_n, size_k, INT64_MAX);
   return pl.splits > 1 ? (int64_t)pl.splits * size_m * size_n * 4 : 0;
 }
 
@@ -521,7 +594,7 @@ extern "C" int nmv_gptq_marlin_gemm(void* c, const void* a, const int32_t* b_q_w
                                     int num_bits, int size_m, int size_n, int size_k,
                                     int num_groups, int is_k_full, nmv_dtype_t dtype,
                                     void* stream) {
-  (void)workspace; (void)workspace_len;  // lock array of the reference: accepted, not needed
+  // `workspace` (the reference's lock array, zero on entry and exit) holds the split-K tickets
   NMV_CHECK(dtype == NMV_F16 || dtype == NMV_BF16,
             "gpt_marlin_gemm only supports bfloat16 and float16");
   NMV_CHECK(num_bits == 4 || num_bits == 8, "num_bits must be 4 or 8. Got = %d", num_bits);
@@ -550,8 +623,9 @@ extern "C" int nmv_gptq_marlin_gemm(void* c, const void* a, const int32_t* b_q_w
     set_error("gptq_marlin_gemm: num_bits = 8 is not implemented on gfx950 yet");
     return NMV_ERR_UNSUPPORTED;
   }
-  const GemmPlan pl = make_plan(size_m, size_n, size_k);
+  const GemmPlan pl = make_plan(size_m, size_n, size_k, workspace ? workspace_len : 0);
   const int64_t need = pl.splits > 1 ? (int64_t)pl.splits * size_m * size_n * 4 : 0;
+  NMV_CHECK(need < (int64_t)1 << 31, "gptq_marlin_gemm: split-K slab too large");
   NMV_CHECK(scratch_bytes >= need && (need == 0 || scratch != nullptr),
             "gptq_marlin_gemm: scratch too small (%lld < %lld)", (long long)scratch_bytes,
             (long long)need);
@@ -562,6 +636,7 @@ extern "C" int nmv_gptq_marlin_gemm(void* c, const void* a, const int32_t* b_q_w
   p.perm = has_act_order ? perm : nullptr;
   p.c = (uint16_t*)c;
   p.slab = (float*)scratch;
+  p.tickets = workspace;
   p.M = size_m; p.N = size_n; p.K = size_k;
   p.group_size = group_size;
   p.k_per_wg = pl.k_per_wg;
@@ -571,16 +646,5 @@ extern "C" int nmv_gptq_marlin_gemm(void* c, const void* a, const int32_t* b_q_w
   NMV_CHECK(rc == 0, "gptq_marlin_gemm: no kernel for plan mt=%d wn=%d wm=%d wk=%d", pl.mt, pl.wn,
             pl.wm, pl.wk);
   NMV_LAUNCH_CHECK();
-  if (pl.splits > 1) {
-    const int64_t mn = (int64_t)size_m * size_n;
-    dim3 grid((unsigned)cdiv64(mn / 4, 256)), block(256);
-    if (dtype == NMV_F16)
-      hipLaunchKernelGGL((splitk_reduce_kernel<F16>), grid, block, 0, s, (uint16_t*)c,
-                         (const float*)scratch, mn, pl.splits);
-    else
-      hipLaunchKernelGGL((splitk_reduce_kernel<BF16>), grid, block, 0, s, (uint16_t*)c,
-                         (const float*)scratch, mn, pl.splits);
-    NMV_LAUNCH_CHECK();
-  }
   return NMV_OK;
 }

@@ -23,6 +23,18 @@ for step in "$@"; do
     w4)     run t_w4 python -m pytest tests/test_gpu_w4a16.py -q -m gpu --timeout 300 ;;
     all)    run t_all python -m pytest tests -q -m gpu --timeout 300 ;;
     bench)  run bench python bench.py ;;
+    gemm)   run gemm python tools/bench_gemm.py ;;
+    gemmprof) cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
+            run gemmprof rocprofv3 --kernel-trace --output-format csv -d gpurun_out/gprof -- python tools/bench_gemm.py ${GEMM_ARGS:-}
+            find gpurun_out/gprof -name "*kernel_trace.csv" | head -1 | xargs -I{} cp {} gpurun_out/gemm_trace.csv ;;
+    gemmpmc) cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
+            run gemmpmc rocprofv3 --pmc ${PMC:-SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU} --kernel-trace --output-format csv -d gpurun_out/gpmc -- python tools/bench_gemm.py ${GEMM_ARGS:-}
+            find gpurun_out/gpmc -name "*counter_collection.csv" | head -1 | xargs -I{} cp {} gpurun_out/gemm_pmc.csv ;;
+    gemmsweep) run gemmsweep python tools/bench_gemm.py --sweep ;;
+    prof)   cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
+            run prof rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -- python bench.py --steps 16 --warmup 4 --no-sweep --no-cpu-baseline ${BENCH_ARGS:-}
+            find gpurun_out/prof -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} gpurun_out/kernel_stats.csv
+            head -40 gpurun_out/kernel_stats.csv ;;
     *)      echo "unknown step $step" ;;
   esac
 done
