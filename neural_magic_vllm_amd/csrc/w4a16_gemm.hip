@@ -40,14 +40,23 @@ constexpr int GT = 256;        // threads per workgroup
 constexpr int STAGE_K = 128;   // k per pipeline stage (= 4 MFMA k-steps of 32)
 constexpr int KSTEPS = STAGE_K / 32;
 
+// (x & mask) | magic in ONE VALU op.  hipcc splits the C expression into v_and_b32 + v_or_b32 because
+// gfx9 VOP3 encodings take no literals; with the mask in an SGPR and the magic in a VGPR the
+// three-operand form is legal (one constant-bus read).
+__device__ __forceinline__ uint32_t and_or(uint32_t x, uint32_t mask_sgpr, uint32_t magic_vgpr) {
+  uint32_t r;
+  asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "s"(mask_sgpr), "v"(magic_vgpr));
+  return r;
+}
+
 template <typename T> struct W4;
 template <> struct W4<BF16> {
   static constexpr uint32_t MASK = 0x00780078u, MAGIC = 0x41804180u, ONES = 0x3F803F80u;
   // nibble -> mantissa bits [6:3]
-  static __device__ __forceinline__ uint32_t lo0(uint32_t x) { return ((x << 3) & MASK) | MAGIC; }
-  static __device__ __forceinline__ uint32_t hi0(uint32_t x) { return ((x >> 1) & MASK) | MAGIC; }
-  static __device__ __forceinline__ uint32_t lo1(uint32_t x) { return ((x >> 5) & MASK) | MAGIC; }
-  static __device__ __forceinline__ uint32_t hi1(uint32_t x) { return ((x >> 9) & MASK) | MAGIC; }
+  static __device__ __forceinline__ uint32_t lo0(uint32_t x, uint32_t m, uint32_t g) { return and_or(x << 3, m, g); }
+  static __device__ __forceinline__ uint32_t hi0(uint32_t x, uint32_t m, uint32_t g) { return and_or(x >> 1, m, g); }
+  static __device__ __forceinline__ uint32_t lo1(uint32_t x, uint32_t m, uint32_t g) { return and_or(x >> 5, m, g); }
+  static __device__ __forceinline__ uint32_t hi1(uint32_t x, uint32_t m, uint32_t g) { return and_or(x >> 9, m, g); }
   static __device__ __forceinline__ f32x4_t mfma(uint4 w, uint4 a, f32x4_t c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w),
                                                    __builtin_bit_cast(bf16x8_t, a), c, 0, 0, 0);
@@ -56,10 +65,10 @@ template <> struct W4<BF16> {
 template <> struct W4<F16> {
   static constexpr uint32_t MASK = 0x03C003C0u, MAGIC = 0x4C004C00u, ONES = 0x3C003C00u;
   // nibble -> mantissa bits [9:6]
-  static __device__ __forceinline__ uint32_t lo0(uint32_t x) { return ((x << 6) & MASK) | MAGIC; }
-  static __device__ __forceinline__ uint32_t hi0(uint32_t x) { return ((x << 2) & MASK) | MAGIC; }
-  static __device__ __forceinline__ uint32_t lo1(uint32_t x) { return ((x >> 2) & MASK) | MAGIC; }
-  static __device__ __forceinline__ uint32_t hi1(uint32_t x) { return ((x >> 6) & MASK) | MAGIC; }
+  static __device__ __forceinline__ uint32_t lo0(uint32_t x, uint32_t m, uint32_t g) { return and_or(x << 6, m, g); }
+  static __device__ __forceinline__ uint32_t hi0(uint32_t x, uint32_t m, uint32_t g) { return and_or(x << 2, m, g); }
+  static __device__ __forceinline__ uint32_t lo1(uint32_t x, uint32_t m, uint32_t g) { return and_or(x >> 2, m, g); }
+  static __device__ __forceinline__ uint32_t hi1(uint32_t x, uint32_t m, uint32_t g) { return and_or(x >> 6, m, g); }
   static __device__ __forceinline__ f32x4_t mfma(uint4 w, uint4 a, f32x4_t c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, w),
                                                   __builtin_bit_cast(f16x8_t, a), c, 0, 0, 0);
@@ -231,9 +240,6 @@ __global__ __launch_bounds__(GT) void w4a16_gemm_kernel(const GemmParams p) {
           }
         }
       }
-#pragma unroll
-      for (int v = 0; v < 8; ++v) accg[v][t] = zero4;
-      accs[t] = zero4;
     }
   };
 
@@ -250,6 +256,9 @@ __global__ __launch_bounds__(GT) void w4a16_gemm_kernel(const GemmParams p) {
   __syncthreads();
 
   const uint4 ones = make_uint4(W4<T>::ONES, W4<T>::ONES, W4<T>::ONES, W4<T>::ONES);
+  const uint32_t kmask = __builtin_amdgcn_readfirstlane(W4<T>::MASK);  // SGPR
+  uint32_t kmagic = W4<T>::MAGIC;
+  asm volatile("" : "+v"(kmagic));  // pin the magic constant in a VGPR
   const int a_rd_base = (wm * MT) * 16 + r;  // row of M-tile 0 for this lane
 
   // one pipeline stage: prefetch stage st+1 into (wn, sn), consume stage st from (wc, sc)
@@ -278,18 +287,20 @@ __global__ __launch_bounds__(GT) void w4a16_gemm_kernel(const GemmParams p) {
         const uint32_t ys[4] = {y.x, y.y, y.z, y.w};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const uint4 wv0 = make_uint4(W4<T>::lo0(xs[j]), W4<T>::hi0(xs[j]), W4<T>::lo0(ys[j]),
-                                       W4<T>::hi0(ys[j]));
-          const uint4 wv1 = make_uint4(W4<T>::lo1(xs[j]), W4<T>::hi1(xs[j]), W4<T>::lo1(ys[j]),
-                                       W4<T>::hi1(ys[j]));
+          const uint4 wv0 = make_uint4(W4<T>::lo0(xs[j], kmask, kmagic), W4<T>::hi0(xs[j], kmask, kmagic),
+                                       W4<T>::lo0(ys[j], kmask, kmagic), W4<T>::hi0(ys[j], kmask, kmagic));
+          const uint4 wv1 = make_uint4(W4<T>::lo1(xs[j], kmask, kmagic), W4<T>::hi1(xs[j], kmask, kmagic),
+                                       W4<T>::lo1(ys[j], kmask, kmagic), W4<T>::hi1(ys[j], kmask, kmagic));
+          const bool first = (ks % FLUSH_EVERY) == 0;  // compile-time after unrolling
 #pragma unroll
           for (int t = 0; t < MT; ++t) {
-            accg[2 * j][t] = W4<T>::mfma(wv0, af[t], accg[2 * j][t]);
-            accg[2 * j + 1][t] = W4<T>::mfma(wv1, af[t], accg[2 * j + 1][t]);
+            accg[2 * j][t] = W4<T>::mfma(wv0, af[t], first ? zero4 : accg[2 * j][t]);
+            accg[2 * j + 1][t] = W4<T>::mfma(wv1, af[t], first ? zero4 : accg[2 * j + 1][t]);
           }
         }
 #pragma unroll
-        for (int t = 0; t < MT; ++t) accs[t] = W4<T>::mfma(ones, af[t], accs[t]);
+        for (int t = 0; t < MT; ++t)
+          accs[t] = W4<T>::mfma(ones, af[t], (ks % FLUSH_EVERY) == 0 ? zero4 : accs[t]);
         if ((ks + 1) % FLUSH_EVERY == 0) flush(sc, ks / FLUSH_EVERY);
       }
     }
@@ -303,7 +314,11 @@ __global__ __launch_bounds__(GT) void w4a16_gemm_kernel(const GemmParams p) {
   }
 
   // channelwise + a trailing partial stage (K % 128 != 0): fold what is still pending
-  if constexpr (GS == 0) flush(s0, 0);
+  if constexpr (GS == 0) {
+    // only when the last stage ended before its 4th k-step (K % 128 != 0 inside this wave's range)
+    const int done = k_w1 > k_w0 ? (k_w1 - k_w0) : 0;
+    if (done % STAGE_K != 0) flush(s0, 0);
+  }
 
   // ---- channelwise scales are applied once, on the fp32 result ----
   if (GS == 0 && out_ok) {
@@ -495,15 +510,16 @@ static int env_int(const char* name, int dflt) {
 static GemmPlan make_plan(int M, int N, int K, int64_t tickets_len) {
   GemmPlan pl;
   const int n_chunks = N / 64;
+  // Measured on MI355X (tools/bench_gemm.py --sweep): the 16-row tile (MT = 1, 2 workgroups per
+  // CU) beats the 32/64-row tiles at every M <= 64, even though 64 rows re-dequantise the weights
+  // four times; larger M walks blockIdx.z.  ~512 workgroups (one resident set) is the sweet spot.
   pl.wm = 1;
-  pl.mt = M <= 16 ? 1 : (M <= 32 ? 2 : 4);
+  pl.mt = env_int("NMV_W4_MT", 1);
   const int rows_per_wg = 16 * pl.mt;
   pl.m_blocks = (M + rows_per_wg - 1) / rows_per_wg;
-  // waves of a workgroup split N when it is wide, K when it is narrow
-  const int cols4 = (n_chunks + 7) / 8;
-  if (cols4 * pl.m_blocks >= 48 || K < 4 * STAGE_K) pl.wn = 4;
-  else if (cols4 * pl.m_blocks >= 24 || pl.mt == 4 || K < 8 * STAGE_K) pl.wn = 2;
-  else pl.wn = 1;
+  if (n_chunks >= 256) pl.wn = (pl.m_blocks == 1 && M <= 8) ? 4 : 2;
+  else pl.wn = pl.m_blocks >= 2 ? 2 : 1;
+  if (K < (4 / pl.wn) * STAGE_K) pl.wn = 4;
   pl.wn = env_int("NMV_W4_WN", pl.wn);
   if (pl.mt == 4 && pl.wn == 1) pl.wn = 2;  // the 64-row tile keeps WK <= 2 (LDS / registers)
   pl.wk = 4 / pl.wn;
@@ -511,10 +527,8 @@ static GemmPlan make_plan(int M, int N, int K, int64_t tickets_len) {
   const int unit = pl.wk * STAGE_K;  // k granularity of a workgroup
   const int k_units = (K + unit - 1) / unit;
   const int base_wgs = pl.n_blocks * pl.m_blocks;
-  int splits = (512 + base_wgs - 1) / base_wgs;  // aim at ~2 workgroups per CU
-  // keep the fp32 partial traffic (splits * M * N * 8 B written + read) near the weight bytes
-  const int cap = std::max(1, K / (8 * std::max(M, 1)));
-  splits = std::min(splits, cap);
+  int splits = std::max(1, 512 / base_wgs);
+  splits = std::min(splits, 32);
   splits = env_int("NMV_W4_SPLITS", splits);
   splits = std::max(1, std::min(splits, k_units));
   if ((int64_t)base_wgs > tickets_len) splits = 1;  // no ticket per output tile available
@@ -535,11 +549,13 @@ static int launch_gemm_gs(const GemmPlan& pl, const GemmParams& p, hipStream_t s
   NMV_W4_CASE(1, 4, 1, 1)
   NMV_W4_CASE(1, 2, 1, 2)
   NMV_W4_CASE(1, 1, 1, 4)
+#ifdef NMV_W4_TALL_TILES  // 32- and 64-row tiles: slower than 16 rows x blockIdx.z on MI355X
   NMV_W4_CASE(2, 4, 1, 1)
   NMV_W4_CASE(2, 2, 1, 2)
   NMV_W4_CASE(2, 1, 1, 4)
   NMV_W4_CASE(4, 4, 1, 1)
   NMV_W4_CASE(4, 2, 1, 2)
+#endif
 #undef NMV_W4_CASE
   return -1;
 }

@@ -24,14 +24,25 @@ def bench(name, k, n, m, dev, iters=40, gs=128):
     a = torch.randn((m, k), device=dev, dtype=torch.bfloat16)
     wsp = torch.zeros(n // 64 * 16, dtype=torch.int32, device=dev)
     e = torch.empty(0, dtype=torch.int32, device=dev)
-    for i in range(ncopy):
+    for i in range(min(ncopy, 3)):
         ops.gptq_marlin_gemm(a, ws[i], sc[i], e, e, wsp, 4, m, n, k, True)
+    torch.cuda.synchronize()
+    # capture `iters` back-to-back calls in one hipGraph: device time without host launch cost
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        ops.gptq_marlin_gemm(a, ws[0], sc[0], e, e, wsp, 4, m, n, k, True)
+    torch.cuda.current_stream().wait_stream(side)
+    with torch.cuda.graph(graph):
+        for i in range(iters):
+            ops.gptq_marlin_gemm(a, ws[i % ncopy], sc[i % ncopy], e, e, wsp, 4, m, n, k, True)
+    graph.replay()
     torch.cuda.synchronize()
     st = torch.cuda.current_stream()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(st)
-    for i in range(iters):
-        ops.gptq_marlin_gemm(a, ws[i % ncopy], sc[i % ncopy], e, e, wsp, 4, m, n, k, True)
+    graph.replay()
     e1.record(st)
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / iters * 1e3
@@ -42,7 +53,7 @@ def bench(name, k, n, m, dev, iters=40, gs=128):
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--sweep", action="store_true")
-    ap.add_argument("--ms", default="1,16,64")
+    ap.add_argument("--ms", default="1,16,32,64")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     ms = [int(x) for x in args.ms.split(",")]
@@ -53,22 +64,27 @@ if __name__ == "__main__":
                 print(f"{name:8s} M={m:3d}  {us:8.1f} us  {gbs:7.0f} GB/s", flush=True)
                 continue
             res = []
-            for wn in (0, 1, 2, 4):
-                for sp in (0, 1, 2, 4, 8, 16, 32):
-                    os.environ.pop("NMV_W4_WN", None)
-                    os.environ.pop("NMV_W4_SPLITS", None)
-                    if wn:
-                        os.environ["NMV_W4_WN"] = str(wn)
-                    if sp:
-                        os.environ["NMV_W4_SPLITS"] = str(sp)
-                    if m > 32 and wn == 4:
-                        continue
-                    try:
-                        us, gbs = bench(name, k, n, m, dev, iters=20)
-                    except Exception as ex:
-                        continue
-                    res.append((us, wn, sp, gbs))
+            for mt in (0, 1, 2, 4):
+                if mt and mt * 16 > max(m, 16):
+                    continue
+                for wn in (1, 2, 4):
+                    for sp in (1, 2, 4, 8, 16, 32):
+                        for kk in ("NMV_W4_WN", "NMV_W4_SPLITS", "NMV_W4_MT"):
+                            os.environ.pop(kk, None)
+                        if mt:
+                            os.environ["NMV_W4_MT"] = str(mt)
+                            os.environ["NMV_W4_WN"] = str(wn)
+                            os.environ["NMV_W4_SPLITS"] = str(sp)
+                        elif wn != 1 or sp != 1:
+                            continue
+                        try:
+                            us, gbs = bench(name, k, n, m, dev, iters=12)
+                        except Exception:
+                            continue
+                        res.append((us, mt, wn, sp, gbs))
+            for kk in ("NMV_W4_WN", "NMV_W4_SPLITS", "NMV_W4_MT"):
+                os.environ.pop(kk, None)
             res.sort()
-            best = ", ".join(f"wn{w}/sp{s}:{u:.1f}us" for u, w, s, _ in res[:6])
-            dflt = [r for r in res if r[1] == 0 and r[2] == 0]
-            print(f"{name:8s} M={m:3d} default {dflt[0][0]:.1f}us {dflt[0][3]:.0f}GB/s | best {best}", flush=True)
+            best = ", ".join(f"mt{a}/wn{w}/sp{s}:{u:.1f}" for u, a, w, s, _ in res[:8])
+            dflt = [r for r in res if r[1] == 0]
+            print(f"{name:8s} M={m:3d} default {dflt[0][0]:.1f}us {dflt[0][4]:.0f}GB/s | best(us) {best}", flush=True)
