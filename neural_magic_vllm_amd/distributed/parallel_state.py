@@ -64,10 +64,12 @@ class GroupCoordinator:
         if dim < 0:
             dim += input_.dim()
         input_size = input_.size()
-        output_tensor = torch.empty((world_size, ) + input_size, dtype=input_.dtype,
-                                    device=input_.device)
-        dist.all_gather_into_tensor(output_tensor, input_.contiguous(), group=self.device_group)
-        output_tensor = output_tensor.movedim(0, dim)
+        # flat [world*d0, ...] output: accepted by both RCCL and gloo
+        inp = input_.contiguous() if input_.dim() > 0 else input_.reshape(1)
+        flat = torch.empty((world_size * inp.shape[0], ) + tuple(inp.shape[1:]), dtype=inp.dtype,
+                           device=inp.device)
+        dist.all_gather_into_tensor(flat, inp, group=self.device_group)
+        output_tensor = flat.reshape((world_size, ) + input_size).movedim(0, dim)
         return output_tensor.reshape(input_size[:dim] + (world_size * input_size[dim], ) +
                                      input_size[dim + 1:])
 
