@@ -174,6 +174,34 @@ int nmv_gptq_marlin_gemm(void* c, const void* a, const int32_t* b_q_weight, cons
                          int is_k_full, nmv_dtype_t dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * W8A8: activation quantisers and the scaled matmul
+ * (csrc/ops.h:101-114,126-130; csrc/quantization/compressed_tensors/int8_quant_kernels.cu,
+ *  csrc/quantization/fp8/common.cu, csrc/quantization/cutlass_w8a8/scaled_mm_entry.cu)
+ * ---------------------------------------------------------------------------------------- */
+
+/* static_scaled_int8_quant (int8_quant_kernels.cu:77-95; dynamic = 0, scale: float[1]) and
+ * dynamic_scaled_int8_quant (:97-115; dynamic = 1, scale: float[num_tokens] written).
+ * input [num_tokens, hidden] contiguous -> out int8 same shape. */
+int nmv_scaled_int8_quant(void* out, const void* input, float* scale, int num_tokens,
+                          int hidden_size, int dynamic, nmv_dtype_t dtype, void* stream);
+
+/* static_scaled_fp8_quant / dynamic_scaled_fp8_quant (fp8/common.cu:129-165): per-tensor scale
+ * float[1]; dynamic: scale must be 0 on entry and receives absmax/448.  out: e4m3fn bytes. */
+int nmv_scaled_fp8_quant(void* out, const void* input, float* scale, int64_t num_elems, int dynamic,
+                         nmv_dtype_t dtype, void* stream);
+
+/* cutlass_scaled_mm (scaled_mm_entry.cu:48-100): out[M,N] = a_scales * (b_scales * (a . b)) + bias.
+ * a [M,K] row-major (lda), b column-major = [N,K] row-major (ldb = b.stride(1)), out row-major
+ * (ldc); scales fp32 with numel 1 (per tensor) or M / N; bias in out_dtype or NULL. */
+int nmv_scaled_mm(void* out, const void* a, const void* b, const float* a_scales,
+                  const float* b_scales, const void* bias, int M, int N, int K, int64_t lda,
+                  int64_t ldb, int64_t ldc, int a_scales_numel, int b_scales_numel,
+                  nmv_q8_dtype_t in_dtype, nmv_dtype_t out_dtype, void* stream);
+
+/* cutlass_scaled_mm_supports_fp8 (scaled_mm_entry.cu:32-46) */
+int nmv_cutlass_scaled_mm_supports_fp8(int64_t cuda_device_capability);
+
+/* ------------------------------------------------------------------------------------------
  * device attributes (csrc/cuda_utils.h:3-5, csrc/cuda_utils_kernels.cu)
  * ---------------------------------------------------------------------------------------- */
 int64_t nmv_get_device_attribute(int64_t attribute, int64_t device_id);

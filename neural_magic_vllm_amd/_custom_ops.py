@@ -142,6 +142,55 @@ def gptq_marlin_gemm(a: torch.Tensor, b_q_weight: torch.Tensor, b_scales: torch.
                                          num_bits, size_m, size_n, size_k, is_k_full)
 
 
+# cutlass (vllm/_custom_ops.py:219-238)
+def cutlass_scaled_mm_supports_fp8(cuda_device_capability: int) -> bool:
+    return torch.ops._C.cutlass_scaled_mm_supports_fp8(cuda_device_capability)
+
+
+def cutlass_scaled_mm(a: torch.Tensor, b: torch.Tensor, scale_a: torch.Tensor,
+                      scale_b: torch.Tensor, out_dtype: Type[torch.dtype],
+                      bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    assert (b.shape[0] % 16 == 0 and b.shape[1] % 16 == 0)
+    assert (out_dtype is torch.bfloat16 or out_dtype is torch.float16)
+    m = a.shape[0]
+    n = b.shape[1]
+    out = torch.empty((m, n), dtype=out_dtype, device=a.device)
+    torch.ops._C.cutlass_scaled_mm(out, a, b, scale_a, scale_b, bias)
+    return out
+
+
+# fp8 (vllm/_custom_ops.py:282-321)
+def scaled_fp8_quant(input: torch.Tensor, scale: Optional[torch.Tensor] = None,
+                     batch_dim_padding: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Quantize to FP8 (e4m3fn): static when `scale` is given, dynamic per-tensor otherwise;
+    `batch_dim_padding` pads the first dimension of the output."""
+    if batch_dim_padding:
+        shape = (max(batch_dim_padding, input.shape[0]), *input.shape[1:])
+        output = torch.empty(shape, device=input.device, dtype=torch.float8_e4m3fn)
+    else:
+        output = torch.empty_like(input, dtype=torch.float8_e4m3fn)
+    if scale is None:
+        scale = torch.zeros(1, device=input.device, dtype=torch.float32)
+        torch.ops._C.dynamic_scaled_fp8_quant(output, input, scale)
+    else:
+        torch.ops._C.static_scaled_fp8_quant(output, input, scale)
+    return output, scale
+
+
+# int8 (vllm/_custom_ops.py:324-351)
+def scaled_int8_quant(input: torch.Tensor,
+                      scale: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """static per-tensor when `scale` is given, dynamic per-token otherwise"""
+    output = torch.empty_like(input, dtype=torch.int8)
+    if scale is not None:
+        torch.ops._C.static_scaled_int8_quant(output, input, scale)
+        return output, scale
+    input_scales = torch.empty((input.numel() // input.shape[-1], 1), device=input.device,
+                               dtype=torch.float32)
+    torch.ops._C.dynamic_scaled_int8_quant(output, input, input_scales)
+    return output, input_scales
+
+
 # cache ops
 def reshape_and_cache(key: torch.Tensor, value: torch.Tensor, key_cache: torch.Tensor,
                       value_cache: torch.Tensor, slot_mapping: torch.Tensor,

@@ -239,6 +239,82 @@ def gptq_marlin_gemm(a, b_q_weight, b_scales, g_idx, perm, workspace, num_bits, 
     return c
 
 
+# ----------------------------------------------------------------------------- W8A8
+def static_scaled_int8_quant(out, input, scale) -> None:
+    """csrc/quantization/compressed_tensors/int8_quant_kernels.cu:77-95"""
+    _req(input.is_contiguous() and out.is_contiguous(), "input/out must be contiguous")
+    _req(scale.numel() == 1 and scale.dtype == torch.float32, "scale must be one float32")
+    _req(out.dtype == torch.int8, "out must be int8")
+    with device_guard(input):
+        check(_lib.load().nmv_scaled_int8_quant(ptr(out), ptr(input), ptr(scale), _rows(input),
+                                                input.shape[-1], 0, dtype_code(input.dtype),
+                                                stream_of(input)))
+
+
+def dynamic_scaled_int8_quant(out, input, scale) -> None:
+    """int8_quant_kernels.cu:97-115: per-token scales"""
+    _req(input.is_contiguous() and out.is_contiguous(), "input/out must be contiguous")
+    _req(scale.dtype == torch.float32 and scale.is_contiguous() and scale.numel() >= _rows(input),
+         "scales must be float32 [num_tokens, 1]")
+    _req(out.dtype == torch.int8, "out must be int8")
+    with device_guard(input):
+        check(_lib.load().nmv_scaled_int8_quant(ptr(out), ptr(input), ptr(scale), _rows(input),
+                                                input.shape[-1], 1, dtype_code(input.dtype),
+                                                stream_of(input)))
+
+
+def _fp8_quant(dynamic: int):
+
+    def fn(out, input, scale) -> None:
+        """csrc/quantization/fp8/common.cu:129-165"""
+        _req(input.is_contiguous() and out.is_contiguous(), "input/out must be contiguous")
+        _req(out.dtype in (torch.float8_e4m3fn, torch.uint8), "out must be float8_e4m3fn")
+        _req(scale.numel() == 1 and scale.dtype == torch.float32, "scale must be one float32")
+        _req(out.numel() >= input.numel(), "out is smaller than input")
+        with device_guard(input):
+            check(_lib.load().nmv_scaled_fp8_quant(ptr(out), ptr(input), ptr(scale), input.numel(),
+                                                   dynamic, dtype_code(input.dtype),
+                                                   stream_of(input)))
+
+    return fn
+
+
+def cutlass_scaled_mm_supports_fp8(cuda_device_capability: int) -> bool:
+    return bool(_lib.load().nmv_cutlass_scaled_mm_supports_fp8(cuda_device_capability))
+
+
+def cutlass_scaled_mm(out, a, b, a_scales, b_scales, bias) -> None:
+    """csrc/quantization/cutlass_w8a8/scaled_mm_entry.cu:48-100 (same checks)"""
+    _req(a.dim() == 2 and b.dim() == 2 and out.dim() == 2, "a, b, c must be 2-D")
+    _req(out.shape[0] == a.shape[0] and a.shape[1] == b.shape[0] and b.shape[1] == out.shape[1],
+         "shape mismatch between a, b and c")
+    _req(a_scales.numel() == 1 or a_scales.numel() == a.shape[0], "a_scales must be scalar or [M]")
+    _req(b_scales.numel() == 1 or b_scales.numel() == b.shape[1], "b_scales must be scalar or [N]")
+    _req(a.stride(1) == 1 and out.stride(1) == 1, "a and c must be row major")
+    _req(b.stride(0) == 1, "b must be column major")
+    _req(out.stride(0) % 16 == 0 and b.stride(1) % 16 == 0, "c.stride(0) and b.stride(1) must be 16B aligned")
+    _req(a_scales.is_contiguous() and b_scales.is_contiguous(), "scales must be contiguous")
+    _req(a_scales.dtype == torch.float32 and b_scales.dtype == torch.float32, "scales must be float32")
+    if bias is not None:
+        _req(bias.numel() == b.shape[1] and bias.is_contiguous() and bias.dim() == 1,
+             "bias must be a contiguous [N] vector")
+        _req(bias.dtype == out.dtype, "bias dtype must match the output")
+    if a.dtype == torch.int8:
+        _req(b.dtype == torch.int8, "a and b must both be int8")
+        q = _lib.NMV_I8
+    else:
+        _req(a.dtype == torch.float8_e4m3fn and b.dtype == torch.float8_e4m3fn,
+             "a and b must both be int8 or both float8_e4m3fn")
+        q = _lib.NMV_FP8_E4M3
+    m, k = a.shape
+    n = b.shape[1]
+    with device_guard(a):
+        check(_lib.load().nmv_scaled_mm(ptr(out), ptr(a), ptr(b), ptr(a_scales), ptr(b_scales),
+                                        ptr(bias), m, n, k, a.stride(0), b.stride(1),
+                                        out.stride(0), a_scales.numel(), b_scales.numel(), q,
+                                        dtype_code(out.dtype), stream_of(a)))
+
+
 # ----------------------------------------------------------------------------- cache ops
 def reshape_and_cache(key, value, key_cache, value_cache, slot_mapping, kv_cache_dtype,
                       kv_scale) -> None:
@@ -371,6 +447,14 @@ _C_OPS = [
     ("batched_rotary_embedding(Tensor positions, Tensor! query, Tensor! key, int head_size, "
      "Tensor cos_sin_cache, bool is_neox, int rot_dim, Tensor cos_sin_cache_offsets) -> ()",
      batched_rotary_embedding),
+    ("cutlass_scaled_mm(Tensor! out, Tensor a, Tensor b, Tensor a_scales, Tensor b_scales, "
+     "Tensor? bias) -> ()", cutlass_scaled_mm),
+    ("static_scaled_fp8_quant(Tensor! out, Tensor input, Tensor scale) -> ()", _fp8_quant(0)),
+    ("dynamic_scaled_fp8_quant(Tensor! out, Tensor input, Tensor! scale) -> ()", _fp8_quant(1)),
+    ("static_scaled_int8_quant(Tensor! out, Tensor input, Tensor scale) -> ()",
+     static_scaled_int8_quant),
+    ("dynamic_scaled_int8_quant(Tensor! out, Tensor input, Tensor! scale) -> ()",
+     dynamic_scaled_int8_quant),
     ("gptq_marlin_repack(Tensor b_q_weight, Tensor perm, int size_k, int size_n, int num_bits) "
      "-> Tensor", gptq_marlin_repack),
     ("gptq_marlin_gemm(Tensor a, Tensor b_q_weight, Tensor b_scales, Tensor g_idx, Tensor perm, "
@@ -389,6 +473,12 @@ _CACHE_OPS = [
      reshape_and_cache_flash),
     ("convert_fp8(Tensor! dst_cache, Tensor src_cache, float scale, str kv_cache_dtype) -> ()",
      convert_fp8),
+]
+
+# ops without tensor arguments (the reference registers them under kCUDA, torch_bindings.cpp:152-156)
+_C_NOTENSOR_OPS = [
+    ("cutlass_scaled_mm_supports_fp8(int cuda_device_capability) -> bool",
+     cutlass_scaled_mm_supports_fp8),
 ]
 
 _UTIL_OPS = [
@@ -413,6 +503,10 @@ def register() -> None:
             lib.define(schema)
             name = _op_name(schema)
             lib.impl(name, fn, "CUDA")
+        if ns == "_C":
+            for schema, fn in _C_NOTENSOR_OPS:
+                lib.define(schema)
+                lib.impl(_op_name(schema), fn, "CompositeExplicitAutograd")
         _libs.append(lib)
     lib = torch.library.Library("_C_cuda_utils", "DEF")
     for schema, fn in _UTIL_OPS:
@@ -425,5 +519,5 @@ def register() -> None:
 
 
 def all_schemas():
-    return {"_C": [s for s, _ in _C_OPS], "_C_cache_ops": [s for s, _ in _CACHE_OPS],
+    return {"_C": [s for s, _ in _C_OPS] + [s for s, _ in _C_NOTENSOR_OPS], "_C_cache_ops": [s for s, _ in _CACHE_OPS],
             "_C_cuda_utils": [s for s, _ in _UTIL_OPS]}

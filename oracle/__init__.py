@@ -184,3 +184,41 @@ def fp8_encode(t_f32):
     out = torch.empty(t_f32.shape, dtype=torch.uint8)
     lib().orc_fp8_encode(_p(_cpu(t_f32.contiguous().float())), _p(out), c_int64(t_f32.numel()))
     return out
+
+
+def scaled_int8_quant(input, scale=None):
+    """static (scale given, float32[1]) or dynamic per-token; returns (int8 tensor, scales)"""
+    out = torch.empty(input.shape, dtype=torch.int8)
+    nt = input.numel() // input.shape[-1]
+    dynamic = scale is None
+    if dynamic:
+        scale = torch.empty((nt, 1), dtype=torch.float32)
+    lib().orc_scaled_int8_quant(_p(out), _p(_cpu(input.contiguous())), _p(scale), c_int(nt),
+                                c_int(input.shape[-1]), c_int(int(dynamic)), c_int(_DT[input.dtype]))
+    return out, scale
+
+
+def scaled_fp8_quant(input, scale=None):
+    out = torch.empty(input.shape, dtype=torch.uint8)
+    dynamic = scale is None
+    if dynamic:
+        scale = torch.zeros(1, dtype=torch.float32)
+    lib().orc_scaled_fp8_quant(_p(out), _p(_cpu(input.contiguous())), _p(scale),
+                               c_int64(input.numel()), c_int(int(dynamic)), c_int(_DT[input.dtype]))
+    return out, scale
+
+
+def scaled_mm(a, b, scale_a, scale_b, out_dtype, bias=None):
+    """a [M,K] int8 / float8_e4m3fn, b [K,N] column-major; returns [M,N] in out_dtype"""
+    m, k = a.shape
+    n = b.shape[1]
+    bt = b.t().contiguous()  # [N, K] row-major
+    is_fp8 = a.dtype == torch.float8_e4m3fn
+    av = a.contiguous().view(torch.uint8) if is_fp8 else a.contiguous().view(torch.uint8)
+    btv = bt.view(torch.uint8)
+    out = torch.empty((m, n), dtype=out_dtype)
+    sa, sb = scale_a.contiguous().float(), scale_b.contiguous().float()
+    lib().orc_scaled_mm(_p(out), _p(av), _p(btv), _p(sa), _p(sb), _p(bias), c_int(m), c_int(n),
+                        c_int(k), c_int(int(sa.numel() > 1)), c_int(int(sb.numel() > 1)),
+                        c_int(int(is_fp8)), c_int(_DT[out_dtype]))
+    return out

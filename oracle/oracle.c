@@ -418,3 +418,77 @@ void orc_act_and_mul(uint16_t* out, const uint16_t* input, int num_tokens, int d
       out[(int64_t)t * d + i] = f_to_h(rnd_h(a, dt) * y, dt);
     }
 }
+
+/* ------------------------------------------------------------------ W8A8
+ * scaled_int8_quant: csrc/quantization/compressed_tensors/int8_quant_kernels.cu:6-75 and the
+ * reference test's checker tests/kernels/test_int8_quant.py:33-38,64-65. */
+static inline int8_t f_to_i8_rn(float x) {
+  float d = nearbyintf(x);
+  if (d < -128.f) d = -128.f;
+  if (d > 127.f) d = 127.f;
+  return (int8_t)d;
+}
+void orc_scaled_int8_quant(int8_t* out, const uint16_t* input, float* scale, int num_tokens,
+                           int hidden, int dynamic, int dt) {
+  for (int t = 0; t < num_tokens; ++t) {
+    const int64_t row = (int64_t)t * hidden;
+    if (dynamic) {
+      float amax = 0.f;
+      for (int i = 0; i < hidden; ++i) { const float v = fabsf(h_to_f(input[row + i], dt)); if (v > amax) amax = v; }
+      scale[t] = amax / 127.0f;
+      const float mul = 127.0f / amax;
+      for (int i = 0; i < hidden; ++i) out[row + i] = f_to_i8_rn(h_to_f(input[row + i], dt) * mul);
+    } else {
+      for (int i = 0; i < hidden; ++i) out[row + i] = f_to_i8_rn(h_to_f(input[row + i], dt) / scale[0]);
+    }
+  }
+}
+
+/* scaled_fp8_quant: csrc/quantization/fp8/common.cu:22-127 (x * (1/scale), clamp +-448, e4m3fn;
+ * dynamic scale = absmax / 448) */
+void orc_scaled_fp8_quant(uint8_t* out, const uint16_t* input, float* scale, int64_t n, int dynamic, int dt) {
+  if (dynamic) {
+    float amax = 0.f;
+    for (int64_t i = 0; i < n; ++i) { const float v = fabsf(h_to_f(input[i], dt)); if (v > amax) amax = v; }
+    scale[0] = amax / 448.0f;
+  }
+  const float inv = 1.0f / scale[0];
+  for (int64_t i = 0; i < n; ++i) {
+    float x = h_to_f(input[i], dt) * inv;
+    x = fmaxf(-448.f, fminf(x, 448.f));
+    out[i] = f_to_fp8(x);
+  }
+}
+
+/* cutlass_scaled_mm: csrc/quantization/cutlass_w8a8/scaled_mm_entry.cu:48-100, epilogue
+ * scaled_mm_c2x.cu:88-140; checker tests/kernels/test_cutlass.py:36-48.
+ * a [M,K] row-major, bt [N,K] row-major (= column-major b).  is_fp8: bytes are e4m3fn. */
+void orc_scaled_mm(uint16_t* out, const uint8_t* a, const uint8_t* bt, const float* a_scales,
+                   const float* b_scales, const uint16_t* bias, int M, int N, int K, int a_per_row,
+                   int b_per_col, int is_fp8, int dt) {
+  float* af = NULL; float* bf = NULL;
+  if (is_fp8) {
+    af = (float*)malloc(sizeof(float) * (size_t)M * K);
+    bf = (float*)malloc(sizeof(float) * (size_t)N * K);
+    for (int64_t i = 0; i < (int64_t)M * K; ++i) af[i] = fp8_to_f(a[i]);
+    for (int64_t i = 0; i < (int64_t)N * K; ++i) bf[i] = fp8_to_f(bt[i]);
+  }
+#pragma omp parallel for collapse(2)
+  for (int m = 0; m < M; ++m)
+    for (int n = 0; n < N; ++n) {
+      float accf;
+      if (is_fp8) {
+        double acc = 0.0;
+        for (int k = 0; k < K; ++k) acc += (double)af[(int64_t)m * K + k] * (double)bf[(int64_t)n * K + k];
+        accf = (float)acc;
+      } else {
+        int64_t acc = 0;
+        for (int k = 0; k < K; ++k) acc += (int)(int8_t)a[(int64_t)m * K + k] * (int)(int8_t)bt[(int64_t)n * K + k];
+        accf = (float)acc;
+      }
+      float o = a_scales[a_per_row ? m : 0] * (b_scales[b_per_col ? n : 0] * accf);
+      if (bias) o += h_to_f(bias[n], dt);
+      out[(int64_t)m * N + n] = f_to_h(o, dt);
+    }
+  free(af); free(bf);
+}
