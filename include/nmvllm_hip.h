@@ -173,6 +173,48 @@ int nmv_gptq_marlin_gemm(void* c, const void* a, const int32_t* b_q_weight, cons
                          int num_bits, int size_m, int size_n, int size_k, int num_groups,
                          int is_k_full, nmv_dtype_t dtype, void* stream);
 
+/* marlin_gemm  (csrc/quantization/marlin/dense/marlin_cuda_kernel.cu:1045-1136): legacy Marlin
+ * checkpoints, 4-bit, group -1 / 128; same tensors as nmv_gptq_marlin_gemm without act-order. */
+int nmv_marlin_gemm(void* c, const void* a, const int32_t* b_q_weight, const void* b_scales,
+                    int32_t* workspace, int64_t workspace_len, void* scratch, int64_t scratch_bytes,
+                    int size_m, int size_n, int size_k, int num_groups, nmv_dtype_t dtype,
+                    void* stream);
+
+/* fp8_marlin_gemm  (csrc/quantization/fp8/fp8_marlin.cu:1212-1308): fp8-e4m3 weights packed by
+ * pack_fp8_to_int32 + gptq_marlin_repack(bits=8), channelwise (or grouped) scales in
+ * marlin_permute_scales order. */
+int nmv_fp8_marlin_gemm(void* c, const void* a, const int32_t* b_q_weight, const void* b_scales,
+                        int32_t* workspace, int64_t workspace_len, int num_bits, int size_m,
+                        int size_n, int size_k, int num_groups, nmv_dtype_t dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * GPTQ (exllama) and AWQ checkpoints  (csrc/ops.h:66-73,119-124)
+ * ---------------------------------------------------------------------------------------- */
+
+/* gptq_gemm  (csrc/quantization/gptq/q_gemm.cu:1823-1846): c = a . ((q - (z + 1)) * s).
+ * b_q_weight int32 [K/pack, N]; qzeros int32 [G, N/pack]; scales [G, N]; use_exllama != 0:
+ * weights were processed by nmv_gptq_shuffle and b_g_idx is the act-order permutation (or NULL);
+ * use_exllama == 0: b_g_idx is the per-row group index (or NULL). bit in {2, 4, 8}. */
+int nmv_gptq_gemm(void* c, const void* a, const int32_t* b_q_weight, const int32_t* b_gptq_qzeros,
+                  const void* b_gptq_scales, const int32_t* b_g_idx, int use_exllama, int bit,
+                  int size_m, int size_n, int size_k, int num_groups, nmv_dtype_t dtype,
+                  void* stream);
+
+/* gptq_shuffle  (q_gemm.cu:1848-1856): in place; q_perm NULL = no act-order.  tmp: scratch of
+ * the size of q_weight (needed only with q_perm). */
+int nmv_gptq_shuffle(int32_t* q_weight, const int32_t* q_perm, int32_t* tmp, int size_k, int size_n,
+                     int bit, void* stream);
+
+/* awq_gemm  (csrc/quantization/awq/gemm_kernels.cu:492-549): c = a . ((q - z) * s);
+ * qweight int32 [K, N/8], qzeros int32 [G, N/8], scales [G, N]. */
+int nmv_awq_gemm(void* c, const void* a, const int32_t* qweight, const void* scales,
+                 const int32_t* qzeros, int size_m, int size_n, int size_k, int num_groups,
+                 nmv_dtype_t dtype, void* stream);
+
+/* awq_dequantize  (gemm_kernels.cu:436-490): out [K, N] */
+int nmv_awq_dequantize(void* out, const int32_t* qweight, const void* scales, const int32_t* qzeros,
+                       int size_n, int size_k, int num_groups, nmv_dtype_t dtype, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * W8A8: activation quantisers and the scaled matmul
  * (csrc/ops.h:101-114,126-130; csrc/quantization/compressed_tensors/int8_quant_kernels.cu,

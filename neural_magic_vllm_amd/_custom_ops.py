@@ -142,6 +142,46 @@ def gptq_marlin_gemm(a: torch.Tensor, b_q_weight: torch.Tensor, b_scales: torch.
                                          num_bits, size_m, size_n, size_k, is_k_full)
 
 
+# awq (vllm/_custom_ops.py:162-177).  NOTE the reference wrapper's parameter NAMES are
+# (input, qweight, qzeros, scales) but it forwards them positionally to the native
+# awq_gemm(in_feats, kernel, scaling_factors, zeros); AWQLinearMethod passes
+# (x, qweight, scales, qzeros) (awq.py:172-173), which is what the native op expects.
+def awq_dequantize(qweight: torch.Tensor, scales: torch.Tensor, zeros: torch.Tensor,
+                   split_k_iters: int, thx: int, thy: int) -> torch.Tensor:
+    return torch.ops._C.awq_dequantize(qweight, scales, zeros, split_k_iters, thx, thy)
+
+
+def awq_gemm(input: torch.Tensor, qweight: torch.Tensor, qzeros: torch.Tensor,
+             scales: torch.Tensor, split_k_iters: int) -> torch.Tensor:
+    return torch.ops._C.awq_gemm(input, qweight, qzeros, scales, split_k_iters)
+
+
+# gptq (vllm/_custom_ops.py:180-192)
+def gptq_gemm(a: torch.Tensor, b_q_weight: torch.Tensor, b_gptq_qzeros: torch.Tensor,
+              b_gptq_scales: torch.Tensor, b_g_idx: torch.Tensor, use_exllama: bool,
+              bit: int) -> torch.Tensor:
+    return torch.ops._C.gptq_gemm(a, b_q_weight, b_gptq_qzeros, b_gptq_scales, b_g_idx,
+                                  use_exllama, bit)
+
+
+def gptq_shuffle(q_weight: torch.Tensor, q_perm: torch.Tensor, bit: int) -> None:
+    torch.ops._C.gptq_shuffle(q_weight, q_perm, bit)
+
+
+# marlin (vllm/_custom_ops.py:201-206)
+def marlin_gemm(a: torch.Tensor, b_q_weight: torch.Tensor, b_scales: torch.Tensor,
+                workspace: torch.Tensor, size_m: int, size_n: int, size_k: int) -> torch.Tensor:
+    return torch.ops._C.marlin_gemm(a, b_q_weight, b_scales, workspace, size_m, size_n, size_k)
+
+
+# fp8 marlin (vllm/_custom_ops.py:272-279)
+def fp8_marlin_gemm(a: torch.Tensor, b_q_weight: torch.Tensor, b_scales: torch.Tensor,
+                    workspace: torch.Tensor, num_bits: int, size_m: int, size_n: int,
+                    size_k: int) -> torch.Tensor:
+    return torch.ops._C.fp8_marlin_gemm(a, b_q_weight, b_scales, workspace, num_bits, size_m,
+                                        size_n, size_k)
+
+
 # cutlass (vllm/_custom_ops.py:219-238)
 def cutlass_scaled_mm_supports_fp8(cuda_device_capability: int) -> bool:
     return torch.ops._C.cutlass_scaled_mm_supports_fp8(cuda_device_capability)

@@ -239,6 +239,118 @@ def gptq_marlin_gemm(a, b_q_weight, b_scales, g_idx, perm, workspace, num_bits, 
     return c
 
 
+def marlin_gemm(a, b_q_weight, b_scales, workspace, size_m, size_n, size_k) -> torch.Tensor:
+    """csrc/quantization/marlin/dense/marlin_cuda_kernel.cu:1045-1136 (legacy Marlin, 4-bit)"""
+    _req(a.shape[0] == size_m and a.shape[1] == size_k, "Shape mismatch: a vs size_m / size_k")
+    _req(size_k % 16 == 0 and b_q_weight.shape[0] == size_k // 16,
+         f"Shape mismatch: b_q_weight.size(0) = {b_q_weight.shape[0]}, size_k = {size_k}")
+    _req(b_q_weight.shape[1] // 16 * 8 == size_n, "size_n does not match b_q_weight")
+    _req(a.is_contiguous() and b_q_weight.is_contiguous() and b_scales.is_contiguous(),
+         "a, b_q_weight and b_scales must be contiguous")
+    _req(a.dtype in (torch.float16, torch.bfloat16) and b_scales.dtype == a.dtype,
+         "marlin_gemm supports float16 (and bfloat16) activations with scales of the same dtype")
+    _req(workspace.numel() >= size_n // 128 * 16 or workspace.numel() >= size_n // 64,
+         "workspace is too small")
+    c = torch.empty((size_m, size_n), dtype=a.dtype, device=a.device)
+    if size_m == 0:
+        return c
+    L = _lib.load()
+    nbytes = L.nmv_gptq_marlin_gemm_scratch_bytes(size_m, size_n, size_k, 0)
+    scratch = torch.empty((max(nbytes, 16), ), dtype=torch.uint8, device=a.device)
+    with device_guard(a):
+        check(L.nmv_marlin_gemm(ptr(c), ptr(a), ptr(b_q_weight), ptr(b_scales), ptr(workspace),
+                                workspace.numel(), ptr(scratch), scratch.numel(), size_m, size_n,
+                                size_k, b_scales.shape[0], dtype_code(a.dtype), stream_of(a)))
+    return c
+
+
+def fp8_marlin_gemm(a, b_q_weight, b_scales, workspace, num_bits, size_m, size_n,
+                    size_k) -> torch.Tensor:
+    """csrc/quantization/fp8/fp8_marlin.cu:1212-1308"""
+    _req(a.shape[0] == size_m and a.shape[1] == size_k, "Shape mismatch: a vs size_m / size_k")
+    _req(b_q_weight.shape[0] == size_k // 16 and b_q_weight.shape[1] // 16 * 4 == size_n,
+         "Shape mismatch: b_q_weight vs size_k / size_n")
+    _req(a.is_contiguous() and b_q_weight.is_contiguous() and b_scales.is_contiguous(),
+         "a, b_q_weight and b_scales must be contiguous")
+    _req(b_scales.dtype == a.dtype and b_scales.shape[-1] == size_n, "b_scales must be [G, size_n] of A's dtype")
+    c = torch.empty((size_m, size_n), dtype=a.dtype, device=a.device)
+    with device_guard(a):
+        check(_lib.load().nmv_fp8_marlin_gemm(ptr(c), ptr(a), ptr(b_q_weight), ptr(b_scales),
+                                              ptr(workspace), workspace.numel(), num_bits, size_m,
+                                              size_n, size_k, b_scales.shape[0],
+                                              dtype_code(a.dtype), stream_of(a)))
+    return c
+
+
+# ----------------------------------------------------------------------------- GPTQ / AWQ
+def gptq_gemm(a, b_q_weight, b_gptq_qzeros, b_gptq_scales, b_g_idx, use_exllama, bit) -> torch.Tensor:
+    """csrc/quantization/gptq/q_gemm.cu:1823-1846"""
+    _req(bit in (2, 3, 4, 8), f"unsupported bit width {bit}")
+    _req(bit != 3, "3-bit GPTQ is not supported on gfx950 (2, 4 and 8 bit are)")
+    pack = 32 // bit
+    size_m, size_k = a.shape[0], a.shape[1]
+    size_n = b_q_weight.shape[1]
+    _req(b_q_weight.shape[0] * pack == size_k, "b_q_weight rows do not match a's K")
+    _req(a.is_contiguous() and b_q_weight.is_contiguous() and b_gptq_scales.is_contiguous()
+         and b_gptq_qzeros.is_contiguous(), "gptq_gemm: tensors must be contiguous")
+    _req(b_gptq_scales.dtype == a.dtype, "scales must have the activation dtype")
+    has_idx = b_g_idx is not None and b_g_idx.numel() > 0 and b_g_idx.device.type != "meta"
+    if has_idx:
+        _req(b_g_idx.numel() == size_k and b_g_idx.dtype == torch.int32, "g_idx must be int32 [K]")
+    c = torch.empty((size_m, size_n), dtype=a.dtype, device=a.device)
+    with device_guard(a):
+        check(_lib.load().nmv_gptq_gemm(ptr(c), ptr(a), ptr(b_q_weight), ptr(b_gptq_qzeros),
+                                        ptr(b_gptq_scales), ptr(b_g_idx) if has_idx else None,
+                                        int(use_exllama), bit, size_m, size_n, size_k,
+                                        b_gptq_scales.shape[0], dtype_code(a.dtype), stream_of(a)))
+    return c
+
+
+def gptq_shuffle(q_weight, q_perm, bit) -> None:
+    """csrc/quantization/gptq/q_gemm.cu:1848-1856 (in place)"""
+    _req(bit in (2, 4, 8), f"gptq_shuffle: {bit}-bit weights are not supported on gfx950")
+    has_perm = q_perm is not None and q_perm.numel() > 0 and q_perm.device.type != "meta"
+    if not has_perm:
+        return
+    pack = 32 // bit
+    _req(q_perm.dtype == torch.int32 and q_perm.numel() == q_weight.shape[0] * pack,
+         "q_perm must be int32 [K]")
+    tmp = torch.empty_like(q_weight)
+    with device_guard(q_weight):
+        check(_lib.load().nmv_gptq_shuffle(ptr(q_weight), ptr(q_perm), ptr(tmp),
+                                           q_weight.shape[0] * pack, q_weight.shape[1], bit,
+                                           stream_of(q_weight)))
+
+
+def awq_gemm(input, kernel, scaling_factors, zeros, split_k_iters) -> torch.Tensor:
+    """csrc/quantization/awq/gemm_kernels.cu:492-549; argument order of csrc/ops.h:66-68"""
+    size_m, size_k = input.shape[0], input.shape[1]
+    size_n = kernel.shape[1] * 8
+    _req(kernel.shape[0] == size_k, "awq_gemm: qweight rows must equal K")
+    _req(scaling_factors.shape[1] == size_n and zeros.shape[1] * 8 == size_n, "awq_gemm: scales/zeros shape")
+    _req(input.is_contiguous() and kernel.is_contiguous() and scaling_factors.is_contiguous()
+         and zeros.is_contiguous(), "awq_gemm: tensors must be contiguous")
+    _req(scaling_factors.dtype == input.dtype, "scales must have the activation dtype")
+    c = torch.empty((size_m, size_n), dtype=input.dtype, device=input.device)
+    with device_guard(input):
+        check(_lib.load().nmv_awq_gemm(ptr(c), ptr(input), ptr(kernel), ptr(scaling_factors),
+                                       ptr(zeros), size_m, size_n, size_k,
+                                       scaling_factors.shape[0], dtype_code(input.dtype),
+                                       stream_of(input)))
+    return c
+
+
+def awq_dequantize(kernel, scaling_factors, zeros, split_k_iters, thx, thy) -> torch.Tensor:
+    """csrc/quantization/awq/gemm_kernels.cu:436-490 -> [K, N]"""
+    size_k, size_n = kernel.shape[0], kernel.shape[1] * 8
+    out = torch.empty((size_k, size_n), dtype=scaling_factors.dtype, device=kernel.device)
+    with device_guard(kernel):
+        check(_lib.load().nmv_awq_dequantize(ptr(out), ptr(kernel), ptr(scaling_factors),
+                                             ptr(zeros), size_n, size_k, scaling_factors.shape[0],
+                                             dtype_code(scaling_factors.dtype), stream_of(kernel)))
+    return out
+
+
 # ----------------------------------------------------------------------------- W8A8
 def static_scaled_int8_quant(out, input, scale) -> None:
     """csrc/quantization/compressed_tensors/int8_quant_kernels.cu:77-95"""
@@ -447,6 +559,17 @@ _C_OPS = [
     ("batched_rotary_embedding(Tensor positions, Tensor! query, Tensor! key, int head_size, "
      "Tensor cos_sin_cache, bool is_neox, int rot_dim, Tensor cos_sin_cache_offsets) -> ()",
      batched_rotary_embedding),
+    ("marlin_gemm(Tensor a, Tensor b_q_weight, Tensor b_scales, Tensor workspace, int size_m, "
+     "int size_n, int size_k) -> Tensor", marlin_gemm),
+    ("fp8_marlin_gemm(Tensor a, Tensor b_q_weight, Tensor b_scales, Tensor workspace, "
+     "int num_bits, int size_m, int size_n, int size_k) -> Tensor", fp8_marlin_gemm),
+    ("gptq_gemm(Tensor a, Tensor b_q_weight, Tensor b_gptq_qzeros, Tensor b_gptq_scales, "
+     "Tensor b_g_idx, bool use_exllama, int bit) -> Tensor", gptq_gemm),
+    ("gptq_shuffle(Tensor! q_weight, Tensor q_perm, int bit) -> ()", gptq_shuffle),
+    ("awq_gemm(Tensor _in_feats, Tensor _kernel, Tensor _scaling_factors, Tensor _zeros, "
+     "int split_k_iters) -> Tensor", awq_gemm),
+    ("awq_dequantize(Tensor _kernel, Tensor _scaling_factors, Tensor _zeros, int split_k_iters, "
+     "int thx, int thy) -> Tensor", awq_dequantize),
     ("cutlass_scaled_mm(Tensor! out, Tensor a, Tensor b, Tensor a_scales, Tensor b_scales, "
      "Tensor? bias) -> ()", cutlass_scaled_mm),
     ("static_scaled_fp8_quant(Tensor! out, Tensor input, Tensor scale) -> ()", _fp8_quant(0)),

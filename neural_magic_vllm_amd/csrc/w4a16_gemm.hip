@@ -571,6 +571,12 @@ static int launch_gemm(const GemmPlan& pl, const GemmParams& p, hipStream_t s) {
   }
 }
 
+// csrc/wq_generic.hip: LDS-staged generic path for the Marlin variants not covered above
+int wq_marlin_fallback(void* c, const void* a, const int32_t* b_q_weight, const void* b_scales,
+                       const int32_t* g_idx, const int32_t* perm, int num_bits, int size_m,
+                       int size_n, int size_k, int num_groups, int is_fp8, nmv_dtype_t dtype,
+                       hipStream_t stream);
+
 }  // namespace nmv
 
 using namespace nmv;
@@ -621,23 +627,27 @@ extern "C" int nmv_gptq_marlin_gemm(void* c, const void* a, const int32_t* b_q_w
   NMV_CHECK(num_groups >= 1, "num_groups must be >= 1");
   const bool has_act_order = (g_idx != nullptr && perm != nullptr);
   int group_size;
-  if (num_groups > 1) {
+  if (num_groups > 1 && has_act_order && !is_k_full) {
+    group_size = -1;  // a K shard carries the scales of every group; rows are mapped by g_idx
+  } else if (num_groups > 1) {
     NMV_CHECK(size_k % num_groups == 0, "size_k = %d, is not divisible by b_scales.size(0) = %d",
               size_k, num_groups);
     group_size = size_k / num_groups;
   } else {
     group_size = 0;
   }
-  if (has_act_order && !is_k_full) {
-    // rows of a K shard keep irregular group runs; needs the per-k-step group masking path
-    set_error("gptq_marlin_gemm: act_order with is_k_full=False is not implemented on gfx950 yet");
-    return NMV_ERR_UNSUPPORTED;
-  }
-  NMV_CHECK(group_size == 0 || group_size == 32 || group_size == 64 || group_size == 128,
+  NMV_CHECK(group_size == 0 || group_size == 32 || group_size == 64 || group_size == 128 ||
+                (has_act_order && !is_k_full),
             "Unsupported group_size = %d", group_size);
-  if (num_bits == 8) {
-    set_error("gptq_marlin_gemm: num_bits = 8 is not implemented on gfx950 yet");
-    return NMV_ERR_UNSUPPORTED;
+  if (num_bits == 8 || (has_act_order && !is_k_full)) {
+    // 8-bit codes, and act-order on a K shard (irregular group runs: one scale row per k through
+    // g_idx), take the generic LDS-staged kernel; same math, not HBM-tuned yet
+    const int rc = wq_marlin_fallback(c, a, b_q_weight, b_scales, has_act_order ? g_idx : nullptr,
+                                      has_act_order ? perm : nullptr, num_bits, size_m, size_n,
+                                      size_k, num_groups, 0, dtype, (hipStream_t)stream);
+    NMV_CHECK(rc == 0, "gptq_marlin_gemm: generic path launch failed");
+    NMV_LAUNCH_CHECK();
+    return NMV_OK;
   }
   const GemmPlan pl = make_plan(size_m, size_n, size_k, workspace ? workspace_len : 0);
   const int64_t need = pl.splits > 1 ? (int64_t)pl.splits * size_m * size_n * 4 : 0;
@@ -663,4 +673,19 @@ extern "C" int nmv_gptq_marlin_gemm(void* c, const void* a, const int32_t* b_q_w
             pl.wm, pl.wk);
   NMV_LAUNCH_CHECK();
   return NMV_OK;
+}
+
+/* legacy Marlin checkpoints (csrc/quantization/marlin/dense/marlin_cuda_kernel.cu:1045-1136):
+ * 4-bit, group -1 / 128, no act-order -- the same tile and scale layout as gptq_marlin */
+extern "C" int nmv_marlin_gemm(void* c, const void* a, const int32_t* b_q_weight,
+                               const void* b_scales, int32_t* workspace, int64_t workspace_len,
+                               void* scratch, int64_t scratch_bytes, int size_m, int size_n,
+                               int size_k, int num_groups, nmv_dtype_t dtype, void* stream) {
+  NMV_CHECK(size_k % 128 == 0, "size_k = %d is not divisible by min_thread_k = 128", size_k);
+  NMV_CHECK(num_groups >= 1 && size_k % num_groups == 0, "marlin_gemm: bad number of scale groups");
+  const int gs = num_groups > 1 ? size_k / num_groups : -1;
+  NMV_CHECK(gs == -1 || gs == 128, "Unexpected groupsize = %d", gs);
+  return nmv_gptq_marlin_gemm(c, a, b_q_weight, b_scales, nullptr, nullptr, workspace,
+                              workspace_len, scratch, scratch_bytes, 4, size_m, size_n, size_k,
+                              num_groups, 1, dtype, stream);
 }
