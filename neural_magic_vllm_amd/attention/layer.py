@@ -27,6 +27,13 @@ class Attention(nn.Module):
         # is no x2 correction as on MI300 (llama.py:503-508 of the reference).
         self.kv_cache_dtype = kv_cache_dtype
         self._kv_scale = 1.0
+        quant_method = quant_config.get_quant_method(self) if quant_config else None
+        if quant_method is not None:
+            # fp8 checkpoints may carry a kv-cache scaling factor (Fp8KVCacheMethod)
+            if "e5m2" in self.kv_cache_dtype:
+                raise ValueError("fp8_e5m2 kv-cache is not supported with fp8 checkpoints.")
+            self.quant_method = quant_method
+            self.quant_method.create_weights(self)
         dtype = torch.get_default_dtype()
         attn_backend = get_attn_backend(num_heads, head_size, num_kv_heads, sliding_window, dtype,
                                         kv_cache_dtype, block_size, blocksparse_params is not None)

@@ -1,0 +1,71 @@
+"""CPU: the LinearMethods create the same parameters (names, shapes, dtypes, sharding attributes)
+as the reference's, captured from the reference classes into tests/golden/linear_method_params.json
+by tools/make_golden.py (Llama-3-8B qkv projection: K 4096, partitions [4096, 1024, 1024])."""
+import json
+import os
+
+import pytest
+import torch
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "linear_method_params.json")
+KEEP = ("input_dim", "output_dim", "packed_dim", "pack_factor", "marlin_tile_size",
+        "needs_scalar_to_array")
+CFGS = {
+    "gptq_marlin": ("gptq_marlin", dict(bits=4, group_size=128, desc_act=False, sym=True), torch.bfloat16),
+    "gptq_marlin_act_order": ("gptq_marlin", dict(bits=4, group_size=128, desc_act=True, sym=True), torch.bfloat16),
+    "gptq": ("gptq", dict(bits=4, group_size=128, desc_act=False), torch.float16),
+    "awq": ("awq", dict(w_bit=4, q_group_size=128, zero_point=True), torch.bfloat16),
+}
+
+
+@pytest.mark.parametrize("name", sorted(CFGS))
+def test_parameter_tables_match_reference(name):
+    from neural_magic_vllm_amd.model_executor.layers.linear import ColumnParallelLinear
+    from neural_magic_vllm_amd.model_executor.layers.quantization import get_quantization_config
+    gold = json.load(open(GOLD))[name]
+    method, cfg, dtype = CFGS[name]
+    qc = get_quantization_config(method).from_config(cfg)
+
+    class Dummy(torch.nn.Module):
+        pass
+
+    layer = Dummy()
+    lm = qc.get_quant_method(ColumnParallelLinear(64, 64, bias=False, params_dtype=dtype,
+                                                  quant_config=None))
+    assert lm is not None
+    lm.create_weights(layer, 4096, [4096, 1024, 1024], 4096, 6144, dtype, weight_loader=None)
+    got = {}
+    for pname, prm in layer.named_parameters():
+        attrs = {k: (str(getattr(prm, k)) if k == "pack_factor" else getattr(prm, k))
+                 for k in KEEP if hasattr(prm, k)}
+        got[pname] = dict(shape=list(prm.shape), dtype=str(prm.dtype), device=prm.device.type, attrs=attrs)
+    assert got == gold
+
+
+def test_registry_and_configs():
+    from neural_magic_vllm_amd.model_executor.layers.quantization import (QUANTIZATION_METHODS,
+                                                                          get_quantization_config)
+    assert list(QUANTIZATION_METHODS) == ["awq", "fp8", "marlin", "gptq_marlin", "gptq",
+                                          "compressed-tensors"]
+    with pytest.raises(ValueError):
+        get_quantization_config("aqlm")
+    gm = get_quantization_config("gptq_marlin")
+    assert gm.is_marlin_compatible(dict(bits=4, group_size=128, sym=True, desc_act=False))
+    assert not gm.is_marlin_compatible(dict(bits=3, group_size=128, sym=True, desc_act=False))
+    assert gm.override_quantization_method(dict(bits=4, group_size=128, sym=True, desc_act=True), None) == "gptq_marlin"
+    ct = get_quantization_config("compressed-tensors").from_config({
+        "config_groups": {"g0": {"targets": ["Linear"],
+                                 "weights": {"num_bits": 8, "type": "int", "symmetric": True, "strategy": "channel"},
+                                 "input_activations": {"num_bits": 8, "type": "int", "dynamic": True, "strategy": "token"}}}})
+    sch = ct.get_scheme(None)
+    assert type(sch).__name__ == "CompressedTensorsW8A8" and not sch.is_static_input_scheme
+
+
+def test_paged_attention_v1_v2_heuristic():
+    """truth table of the reference's choice (paged_attn.py:112-121)"""
+    from neural_magic_vllm_amd.attention.ops.paged_attn import PagedAttention
+    cases = {(512, 1, 32): True, (513, 1, 32): False, (513, 16, 32): False, (513, 17, 32): True,
+             (8192, 64, 32): True, (8193, 64, 32): False, (4096, 8, 64): False, (100, 1, 1): True}
+    for (msl, ns, nh), exp in cases.items():
+        assert PagedAttention.use_v1(msl, ns, nh) == exp, (msl, ns, nh)
+    assert PagedAttention.get_kv_cache_shape(10, 16, 8, 128) == (2, 10, 16 * 8 * 128)

@@ -22,6 +22,7 @@ for step in "$@"; do
     benchtiny) run benchtiny python bench.py --model tiny --steps 16 --warmup 2 --batch 8 --context 64 ;;
     w8)     run t_w8 python -m pytest tests/test_gpu_w8a8.py -q -m gpu --timeout 300 ;;
     wq)     run t_wq python -m pytest tests/test_gpu_wq_formats.py -q -m gpu --timeout 300 ;;
+    lm)     run t_lm python -m pytest tests/test_gpu_linear_methods.py -q -m gpu --timeout 300 ;;
     w4)     run t_w4 python -m pytest tests/test_gpu_w4a16.py -q -m gpu --timeout 300 ;;
     all)    run t_all python -m pytest tests -q -m gpu --timeout 300 ;;
     bench)  run bench python bench.py ;;

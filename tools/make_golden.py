@@ -172,6 +172,56 @@ def gen_quant():
              marlin_s=helpers.to_np(ms), perm=perm.numpy(), marlin_q_w_perm=mw_perm.numpy())
 
 
+def gen_param_tables():
+    """parameter names / shapes / dtypes / sharding attributes the reference's LinearMethods create
+    for the Llama-3-8B qkv projection (last row)."""
+    import json
+    load_reference_python()
+    from vllm.model_executor.layers.quantization import QUANTIZATION_METHODS
+    cfgs = {
+        "gptq_marlin": dict(bits=4, group_size=128, desc_act=False, sym=True),
+        "gptq_marlin_act_order": dict(bits=4, group_size=128, desc_act=True, sym=True),
+        "gptq": dict(bits=4, group_size=128, desc_act=False),
+        "awq": dict(w_bit=4, q_group_size=128, zero_point=True),
+        "marlin": dict(group_size=128),
+        "fp8": dict(quant_method="fp8", activation_scheme="static"),
+    }
+    keep = ("input_dim", "output_dim", "packed_dim", "pack_factor", "marlin_tile_size",
+            "needs_scalar_to_array")
+    out = {}
+
+    class Dummy(torch.nn.Module):
+        pass
+
+    for name, cfg in cfgs.items():
+        method_name = name.replace("_act_order", "")
+        qc = QUANTIZATION_METHODS[method_name].from_config(cfg)
+        lm_cls = type(qc.get_quant_method.__func__) if False else None
+        # build the linear method directly (get_quant_method needs a LinearBase instance)
+        import importlib
+        mod = importlib.import_module(type(qc).__module__)
+        layer = Dummy()
+        try:
+            lm = [getattr(mod, n) for n in dir(mod)
+                  if n.endswith("LinearMethod") and n != "LinearMethodBase"][0](qc)
+            lm.create_weights(layer, 4096, [4096, 1024, 1024], 4096, 6144,
+                              torch.float16 if name in ("gptq", "marlin") else torch.bfloat16,
+                              weight_loader=None)
+        except RuntimeError as e:  # e.g. the legacy marlin method allocates its workspace on "cuda"
+            print(f"  (skipped {name}: {str(e)[:60]})")
+            continue
+        table = {}
+        for pname, prm in layer.named_parameters():
+            attrs = {k: (str(getattr(prm, k)) if k == "pack_factor" else getattr(prm, k))
+                     for k in keep if hasattr(prm, k)}
+            table[pname] = dict(shape=list(prm.shape), dtype=str(prm.dtype), device=prm.device.type,
+                                attrs=attrs)
+        out[name] = table
+    with open(os.path.join(GOLD, "linear_method_params.json"), "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    print("  linear_method_params.json")
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     build_ref.build()
@@ -180,4 +230,7 @@ if __name__ == "__main__":
     gen_cache()
     gen_glue()
     gen_quant()
+    gen_param_tables()
     print("done")
+
+
