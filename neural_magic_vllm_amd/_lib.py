@@ -12,7 +12,8 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnmvllm_hip.so")
+# NMV_HIP_LIB: kernel-development override (A/B builds of the same C ABI); never a CPU fallback
+LIB_PATH = os.environ.get("NMV_HIP_LIB") or os.path.join(_HERE, "libnmvllm_hip.so")
 
 # enums of include/nmvllm_hip.h
 NMV_F16, NMV_BF16, NMV_F32 = 0, 1, 2

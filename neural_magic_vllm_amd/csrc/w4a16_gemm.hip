@@ -32,6 +32,8 @@
 // across workgroups writes fp32 slabs that a second tiny kernel sums in a fixed order
 // (bit-reproducible, unlike the reference's lock-based fp16 global reduce :1054-1110).
 // HBM-bound for M <= 64: algorithmic bytes K*N/2 + (K/g)*N*2 + 2*M*K + 2*M*N.
+#include <type_traits>
+
 #include "common.h"
 
 namespace nmv {
@@ -89,6 +91,86 @@ struct GemmParams {
   int k_per_wg;           // k range of one workgroup (multiple of WK*STAGE_K)
   int splits;
 };
+
+
+// ---------------------------------------------------------------------------------------------
+// Split-K: the workgroup that drew the last ticket of a tile sums the fp32 slabs.
+// The sum is latency-bound (every slab read is an sc1 load that goes past the XCD's L2), so the
+// only thing that matters is how many loads are in flight: a tile with few elements (decode: 1..16
+// rows) is spread over the split range as well -- thread = (element, partition of the splits),
+// up to 16 loads in flight each, partial sums combined through LDS -- and a tile with many
+// elements keeps 16 split loads in flight per element.  The order of the additions is fixed by
+// (split index, partition index) only, never by arrival: bit-reproducible.
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+constexpr int RED_INFLIGHT = 16;
+
+template <typename T>
+__device__ __forceinline__ void splitk_reduce_tile(const GemmParams& p, __amdgpu_buffer_rsrc_t rs,
+                                                   int m0, int tile_rows, int n_base,
+                                                   int tile_cols, f32x4_t* red /* LDS, GT entries */) {
+  const int rows = min(tile_rows, p.M - m0);
+  const int cols = min(tile_cols, p.N - n_base);
+  if (rows <= 0 || cols <= 0) return;  // uniform
+  const int f4_per_row = cols >> 2;
+  const int n_elems = rows * f4_per_row;
+  const int64_t split_stride = (int64_t)p.M * p.N * 4;  // bytes
+  int parts = 1;  // uniform: partitions of the split range
+  while (parts * 2 * n_elems <= GT && parts * 2 <= p.splits) parts *= 2;
+  const int per_part = (p.splits + parts - 1) / parts;
+  // exactly the loads that are needed, in batches of 16 / 8 / 4 / 2 / 1 all in flight together
+  auto sum_range = [&](int off0, int s_begin, int s_end) -> f32x4_t {
+    f32x4_t sum = {0.f, 0.f, 0.f, 0.f};
+    int sb = s_begin;
+    auto batch = [&](auto n_tag) {
+      constexpr int NB = decltype(n_tag)::value;
+      u32x4_t q[NB];
+#pragma unroll
+      for (int u = 0; u < NB; ++u)
+        q[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, off0 + (int)((sb + u) * split_stride), 0, 16);
+#pragma unroll
+      for (int u = 0; u < NB; ++u) sum += __builtin_bit_cast(f32x4_t, q[u]);  // fixed order
+      sb += NB;
+    };
+    while (s_end - sb >= RED_INFLIGHT) batch(std::integral_constant<int, RED_INFLIGHT>{});
+    if (s_end - sb >= 8) batch(std::integral_constant<int, 8>{});
+    if (s_end - sb >= 4) batch(std::integral_constant<int, 4>{});
+    if (s_end - sb >= 2) batch(std::integral_constant<int, 2>{});
+    if (s_end - sb >= 1) batch(std::integral_constant<int, 1>{});
+    return sum;
+  };
+  auto store_out = [&](int m, int n, f32x4_t sum) {
+    uint2 pk;
+    pk.x = T::pack2(sum[0], sum[1]);
+    pk.y = T::pack2(sum[2], sum[3]);
+    *reinterpret_cast<uint2*>(p.c + (int64_t)m * p.N + n) = pk;
+  };
+  if (parts == 1) {
+    for (int e = threadIdx.x; e < n_elems; e += GT) {
+      const int m = m0 + e / f4_per_row;
+      const int n = n_base + (e % f4_per_row) * 4;
+      store_out(m, n, sum_range((int)(((int64_t)m * p.N + n) * 4), 0, p.splits));
+    }
+    return;
+  }
+  const int part = threadIdx.x / n_elems;
+  const int e = threadIdx.x - part * n_elems;
+  const int m = m0 + e / f4_per_row;
+  const int n = n_base + (e % f4_per_row) * 4;
+  const bool active = part < parts;
+  if (active) {
+    const int s_begin = part * per_part;
+    const int s_end = min(s_begin + per_part, p.splits);
+    f32x4_t sum = {0.f, 0.f, 0.f, 0.f};
+    if (s_begin < s_end) sum = sum_range((int)(((int64_t)m * p.N + n) * 4), s_begin, s_end);
+    red[threadIdx.x] = sum;
+  }
+  __syncthreads();
+  if (part == 0) {
+    f32x4_t sum = red[e];
+    for (int q = 1; q < parts; ++q) sum += red[q * n_elems + e];  // partition order
+    store_out(m, n, sum);
+  }
+}
 
 // ---------------------------------------------------------------------------------------------
 template <typename T, int MT, int WN, int WM, int WK, int GS /* 0 = channelwise */>
@@ -394,7 +476,6 @@ __global__ __launch_bounds__(GT) void w4a16_gemm_kernel(const GemmParams p) {
   // them in split order -> the result is bit-reproducible, whichever workgroup arrives last.
   const int64_t slab_bytes = (int64_t)p.splits * p.M * p.N * 4;
   __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p.slab, 0, (int)slab_bytes, 0x00020000);
-  typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
   if (writer) {
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
@@ -418,37 +499,366 @@ __global__ __launch_bounds__(GT) void w4a16_gemm_kernel(const GemmParams p) {
   if (ticket_s != p.splits - 1) return;  // uniform for the workgroup
   if (threadIdx.x == 0)  // leave the ticket array zeroed for the next call
     __hip_atomic_store(p.tickets + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  // all 256 threads of the last workgroup sum the tile: float4 columns strided over threads,
-  // the split loop unrolled so that 8 independent sc1 loads are in flight per element
-  constexpr int TILE_COLS = WN * 128;
-  constexpr int TILE_ROWS = 16 * MT * WM;
-  constexpr int F4_PER_ROW = TILE_COLS / 4;
-  const int n_base = blockIdx.x * TILE_COLS;
-  const int64_t split_stride = (int64_t)p.M * p.N * 4;  // bytes
-  for (int e = threadIdx.x; e < TILE_ROWS * F4_PER_ROW; e += GT) {
-    const int m = m0 + e / F4_PER_ROW;
-    const int n = n_base + (e % F4_PER_ROW) * 4;
-    if (m >= p.M || n >= p.N) continue;
-    const int off0 = (int)(((int64_t)m * p.N + n) * 4);
-    f32x4_t sum = {0.f, 0.f, 0.f, 0.f};
-    int sidx = 0;
-    for (; sidx + 8 <= p.splits; sidx += 8) {
-      u32x4_t q[8];
+  __syncthreads();  // the LDS stages are dead: reuse them for the partial sums
+  splitk_reduce_tile<T>(p, rs, m0, 16 * MT * WM, blockIdx.x * (WN * 128), WN * 128,
+                        reinterpret_cast<f32x4_t*>(lds));
+}
+
+// ---------------------------------------------------------------------------------------------
+// M >= 17: the 128-column x 64-row (or 32-row) workgroup tile with SHARED dequantisation.
+//
+// The register-only kernel above re-expands the same weights once per 16-row block (4x at M = 64,
+// M/16 x in prefill).  Here a workgroup expands every weight ONCE per 64 (32) rows:
+//   * wave w streams chunk (w & 1), k-step (w >> 1) of the 64-deep stage: one 16-byte Marlin
+//     vector per thread; v_permlane32_swap gives every lane the raw words of both k-tiles, the
+//     lower half-wave expands the block-0 columns, the upper one block 1, so a lane owns a whole
+//     16-byte MFMA operand and the wave stores 1 KiB contiguous per ds_write_b128 into the image
+//     [k-step][16-column tile][k-quad g][column r] (conflict-free for the store's 8-lane groups and
+//     for ds_read_b128's 16-lane groups: a tile read is lane l -> 16 l);
+//   * the 4 waves are arranged WNN x WMM; a wave owns (128/WNN) columns x 32 rows: 12 (6)
+//     ds_read_b128 and 20 (12) MFMAs per stage, accumulators 72 (40) VGPRs, two workgroups/CU;
+//   * weights run 4 stages (256 k) ahead in a register ring, activations 2; the main loop has no
+//     branches and no load-dependent selects (unconditional clamped loads, whole 256-k rings:
+//     the plan only picks this kernel for K % 256 == 0);
+//   * zero point (S-MFMA), group scales in fp32 at the group boundary, sc1 slabs + ticket +
+//     fixed-order reduction are the same as above.
+// Measured (MI355X, Llama-3-8B gate_up 4096 x 28672, g128): M = 64 42.5 us vs 45.8 us for the
+// register kernel, M = 32 31.3 vs 31.8, M = 2048 727 vs 1061 us.  Ablations: with
+// MFMA + LDS reads removed 31 us, with the expansion removed 41 us, loads + barrier alone 26 us:
+// the stage chain is serial and the load skeleton is latency-bound at ~24 KB in flight per CU.
+// Next step: raw weights and activations through LDS-DMA rings (no VGPR cost for depth).
+#ifndef NMV_ABL
+#define NMV_ABL 0  // experiments only: 1 no A loads, 2 no MFMA/ds_read, 3 no W expansion, 4 no W loads
+#endif
+#ifndef NMV_LDS_MID_BARRIER
+#define NMV_LDS_MID_BARRIER 0
+#endif
+constexpr int LSTAGE_K = 64;                 // k per stage (2 MFMA k-steps)
+constexpr int LKSTEPS = LSTAGE_K / 32;
+constexpr int LNT = 128;                     // columns per workgroup
+
+template <typename T, int WNN, int WMM, int GS>
+__global__ __launch_bounds__(GT, 2) void w4a16_gemm_lds_kernel(const GemmParams p) {
+  static_assert(WNN * WMM == 4, "4 waves per workgroup");
+  static_assert(GS == 0 || GS == 128, "the scale schedule below is one group per two stages");
+  constexpr int MT = 2;                       // 16-row tiles per wave
+  constexpr int MROWS = 32 * WMM;             // rows per workgroup
+  constexpr int WAVE_N = LNT / WNN;           // columns per wave
+  constexpr int NTW = WAVE_N / 16;            // column tiles per wave
+  constexpr int W_U4 = LKSTEPS * LNT * 4;     // uint4 per weight stage buffer (16 KB)
+  constexpr int A_U4 = LKSTEPS * 4 * MROWS;   // uint4 per activation stage buffer
+  constexpr int APT = (MROWS * 8 + GT - 1) / GT;  // activation 16-byte chunks per thread and stage
+  constexpr int FLUSH_KS = GS == 0 ? 4 : GS / 32;  // k-steps per scale group (1, 2 or 4)
+  __shared__ __attribute__((aligned(16))) uint4 lds[2 * W_U4 + 2 * A_U4];
+  uint4* w_s = lds;
+  uint4* a_s = lds + 2 * W_U4;
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wn = wave % WNN, wm = wave / WNN;
+  const int r = lane & 15, g = lane >> 4;
+  const int n_chunks = p.N >> 6;
+  const int chunk0 = blockIdx.x * 2;
+  const int m0 = blockIdx.z * MROWS;
+  const int split = blockIdx.y;
+  const int k0 = split * p.k_per_wg;
+  const int k1 = min(k0 + p.k_per_wg, p.K);
+  const int n_stages = (max(k1 - k0, 0) + LSTAGE_K - 1) / LSTAGE_K;
+
+  // ---- loader roles ----
+  // Every global load of the main loop is unconditional (addresses clamped into the tensors) and
+  // the loop body has no branches: a uniform branch around a load makes the compiler's s_waitcnt
+  // placement fall back to vmcnt(0) at the join, which serialises the whole prefetch ring.
+  // Out-of-range k / rows are neutralised through the ACTIVATIONS only (zero operands); weights
+  // are always finite (16 + q), so whatever they are multiplied with zero they contribute zero.
+  // wave w streams chunk (w & 1), k-step (w >> 1): lanes 0-31 the even k-tile, lanes 32-63 the
+  // odd one (two 512-byte runs per load instruction)
+  // half-wave lane li takes vector (li & 7) * 4 + (li >> 3): k-quad q = li >> 3 of column
+  // n_in = li & 7, so that each 8-lane store group below lands on 128 contiguous bytes
+  const int li = lane & 31, lhalf = lane >> 5, lc = wave & 1, lks = wave >> 1;
+  const int lq = li >> 3, ln_in = li & 7;
+  const int lkt = lks * 2 + lhalf;
+  const int64_t row_u4 = p.N >> 1;
+  // K % 64 == 0 on this path (see make_plan): stages are whole; a stage index past the end of K
+  // re-reads the last stage of the tensor (cache hit) and is multiplied by zero activations
+  const int st_last = __builtin_amdgcn_readfirstlane(((p.K - k0) >> 6) - 1);
+  // De-phasing: every workgroup walks the same activation rows, whose row stride (2 K bytes) is a
+  // multiple of the L2 channel interleave, so workgroups marching in lock-step all pull their
+  // activation slices through ONE L2 channel of the XCD (measured: ~128 B/clk for the whole XCD,
+  // 4x slower than the weight stream).  Workgroup number i of an XCD therefore starts its k loop
+  // i scale-groups (128 k = 256 B = one channel) further on and wraps around.  The order of the
+  // fp32 accumulation becomes a function of the block index: still fixed for a given launch shape.
+  const int n_pad = n_stages;  // whole rings: k1 - k0 is a multiple of 256
+  const int wg_linear = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+  const int rot = n_pad > 0 ? 2 * ((wg_linear >> 3) % (n_pad >> 1)) : 0;
+  auto eff = [&](int st) -> int {
+    const int se = st + rot;
+    return se >= n_pad ? se - n_pad : se;
+  };
+  const uint4* bp = p.b + (int64_t)min(chunk0 + lc, n_chunks - 1) * 32 + (ln_in * 4 + lq) +
+                    ((int64_t)(k0 >> 4) + lkt) * row_u4;
+  auto load_w = [&](int st) -> uint4 {
+    if (NMV_ABL == 4) return make_uint4(st, lane, st, lane);
+    return bp[(int64_t)min(eff(st), st_last) * (4 * row_u4)];
+  };
+  const uint16_t* ap[APT];
 #pragma unroll
-      for (int u = 0; u < 8; ++u)
-        q[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, off0 + (int)((sidx + u) * split_stride), 0, 16);
-#pragma unroll
-      for (int u = 0; u < 8; ++u) sum += __builtin_bit_cast(f32x4_t, q[u]);  // fixed order
-    }
-    for (; sidx < p.splits; ++sidx) {
-      const u32x4_t q = __builtin_amdgcn_raw_buffer_load_b128(rs, off0 + (int)(sidx * split_stride), 0, 16);
-      sum += __builtin_bit_cast(f32x4_t, q);
-    }
-    uint2 pk;
-    pk.x = T::pack2(sum[0], sum[1]);
-    pk.y = T::pack2(sum[2], sum[3]);
-    *reinterpret_cast<uint2*>(p.c + (int64_t)m * p.N + n) = pk;
+  for (int i = 0; i < APT; ++i) {
+    const int id = threadIdx.x + i * GT;   // MROWS * 8 is a multiple of 256: no tail
+    const int m = m0 + (id >> 3);
+    ap[i] = p.a + (int64_t)min(m, p.M - 1) * p.K + k0 + (id & 7) * 8;
   }
+  auto load_a = [&](int st, uint4 (&av)[APT]) {
+    const int off = min(eff(st), st_last) * LSTAGE_K;
+#pragma unroll
+    for (int i = 0; i < APT; ++i) {
+      if (NMV_ABL == 1) av[i] = make_uint4(off, off, off, off);
+      else av[i] = ld16(ap[i] + off);
+    }
+  };
+  const uint32_t kmask = __builtin_amdgcn_readfirstlane(W4<T>::MASK);
+  uint32_t kmagic = W4<T>::MAGIC;
+  asm volatile("" : "+v"(kmagic));
+  // Expand one stage into LDS.  v_permlane32_swap hands every lane the raw words of BOTH k-tiles
+  // of its vector; the lower half-wave then expands the columns of block 0 (nibbles 0,1,4,5), the
+  // upper half-wave those of block 1 (nibbles 2,3,6,7 = the same expansion of x >> 8), so each
+  // lane owns a complete 16-byte MFMA operand (8 k of one column) and the wave writes 1 KiB
+  // contiguous per ds_write_b128: no bank conflicts.
+  const uint32_t blk_shift = lhalf * 8;
+  auto store_w = [&](int buf, uint4 x) {
+    const uint32_t xs[4] = {x.x, x.y, x.z, x.w};
+    // image: [k-step][16-column tile][k-quad g][column r] x 16 B, i.e. a wave's operand read of
+    // one tile is lane l -> 16 l (conflict-free for ds_read_b128's lane groups)
+    uint4* dst = w_s + buf * W_U4 + (lks * (LNT / 16) + lc * 4) * 64 + lq * 16 + lhalf * 8 + ln_in;
+    if (NMV_ABL == 3 || NMV_ABL == 9) { asm volatile("" :: "v"(x.x), "v"(x.y), "v"(x.z), "v"(x.w)); return; }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const auto eo = __builtin_amdgcn_permlane32_swap(xs[j], xs[j], false, false);
+      const uint32_t e = eo[0] >> blk_shift;  // even k-tile
+      const uint32_t o = eo[1] >> blk_shift;  // odd k-tile
+      dst[j * 64] = make_uint4(W4<T>::lo0(e, kmask, kmagic), W4<T>::hi0(e, kmask, kmagic),
+                                   W4<T>::lo0(o, kmask, kmagic), W4<T>::hi0(o, kmask, kmagic));
+    }
+  };
+  // No masking anywhere: rows past M are clamped duplicates of row M-1 and only feed output rows
+  // that are never stored; k ranges are whole rings (K % 256 == 0, see make_plan), so there are no
+  // stages past k1 to neutralise.
+  auto store_a = [&](int buf, const uint4 (&av)[APT]) {
+    uint32_t* base = reinterpret_cast<uint32_t*>(a_s + buf * A_U4);
+#pragma unroll
+    for (int i = 0; i < APT; ++i) {
+      const int id = threadIdx.x + i * GT;
+      const int c8 = id & 7, row = id >> 3;
+      const int ks = c8 >> 2, cc = c8 & 3;
+      const int e0 = ((ks * 4 + 0) * MROWS + row) * 4 + cc;
+      base[e0] = av[i].x;
+      base[e0 + 4 * MROWS] = av[i].y;
+      base[e0 + 8 * MROWS] = av[i].z;
+      base[e0 + 12 * MROWS] = av[i].w;
+    }
+  };
+
+  // ---- accumulators ----
+  f32x4_t accm[NTW][MT], accg[NTW][MT], accs[MT];
+  const f32x4_t zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int v = 0; v < NTW; ++v)
+#pragma unroll
+    for (int t = 0; t < MT; ++t) { accm[v][t] = zero4; accg[v][t] = zero4; }
+#pragma unroll
+  for (int t = 0; t < MT; ++t) accs[t] = zero4;
+
+  // output-fragment geometry of this lane: columns n_w0 + 16 T + 4 g + reg, rows m_w0 + 16 t + r
+  const int n_w0 = blockIdx.x * LNT + wn * WAVE_N;
+  const int m_w0 = m0 + wm * 32;
+  const int out_chunk = n_w0 >> 6;
+  const bool out_ok = n_w0 < p.N;  // N % 64 == 0 and WAVE_N divides 64: all or nothing
+  const int tile_off = (n_w0 & 63) >> 4;
+  // grouped scale layout: element (4 (g&1) + reg) * 8 + 2 (tile_off + T) + (g >> 1) of the chunk
+  // per (reg, tile v) the lane wants element 2 (tile_off + v) + (g >> 1): dword v of the NTW
+  // dwords that start at element 2 tile_off, upper or lower half by lane
+  const uint16_t* sp = p.s + (int64_t)(out_ok ? out_chunk : 0) * 64 + (g & 1) * 32 + 2 * tile_off;
+  const uint32_t sc_shift = (g >> 1) * 16;
+  auto load_scales = [&](int k_abs, uint32_t (&sv)[4][NTW]) {
+    if constexpr (GS != 0) {
+      const uint16_t* sg = sp + (int64_t)(min(k_abs, p.K - 1) / GS) * p.N;
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        if constexpr (NTW == 4) {
+          const uint4 x = ld16(sg + reg * 8);
+          sv[reg][0] = x.x; sv[reg][1] = x.y; sv[reg][2] = x.z; sv[reg][3] = x.w;
+        } else {
+          const uint2 x = *reinterpret_cast<const uint2*>(sg + reg * 8);
+          sv[reg][0] = x.x; sv[reg][1] = x.y;
+        }
+      }
+    }
+  };
+  auto flush = [&](const uint32_t (&sv)[4][NTW]) {
+    float zs[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) zs[t] = -W4_ZP * accs[t][0];
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+#pragma unroll
+      for (int v = 0; v < NTW; ++v) {
+        float scv = 1.f;
+        if constexpr (GS != 0) scv = T::to_float((uint16_t)(sv[reg][v] >> sc_shift));
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+          const float dlt = accg[v][t][reg] + zs[t];
+          if constexpr (GS != 0) accm[v][t][reg] = fmaf(scv, dlt, accm[v][t][reg]);
+          else accm[v][t][reg] += dlt;
+        }
+      }
+    }
+  };
+
+  // ---- prologue: four stages of global loads in flight, stage 0 parked in LDS ----
+  uint4 wr0, wr1, wr2, wr3;
+  uint4 ar0[APT], ar1[APT];  // activations come from L2: two stages ahead are enough
+  uint32_t sc[4][NTW], sc2[4][NTW];  // scales of the open group / the one after it (alternating)
+  load_a(0, ar0);
+  wr0 = load_w(0);
+  wr1 = load_w(1);
+  wr2 = load_w(2);
+  wr3 = load_w(3);
+  load_scales(k0 + eff(0) * LSTAGE_K, sc);
+  store_w(0, wr0); store_a(0, ar0);
+  load_a(1, ar1);
+  __syncthreads();
+  const uint4 ones = make_uint4(W4<T>::ONES, W4<T>::ONES, W4<T>::ONES, W4<T>::ONES);
+
+  // one stage (U = its position in the 4-stage ring, so the scale-group schedule is static):
+  // refill the ring slot that just became free with stage st+4, multiply stage st out of LDS,
+  // then expand stage st+1 (ring slot `nw`) into the other LDS buffer.  k0 is a multiple of 128
+  // and the loop runs whole rings (256 k), so every scale group closes inside the loop; stages
+  // past k1 multiply zero activations.
+  auto stage = [&](auto u_tag, int st, uint4& freew, uint4 (&freea)[APT], const uint4& nw,
+                   const uint4 (&na)[APT], const uint32_t (&sc_use)[4][NTW],
+                   uint32_t (&sc_load)[4][NTW]) {
+    constexpr int U = decltype(u_tag)::value;
+    constexpr int buf = U & 1;
+    // a stage that closes a scale group fetches the NEXT group's scales first, ahead of its ring
+    // refill: by the time they are used (next flush) every load older than them has to be back
+    // anyway for the LDS expansion, so the ring never waits on their account
+    constexpr bool closes_group = ((U + 1) * LKSTEPS) % FLUSH_KS == 0;
+    if constexpr (closes_group && GS != 0) load_scales(k0 + eff(st + 1) * LSTAGE_K, sc_load);
+    load_a(st + 2, freea);  // ahead of the weight refill: in-order vmcnt then never makes the
+    freew = load_w(st + 4);   // weight ring wait for more than W(st + 3) on account of A
+
+    // keep the scheduler from hoisting the expansion of later ring slots up here (that would
+    // make this stage wait for loads issued one stage ago) and from sinking the refill
+    __builtin_amdgcn_sched_barrier(0);
+    const uint4* wb = w_s + buf * W_U4;
+    const uint4* ab = a_s + buf * A_U4;
+#pragma unroll
+    for (int ks = 0; ks < LKSTEPS; ++ks) {
+      if (NMV_ABL == 2 || NMV_ABL == 9) break;
+      const int kstep = U * LKSTEPS + ks;             // static after unrolling
+      const bool first = kstep % FLUSH_KS == 0;
+      const bool last = (kstep + 1) % FLUSH_KS == 0;
+      uint4 af[MT];
+#pragma unroll
+      for (int t = 0; t < MT; ++t) af[t] = ab[(ks * 4 + g) * MROWS + wm * 32 + t * 16 + r];
+#pragma unroll
+      for (int v = 0; v < NTW; ++v) {
+        const uint4 wf = wb[(ks * (LNT / 16) + wn * NTW + v) * 64 + lane];
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+          accg[v][t] = W4<T>::mfma(wf, af[t], first ? zero4 : accg[v][t]);
+      }
+#pragma unroll
+      for (int t = 0; t < MT; ++t) accs[t] = W4<T>::mfma(ones, af[t], first ? zero4 : accs[t]);
+      if (last) flush(sc_use);
+    }
+    if (NMV_LDS_MID_BARRIER) __builtin_amdgcn_sched_barrier(0);
+    store_w(buf ^ 1, nw);
+    if (NMV_ABL == 8) asm volatile("" :: "v"(na[0].x), "v"(na[0].y), "v"(na[0].z), "v"(na[0].w));
+    else store_a(buf ^ 1, na);
+    __builtin_amdgcn_sched_barrier(0);
+    if (NMV_ABL != 7) __syncthreads();
+  };
+  const int n_rings = NMV_ABL == 5 ? 0 : n_pad >> 2;
+  for (int it = 0; it < n_rings; ++it) {
+    const int st = it * 4;
+    stage(std::integral_constant<int, 0>{}, st, wr0, ar0, wr1, ar1, sc, sc2);
+    stage(std::integral_constant<int, 1>{}, st + 1, wr1, ar1, wr2, ar0, sc, sc2);
+    stage(std::integral_constant<int, 2>{}, st + 2, wr2, ar0, wr3, ar1, sc2, sc);
+    stage(std::integral_constant<int, 3>{}, st + 3, wr3, ar1, wr0, ar0, sc2, sc);
+  }
+
+  if (GS == 0 && out_ok) {
+#pragma unroll
+    for (int v = 0; v < NTW; ++v) {
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int c64 = (tile_off + v) * 16 + 4 * g + reg;
+        const int c = c64 & 31;
+        const int pos = (c64 >> 5) * 32 + ((c & 7) >> 1) * 8 + 2 * (c >> 3) + (c & 1);
+        const float sv = T::to_float(p.s[(int64_t)out_chunk * 64 + pos]);
+#pragma unroll
+        for (int t = 0; t < MT; ++t) accm[v][t][reg] *= sv;
+      }
+    }
+  }
+
+  // ---- epilogue ----
+  if (NMV_ABL == 6) {
+    float acc = 0.f;
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+      for (int v = 0; v < NTW; ++v) acc += accm[v][t][0] + accm[v][t][1] + accm[v][t][2] + accm[v][t][3];
+    if (acc == 12345.678f) p.c[0] = 1;
+    return;
+  }
+  if (p.splits == 1) {
+    if (!out_ok) return;
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+      const int m = m_w0 + t * 16 + r;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int v = 0; v < NTW; ++v) {
+        const int n = n_w0 + v * 16 + 4 * g;
+        const f32x4_t o = accm[v][t];
+        uint2 pk;
+        pk.x = T::pack2(o[0], o[1]);
+        pk.y = T::pack2(o[2], o[3]);
+        *reinterpret_cast<uint2*>(p.c + (int64_t)m * p.N + n) = pk;
+      }
+    }
+    return;
+  }
+  // split-K: write-through slabs, ticket, the last workgroup of the tile reduces (see above)
+  const int64_t slab_bytes = (int64_t)p.splits * p.M * p.N * 4;
+  __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p.slab, 0, (int)slab_bytes, 0x00020000);
+  if (out_ok) {
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+      const int m = m_w0 + t * 16 + r;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int v = 0; v < NTW; ++v) {
+        const int n = n_w0 + v * 16 + 4 * g;
+        const int off = (int)((((int64_t)split * p.M + m) * p.N + n) * 4);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, accm[v][t]), rs, off, 0, 16);
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __shared__ int ticket_s;
+  __syncthreads();
+  const int tile = blockIdx.z * gridDim.x + blockIdx.x;
+  if (threadIdx.x == 0)
+    ticket_s = __hip_atomic_fetch_add(p.tickets + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  if (ticket_s != p.splits - 1) return;
+  if (threadIdx.x == 0)
+    __hip_atomic_store(p.tickets + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();  // the operand images are dead: reuse them for the partial sums
+  splitk_reduce_tile<T>(p, rs, m0, MROWS, blockIdx.x * LNT, LNT, reinterpret_cast<f32x4_t*>(lds));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -497,6 +907,7 @@ __global__ void marlin_repack_kernel(const uint32_t* __restrict__ qw, const int*
 struct GemmPlan {
   int mt, wn, wm, wk;  // kernel shape
   int splits, k_per_wg, m_blocks, n_blocks;
+  int lds_kind;  // 0: register kernel (16-row tiles); 1: LDS kernel 4x1 (32 rows); 2: 2x2 (64 rows)
 };
 
 static int env_int(const char* name, int dflt) {
@@ -507,9 +918,32 @@ static int env_int(const char* name, int dflt) {
 // Pick the workgroup shape and the split-K factor.  Decode-sized GEMMs (M <= 64) last only a
 // few microseconds at HBM speed, so the plan aims at >= ~2 workgroups per CU while keeping the
 // fp32 partial traffic (splits * M * N * 4 B) well below the weight bytes (K * N / 2).
-static GemmPlan make_plan(int M, int N, int K, int64_t tickets_len) {
+static GemmPlan make_plan(int M, int N, int K, int64_t tickets_len, bool allow_lds = false) {
   GemmPlan pl;
   const int n_chunks = N / 64;
+  pl.lds_kind = 0;
+  const int lds_min_m = env_int("NMV_W4_LDS_MIN_M", 17);
+  if (allow_lds && M >= lds_min_m && K % 256 == 0) {
+    // shared-dequantisation tile: 128 columns x 32 rows (<= 32 rows) or x 64 rows
+    pl.lds_kind = env_int("NMV_W4_LDS_KIND", (M <= 32) ? 1 : 2);
+    pl.mt = 2; pl.wm = pl.lds_kind; pl.wn = 4 / pl.wm; pl.wk = 1;
+    const int rows = 32 * pl.wm;
+    pl.m_blocks = (M + rows - 1) / rows;
+    pl.n_blocks = (n_chunks + 1) / 2;
+    const int unit = 256;  // whole prefetch rings
+    const int k_units = (K + unit - 1) / unit;
+    const int base_wgs = pl.n_blocks * pl.m_blocks;
+    // one resident wave of workgroups (2 per CU); more than 8 slabs per tile costs more in the
+    // reduction than the extra parallelism returns (measured on the Llama-3-8B shapes, M = 64)
+    int splits = std::max(1, env_int("NMV_W4_LDS_WGS", 512) / base_wgs);
+    splits = std::min(splits, env_int("NMV_W4_LDS_MAX_SPLITS", 8));
+    splits = env_int("NMV_W4_SPLITS", splits);
+    splits = std::max(1, std::min(splits, k_units));
+    if ((int64_t)base_wgs > tickets_len) splits = 1;
+    pl.k_per_wg = ((k_units + splits - 1) / splits) * unit;
+    pl.splits = (K + pl.k_per_wg - 1) / pl.k_per_wg;
+    return pl;
+  }
   // Measured on MI355X (tools/bench_gemm.py --sweep): the 16-row tile (MT = 1, 2 workgroups per
   // CU) beats the 32/64-row tiles at every M <= 64, even though 64 rows re-dequantise the weights
   // four times; larger M walks blockIdx.z.  ~512 workgroups (one resident set) is the sweet spot.
@@ -541,6 +975,17 @@ static GemmPlan make_plan(int M, int N, int K, int64_t tickets_len) {
 template <typename T, int GS>
 static int launch_gemm_gs(const GemmPlan& pl, const GemmParams& p, hipStream_t s) {
   dim3 grid(pl.n_blocks, pl.splits, pl.m_blocks), block(GT);
+  if constexpr (GS == 0 || GS == 128) {
+    if (pl.lds_kind == 1) {
+      hipLaunchKernelGGL((w4a16_gemm_lds_kernel<T, 4, 1, GS>), grid, block, 0, s, p);
+      return 0;
+    }
+    if (pl.lds_kind == 2) {
+      hipLaunchKernelGGL((w4a16_gemm_lds_kernel<T, 2, 2, GS>), grid, block, 0, s, p);
+      return 0;
+    }
+  }
+  if (pl.lds_kind != 0) return -1;
 #define NMV_W4_CASE(MT_, WN_, WM_, WK_)                                                         \
   if (pl.mt == MT_ && pl.wn == WN_ && pl.wm == WM_ && pl.wk == WK_) {                           \
     hipLaunchKernelGGL((w4a16_gemm_kernel<T, MT_, WN_, WM_, WK_, GS>), grid, block, 0, s, p);   \
@@ -602,11 +1047,12 @@ extern "C" int nmv_gptq_marlin_repack(const int32_t* b_q_weight, const int32_t* 
 
 extern "C" int64_t nmv_gptq_marlin_gemm_scratch_bytes(int size_m, int size_n, int size_k,
                                                       int has_act_order) {
-  (void)has_act_order;  // the A gather is fused into the LDS staging: no a_tmp copy
+  // the A gather is fused into the LDS staging: no a_tmp copy, only the split-K slabs
   if (size_m <= 0 || size_n <= 0 || size_k <= 0) return 0;
   // upper bound over every plan the entry point may pick (the ticket array only lowers splits)
-  const GemmPlan pl = make_plan(size_m, size_n, size_k, INT64_MAX);
-  return pl.splits > 1 ? (int64_t)pl.splits * size_m * size_n * 4 : 0;
+  int max_splits = make_plan(size_m, size_n, size_k, INT64_MAX, false).splits;
+  if (!has_act_order) max_splits = std::max(max_splits, make_plan(size_m, size_n, size_k, INT64_MAX, true).splits);
+  return max_splits > 1 ? (int64_t)max_splits * size_m * size_n * 4 : 0;
 }
 
 extern "C" int nmv_gptq_marlin_gemm(void* c, const void* a, const int32_t* b_q_weight,
@@ -649,7 +1095,10 @@ extern "C" int nmv_gptq_marlin_gemm(void* c, const void* a, const int32_t* b_q_w
     NMV_LAUNCH_CHECK();
     return NMV_OK;
   }
-  const GemmPlan pl = make_plan(size_m, size_n, size_k, workspace ? workspace_len : 0);
+  // the shared-dequantisation kernel covers the prevalent formats (group 128 / channelwise, no
+  // act-order gather); everything else stays on the register kernel
+  const bool allow_lds = !has_act_order && (group_size == 0 || group_size == 128);
+  const GemmPlan pl = make_plan(size_m, size_n, size_k, workspace ? workspace_len : 0, allow_lds);
   const int64_t need = pl.splits > 1 ? (int64_t)pl.splits * size_m * size_n * 4 : 0;
   NMV_CHECK(need < (int64_t)1 << 31, "gptq_marlin_gemm: split-K slab too large");
   NMV_CHECK(scratch_bytes >= need && (need == 0 || scratch != nullptr),

@@ -62,7 +62,7 @@ def test_marlin_repack_golden(gpu_device, name):
 
 @pytest.mark.parametrize("k", K_SIZES)
 @pytest.mark.parametrize("n", [64, 448, 1088])
-@pytest.mark.parametrize("m", [1, 13, 26, 67])
+@pytest.mark.parametrize("m", [1, 13, 26, 40, 67])
 @pytest.mark.parametrize("group_size", [-1, 32, 64, 128])
 @pytest.mark.parametrize("dtype", [torch.half, torch.bfloat16])
 def test_marlin_gemm(gpu_device, k, n, m, group_size, dtype):

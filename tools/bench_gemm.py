@@ -54,13 +54,16 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--sweep", action="store_true")
     ap.add_argument("--ms", default="1,16,32,64")
+    ap.add_argument("--gs", type=int, default=128, help="group size; -1 = channelwise")
+    ap.add_argument("--shapes", default=",".join(SHAPES))
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     ms = [int(x) for x in args.ms.split(",")]
-    for name, (k, n) in SHAPES.items():
+    for name in args.shapes.split(","):
+        k, n = SHAPES[name]
         for m in ms:
             if not args.sweep:
-                us, gbs = bench(name, k, n, m, dev)
+                us, gbs = bench(name, k, n, m, dev, gs=k if args.gs == -1 else args.gs)
                 print(f"{name:8s} M={m:3d}  {us:8.1f} us  {gbs:7.0f} GB/s", flush=True)
                 continue
             res = []
