@@ -8,9 +8,10 @@ replayed from a captured hipGraph; inputs (weights, KV cache with `context` toke
 sequence) are resident in HBM before the timed region.
 
 Extra objects on the line:
-  roofline     -- dominant kernel = the W4A16 GEMM (w4a16_gemm_kernel): algorithmic bytes of the
-                  4 GEMMs of a layer / mean device time of those launches, measured with HIP
-                  events on the launch stream in a separate loop of the same kernels.
+  roofline     -- dominant kernel = the W4A16 GEMM (w4a16_gemm[_lds]_kernel): algorithmic bytes of
+                  the 4 GEMMs of a layer / mean device time of those 4 launches, measured live with
+                  HIP events around a hipGraph replay of the same kernels (no host launch cost).
+  ttft_ms_p50  -- p50 wall time of one 512-token prompt step (BASELINE metric's second half).
   cpu_baseline -- the oracle (oracle/oracle.c, OpenMP) on the host cores: one decoder layer's
                   dequant+GEMMs and paged attention for the same batch, scaled to a full step.
 """
@@ -44,46 +45,93 @@ def parse():
     return ap.parse_args()
 
 
-def gemm_roofline(runner, batch, dev, iters=30):
-    """HIP-event timing of the dominant kernel on its launch stream: the 4 quantised GEMMs of
-    one decoder layer at M = batch, back to back (each call = GEMM kernel [+ split-K reduce])."""
+@torch.inference_mode()
+def gemm_roofline(runner, batch, dev, groups=32):
+    """Device time of the dominant kernel: the 4 quantised GEMMs of one decoder layer at
+    M = batch (each call = ONE kernel launch; the split-K reduction is inside it), `groups`
+    launch groups rotating over all layers' weights (HBM, not the 256 MiB Infinity Cache), captured
+    in one hipGraph and timed with HIP events on the replay stream -- no host launch cost in the
+    number.  profiles/ holds the rocprofv3 kernel-trace of the same kernels (tools/gpu_ci.sh)."""
     from neural_magic_vllm_amd import _custom_ops as ops
-    layer = runner.model.model.layers[0]
-    mods = [layer.self_attn.qkv_proj, layer.self_attn.o_proj, layer.mlp.gate_up_proj,
-            layer.mlp.down_proj]
+    layers = runner.model.model.layers
+    names = ("qkv_proj", "o_proj", "gate_up_proj", "down_proj")
+
+    def mods_of(L):
+        return [L.self_attn.qkv_proj, L.self_attn.o_proj, L.mlp.gate_up_proj, L.mlp.down_proj]
+
+    mods = mods_of(layers[0])
     xs = [torch.randn((batch, m.input_size_per_partition), device=dev, dtype=runner.dtype)
           for m in mods]
-    # rotate over all layers so that weights come from HBM, not from the 256 MiB Infinity Cache
-    layers = runner.model.model.layers
 
-    def run(li):
-        L = layers[li % len(layers)]
-        for m, x in zip([L.self_attn.qkv_proj, L.self_attn.o_proj, L.mlp.gate_up_proj,
-                         L.mlp.down_proj], xs):
-            ops.gptq_marlin_gemm(x, m.qweight, m.scales, m.g_idx, m.g_idx_sort_indices,
-                                 m.workspace, 4, batch, m.output_size_per_partition,
-                                 m.input_size_per_partition, m.is_k_full)
+    def run(li, only=None):
+        for j, (m, x) in enumerate(zip(mods_of(layers[li % len(layers)]), xs)):
+            if only is None or only == j:
+                ops.gptq_marlin_gemm(x, m.qweight, m.scales, m.g_idx, m.g_idx_sort_indices,
+                                     m.workspace, 4, batch, m.output_size_per_partition,
+                                     m.input_size_per_partition, m.is_k_full)
 
-    alg = 0
+    def timed(only):
+        run(0, only)
+        torch.cuda.synchronize(dev)
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            run(0, only)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            for i in range(groups):
+                run(i, only)
+        graph.replay()
+        torch.cuda.synchronize(dev)
+        stream = torch.cuda.current_stream(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        graph.replay()
+        e1.record(stream)
+        torch.cuda.synchronize(dev)
+        return e0.elapsed_time(e1) / groups * 1e3  # us per group
+
+    algs = []
     for m in mods:
         k, n = m.input_size_per_partition, m.output_size_per_partition
-        alg += k * n // 2 + m.scales.numel() * 2 + 2 * batch * k + 2 * batch * n
-    for i in range(len(layers)):
-        run(i)
-    torch.cuda.synchronize(dev)
-    stream = torch.cuda.current_stream(dev)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record(stream)
-    for i in range(iters):
-        run(i)
-    e1.record(stream)
-    torch.cuda.synchronize(dev)
-    ms = e0.elapsed_time(e1) / iters
-    achieved = alg / (ms * 1e-3) / 1e9
-    return {"bound": "hbm", "kernel": "w4a16_gemm_kernel (4 GEMMs of one decoder layer)",
+        algs.append(k * n // 2 + m.scales.numel() * 2 + 2 * batch * k + 2 * batch * n)
+    alg = sum(algs)
+    us = timed(None)
+    per = {nm: {"us": round(timed(j), 2), "algorithmic_bytes": algs[j]} for j, nm in enumerate(names)}
+    for v in per.values():
+        v["GB/s"] = round(v["algorithmic_bytes"] / v["us"] / 1e3, 1)
+    achieved = alg / (us * 1e-6) / 1e9
+    # HBM traffic from the PMC pass (FETCH_SIZE/WRITE_SIZE, separate rocprofv3 runs, gfx950
+    # correction applied): measured offline with tools/gpu_ci.sh, summary committed under profiles/
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "gemm_traffic.json")
+    if os.path.exists(tpath):
+        with open(tpath) as f:
+            t = json.load(f)
+        traffic = t.get("by_batch", {}).get(str(batch))
+    kern = "w4a16_gemm_lds_kernel" if batch > 16 else "w4a16_gemm_kernel"
+    return {"bound": "hbm", "kernel": f"{kern} (the 4 GEMM launches of one decoder layer, M={batch})",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-            "algorithmic_bytes_per_launch_group": alg, "avg_us_per_launch_group": round(ms * 1e3, 2)}
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+            "algorithmic_bytes_per_launch_group": alg, "avg_us_per_launch_group": round(us, 2),
+            "launches_per_group": 4, "timing": "HIP events around a hipGraph replay", "per_gemm": per}
+
+
+@torch.inference_mode()
+def ttft(runner, dev, prompt_len, runs=5):
+    """p50 time to first token: one prompt of `prompt_len` tokens through the whole model (our
+    GEMM / norm / rope / cache-write kernels; prompt attention = torch SDPA)."""
+    runner.setup_batch(1, prompt_len, 8)
+    ts = []
+    for i in range(runs + 1):
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        runner.prefill(prompt_len, seed=i)
+        torch.cuda.synchronize(dev)
+        ts.append((time.perf_counter() - t0) * 1e3)
+    ts = sorted(ts[1:])
+    return round(ts[len(ts) // 2], 3)
 
 
 def cpu_baseline(arch, batch, context, budget_s=20.0):
@@ -191,6 +239,9 @@ def main():
                                 "hbm_bound_ms": round((wb + kvb) / (HBM_PEAK_GBS * 1e9) * 1e3, 4),
                                 "frac_of_hbm_bound": round((wb + kvb) / (HBM_PEAK_GBS * 1e9) / (ms_per_step * 1e-3), 4)}
         out["roofline"] = gemm_roofline(runner, args.batch, dev)
+    if rank == 0 and world == 1 and not args.no_sweep:
+        out["ttft_ms_p50"] = {"prompt_tokens": args.context, "batch": 1,
+                              "value": ttft(runner, dev, args.context)}
     if world == 1 and not args.no_sweep:
         sweep = {}
         for b in (1, 8, 32):

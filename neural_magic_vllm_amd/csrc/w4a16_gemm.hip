@@ -976,12 +976,13 @@ template <typename T, int GS>
 static int launch_gemm_gs(const GemmPlan& pl, const GemmParams& p, hipStream_t s) {
   dim3 grid(pl.n_blocks, pl.splits, pl.m_blocks), block(GT);
   if constexpr (GS == 0 || GS == 128) {
+    const int pad = env_int("NMV_W4_LDS_PAD", 0);  // experiments: extra LDS lowers the occupancy
     if (pl.lds_kind == 1) {
-      hipLaunchKernelGGL((w4a16_gemm_lds_kernel<T, 4, 1, GS>), grid, block, 0, s, p);
+      hipLaunchKernelGGL((w4a16_gemm_lds_kernel<T, 4, 1, GS>), grid, block, pad, s, p);
       return 0;
     }
     if (pl.lds_kind == 2) {
-      hipLaunchKernelGGL((w4a16_gemm_lds_kernel<T, 2, 2, GS>), grid, block, 0, s, p);
+      hipLaunchKernelGGL((w4a16_gemm_lds_kernel<T, 2, 2, GS>), grid, block, pad, s, p);
       return 0;
     }
   }

@@ -33,6 +33,13 @@ for step in "$@"; do
     gemmpmc) cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
             run gemmpmc rocprofv3 --pmc ${PMC:-SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU} --kernel-trace --output-format csv -d gpurun_out/gpmc -- python tools/bench_gemm.py ${GEMM_ARGS:-}
             find gpurun_out/gpmc -name "*counter_collection.csv" | head -1 | xargs -I{} cp {} gpurun_out/gemm_pmc.csv ;;
+    traffic) cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
+            # HBM bytes of the GEMM launches: FETCH_SIZE and WRITE_SIZE do not fit one pass
+            for c in FETCH_SIZE WRITE_SIZE; do
+              run traffic_$c rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/tr_$c -- python tools/bench_gemm.py --ms ${TRAFFIC_MS:-1,16,32,64}
+              find gpurun_out/tr_$c -name "*counter_collection.csv" | head -1 | xargs -I{} cp {} gpurun_out/traffic_$c.csv
+              rm -rf gpurun_out/tr_$c
+            done ;;
     gemmsweep) run gemmsweep python tools/bench_gemm.py --sweep ;;
     prof)   cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
             run prof rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -- python bench.py --steps 16 --warmup 4 --no-sweep --no-cpu-baseline ${BENCH_ARGS:-}
