@@ -42,18 +42,21 @@ constexpr int GT = 256;        // threads per workgroup
 constexpr int STAGE_K = 128;   // k per pipeline stage (= 4 MFMA k-steps of 32)
 constexpr int KSTEPS = STAGE_K / 32;
 
-// (x & mask) | magic in ONE VALU op.  hipcc splits the C expression into v_and_b32 + v_or_b32 because
-// gfx9 VOP3 encodings take no literals; with the mask in an SGPR and the magic in a VGPR the
-// three-operand form is legal (one constant-bus read).
+// (x & mask) | magic in ONE VALU op (v_and_or_b32).  gfx9 VOP3 encodings take no literals, so
+// hipcc splits the expression into v_and_b32 + v_or_b32 when mask and magic are constants; callers
+// therefore pin the mask in an SGPR (readfirstlane) and the magic in a VGPR (an empty asm), and the
+// compiler then selects the three-operand form itself.  This must stay a compiler-visible
+// expression: an inline-asm v_and_or_b32 whose result fed the next v_mfma directly produced
+// garbage accumulator tiles (the hazard recogniser does not look inside asm statements).
 __device__ __forceinline__ uint32_t and_or(uint32_t x, uint32_t mask_sgpr, uint32_t magic_vgpr) {
-  uint32_t r;
-  asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "s"(mask_sgpr), "v"(magic_vgpr));
-  return r;
+  return (x & mask_sgpr) | magic_vgpr;
 }
 
 template <typename T> struct W4;
 template <> struct W4<BF16> {
   static constexpr uint32_t MASK = 0x00780078u, MAGIC = 0x41804180u, ONES = 0x3F803F80u;
+  // the same four shifts as rotate-right amounts (the wrapped bits fall outside MASK)
+  static constexpr uint32_t ROT_LO0 = 29, ROT_HI0 = 1, ROT_LO1 = 5, ROT_HI1 = 9;
   // nibble -> mantissa bits [6:3]
   static __device__ __forceinline__ uint32_t lo0(uint32_t x, uint32_t m, uint32_t g) { return and_or(x << 3, m, g); }
   static __device__ __forceinline__ uint32_t hi0(uint32_t x, uint32_t m, uint32_t g) { return and_or(x >> 1, m, g); }
@@ -66,6 +69,7 @@ template <> struct W4<BF16> {
 };
 template <> struct W4<F16> {
   static constexpr uint32_t MASK = 0x03C003C0u, MAGIC = 0x4C004C00u, ONES = 0x3C003C00u;
+  static constexpr uint32_t ROT_LO0 = 26, ROT_HI0 = 30, ROT_LO1 = 2, ROT_HI1 = 6;
   // nibble -> mantissa bits [9:6]
   static __device__ __forceinline__ uint32_t lo0(uint32_t x, uint32_t m, uint32_t g) { return and_or(x << 6, m, g); }
   static __device__ __forceinline__ uint32_t hi0(uint32_t x, uint32_t m, uint32_t g) { return and_or(x << 2, m, g); }
@@ -862,6 +866,312 @@ __global__ __launch_bounds__(GT, 2) void w4a16_gemm_lds_kernel(const GemmParams 
 }
 
 // ---------------------------------------------------------------------------------------------
+// M >= 17, "tall" register tile: one wave = ONE 64-column chunk x 16 MT rows (MT = 2 or 4).
+//
+// The 16-row kernel re-expands every weight once per 16 rows; the LDS kernel below expands once per
+// workgroup but pays a serial barrier chain per 64 k.  Here the expansion is shared the cheap way:
+// the wave that expanded a weight multiplies it against ALL its MT row tiles, straight from
+// registers -- no LDS round trip and no barrier for the weights.  A 64-column chunk has 16-column
+// MFMA tiles j = 0..3 whose rows are r = 8 blk + n_in, so lane (r, g) needs the blk half of Marlin
+// vector (n_in, q = g) from both k-tiles of the 32-deep step.  Lanes r and r^8 want the two halves of
+// the same two vectors: the blk-0 lane loads the even k-tile, the blk-1 lane the odd one (every
+// byte is loaded once, one 16-byte load per lane and k-step), they swap through one DPP row
+// rotate (row_ror:8), and each lane expands its own half with per-lane rotate amounts
+// (v_alignbit_b32 + v_and_or_b32 = 2 ops per 2 weights, as everywhere).  Weights run RING-1 stages
+// ahead in an 8-VGPR-per-stage ring; activations are staged through LDS as in the 16-row kernel;
+// group scales come through LDS with them.  Main loop: branch-free, whole rings (the plan only
+// picks this kernel when every wave's k range is a multiple of 256).
+constexpr int TS_K = 64;       // k per stage
+constexpr int TRING = 4;       // ring slots (stages)
+
+template <typename T, int MT, int WN, int WK, int GS>
+__global__ __launch_bounds__(GT, 2) void w4a16_gemm_tall_kernel(const GemmParams p) {
+  static_assert(WN * WK == 4, "4 waves per workgroup");
+  static_assert(GS == 0 || GS == 128, "one scale group per two stages, or channelwise");
+  constexpr int MP = 16 * MT;                  // rows per workgroup
+  constexpr int A_U4 = 2 * 4 * MP;             // uint4 per (stage, k-group): [k-step][g][row]
+  constexpr int SC_U4 = 4 * 8;                 // one scale group: [k-group * WN + wn] x 128 B
+  constexpr int MAIN_U4 = 2 * WK * A_U4 + 2 * SC_U4;
+  constexpr int RED_U4 = (WK > 1) ? (WK - 1) * WN * MT * 256 : 0;
+  constexpr int LDS_U4 = MAIN_U4 > RED_U4 ? (MAIN_U4 > GT ? MAIN_U4 : GT) : (RED_U4 > GT ? RED_U4 : GT);
+  __shared__ __attribute__((aligned(16))) uint4 lds[LDS_U4];
+  uint4* a_s = lds;
+  uint4* sc_s = lds + 2 * WK * A_U4;
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wn = wave % WN, wk = wave / WN;
+  const int r = lane & 15, g = lane >> 4;
+  const int blk = r >> 3, n_in = r & 7;
+  const int n_chunks = p.N >> 6;
+  const int chunk = blockIdx.x * WN + wn;
+  const bool chunk_ok = chunk < n_chunks;
+  const int m0 = blockIdx.z * MP;
+  const int split = blockIdx.y;
+  const int k_wg0 = split * p.k_per_wg;
+  const int k_wg1 = min(k_wg0 + p.k_per_wg, p.K);
+  const int k_per_wave = (k_wg1 - k_wg0) / WK;      // multiple of 256 (make_plan)
+  const int k_w0 = k_wg0 + wk * k_per_wave;
+  const int n_stages = k_per_wave / TS_K;           // multiple of 4
+  // a stage index past the end (the ring's look-ahead) re-reads the last stage; never consumed
+  const int st_last = __builtin_amdgcn_readfirstlane(n_stages - 1);
+
+  // ---- weights: lane (blk, n_in, q = g) streams vector n_in*4+q of k-tile 2 ks + blk ----
+  const int64_t row_u4 = p.N >> 1;
+  const uint4* bp = p.b + (int64_t)(chunk_ok ? chunk : 0) * 32 + (n_in * 4 + g) +
+                    ((int64_t)(k_w0 >> 4) + blk) * row_u4;
+  auto load_w = [&](int st, uint4 (&w)[2]) {
+    const uint4* q = bp + (int64_t)min(st, st_last) * (4 * row_u4);
+    w[0] = q[0];
+    w[1] = q[2 * row_u4];
+  };
+  const uint32_t kmask = __builtin_amdgcn_readfirstlane(W4<T>::MASK);
+  uint32_t kmagic = W4<T>::MAGIC;
+  asm volatile("" : "+v"(kmagic));
+  const uint32_t rot_lo = blk ? W4<T>::ROT_LO1 : W4<T>::ROT_LO0;
+  const uint32_t rot_hi = blk ? W4<T>::ROT_HI1 : W4<T>::ROT_HI0;
+  const bool odd_lane = blk != 0;
+
+  // ---- activations (+ the scale rows of the group) -> registers -> LDS ----
+  constexpr int A_CHUNKS = WK * MP * 8;                    // 16-byte pieces per stage
+  constexpr int APT = (A_CHUNKS + GT - 1) / GT;
+  static_assert(A_CHUNKS % GT == 0, "no tail");
+  const uint16_t* ap[APT];
+#pragma unroll
+  for (int i = 0; i < APT; ++i) {
+    const int id = threadIdx.x + i * GT;
+    const int c8 = id & 7, row = (id >> 3) % MP, kg = (id >> 3) / MP;
+    ap[i] = p.a + (int64_t)min(m0 + row, p.M - 1) * p.K + (k_wg0 + kg * k_per_wave) + c8 * 8;
+  }
+  auto load_a = [&](int st, uint4 (&av)[APT]) {
+    // rows past M are clamped duplicates that only feed rows which are never stored
+    const int off = min(st, st_last) * TS_K;
+#pragma unroll
+    for (int i = 0; i < APT; ++i) av[i] = ld16(ap[i] + off);
+  };
+  auto store_a = [&](int buf, const uint4 (&av)[APT]) {
+    uint32_t* base = reinterpret_cast<uint32_t*>(a_s);
+#pragma unroll
+    for (int i = 0; i < APT; ++i) {
+      const int id = threadIdx.x + i * GT;
+      const int c8 = id & 7, row = (id >> 3) % MP, kg = (id >> 3) / MP;
+      const int ks = c8 >> 2, cc = c8 & 3;
+      const int e0 = ((buf * WK + kg) * A_U4 + (ks * 4 + 0) * MP + row) * 4 + cc;
+      base[e0] = av[i].x;
+      base[e0 + 4 * MP] = av[i].y;
+      base[e0 + 8 * MP] = av[i].z;
+      base[e0 + 12 * MP] = av[i].w;
+    }
+  };
+  // scale rows: threads 0..31 = (k-group*WN + wn') x 8 pieces of 16 B (64 columns x 2 B)
+  const int s_combo = (threadIdx.x >> 3) & 3, s_piece = threadIdx.x & 7;
+  const int s_chunk = min(blockIdx.x * WN + (s_combo % WN), n_chunks - 1);
+  const uint16_t* s_src = p.s + (int64_t)s_chunk * 64 + s_piece * 8;
+  const int s_k0 = k_wg0 + (s_combo / WN) * k_per_wave;
+  auto load_sc = [&](int st) -> uint4 {
+    if constexpr (GS == 0) return make_uint4(0, 0, 0, 0);
+    const int k_abs = min(s_k0 + st * TS_K, p.K - 1);
+    return ld16(s_src + (int64_t)(k_abs / 128) * p.N);
+  };
+  auto store_sc = [&](int gbuf, uint4 v) {
+    if constexpr (GS != 0) {
+      if (threadIdx.x < 32) sc_s[gbuf * SC_U4 + threadIdx.x] = v;
+    }
+  };
+
+  // ---- accumulators ----
+  f32x4_t accm[4][MT], accg[4][MT], accs[MT];
+  const f32x4_t zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int t = 0; t < MT; ++t) { accm[j][t] = zero4; accg[j][t] = zero4; }
+#pragma unroll
+  for (int t = 0; t < MT; ++t) accs[t] = zero4;
+
+  // output fragment of this lane: columns chunk*64 + 16 j + 4 g + reg, rows m0 + 16 t + r.
+  // grouped scale layout: element (4 (g&1) + reg) * 8 + 2 j + (g >> 1) of the chunk's 64
+  const uint32_t sc_shift = (g >> 1) * 16;
+  auto flush = [&](int gbuf) {
+    float zs[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) zs[t] = -W4_ZP * accs[t][0];
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      uint4 d4 = make_uint4(0, 0, 0, 0);
+      if constexpr (GS != 0) d4 = sc_s[gbuf * SC_U4 + (wk * WN + wn) * 8 + (g & 1) * 4 + reg];
+      const uint32_t d[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float scv = 1.f;
+        if constexpr (GS != 0) scv = T::to_float((uint16_t)(d[j] >> sc_shift));
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+          const float dlt = accg[j][t][reg] + zs[t];
+          if constexpr (GS != 0) accm[j][t][reg] = fmaf(scv, dlt, accm[j][t][reg]);
+          else accm[j][t][reg] += dlt;
+        }
+      }
+    }
+  };
+
+  // ---- prologue ----
+  uint4 w0[2], w1[2], w2[2], w3[2];
+  uint4 ar[APT];
+  uint4 scr = make_uint4(0, 0, 0, 0);
+  load_a(0, ar);
+  scr = load_sc(0);
+  load_w(0, w0);
+  load_w(1, w1);
+  load_w(2, w2);
+  store_a(0, ar);
+  store_sc(0, scr);
+  __syncthreads();
+  const uint4 ones = make_uint4(W4<T>::ONES, W4<T>::ONES, W4<T>::ONES, W4<T>::ONES);
+
+  // one stage (U = position in the ring: buffer parity and the scale-group schedule are static):
+  // fetch the activations of stage st+1 and the weights of stage st+3 (into the slot stage st-1
+  // just released), multiply stage st, park stage st+1's activations, barrier
+  auto stage = [&](auto u_tag, int st, const uint4 (&wc)[2], uint4 (&wfree)[2]) {
+    constexpr int U = decltype(u_tag)::value;
+    constexpr int buf = U & 1;
+    constexpr int gbuf = (U >> 1) & 1;            // scale buffer of the group of this stage
+    load_a(st + 1, ar);
+    if constexpr ((U & 1) == 1) scr = load_sc(st + 1);   // next stage opens a group
+    load_w(st + 3, wfree);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int kstep = U * 2 + ks;
+      const bool first = kstep % 4 == 0;          // static after unrolling
+      uint4 af[MT];
+#pragma unroll
+      for (int t = 0; t < MT; ++t) af[t] = a_s[(buf * WK + wk) * A_U4 + (ks * 4 + g) * MP + t * 16 + r];
+      const uint32_t own[4] = {wc[ks].x, wc[ks].y, wc[ks].z, wc[ks].w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        // partner lane r^8 holds the other k-tile of the same vector
+        const uint32_t oth = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)own[j], 0x128, 0xf, 0xf, false);
+        const uint32_t e = odd_lane ? oth : own[j];   // even k-tile
+        const uint32_t o = odd_lane ? own[j] : oth;   // odd k-tile
+        const uint4 wv = make_uint4(and_or(__builtin_amdgcn_alignbit(e, e, rot_lo), kmask, kmagic),
+                                    and_or(__builtin_amdgcn_alignbit(e, e, rot_hi), kmask, kmagic),
+                                    and_or(__builtin_amdgcn_alignbit(o, o, rot_lo), kmask, kmagic),
+                                    and_or(__builtin_amdgcn_alignbit(o, o, rot_hi), kmask, kmagic));
+#pragma unroll
+        for (int t = 0; t < MT; ++t) accg[j][t] = W4<T>::mfma(wv, af[t], first ? zero4 : accg[j][t]);
+      }
+#pragma unroll
+      for (int t = 0; t < MT; ++t) accs[t] = W4<T>::mfma(ones, af[t], first ? zero4 : accs[t]);
+      if (kstep % 4 == 3) flush(gbuf);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    store_a(buf ^ 1, ar);
+    if constexpr ((U & 1) == 1) store_sc(gbuf ^ 1, scr);
+    __syncthreads();
+  };
+  for (int st = 0; st < n_stages; st += 4) {
+    stage(std::integral_constant<int, 0>{}, st, w0, w3);
+    stage(std::integral_constant<int, 1>{}, st + 1, w1, w0);
+    stage(std::integral_constant<int, 2>{}, st + 2, w2, w1);
+    stage(std::integral_constant<int, 3>{}, st + 3, w3, w2);
+  }
+
+  // ---- channelwise scales are applied once, on the fp32 result ----
+  if (GS == 0 && chunk_ok) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int c64 = j * 16 + 4 * g + reg;
+        const int c = c64 & 31;
+        const int pos = (c64 >> 5) * 32 + ((c & 7) >> 1) * 8 + 2 * (c >> 3) + (c & 1);
+        const float sv = T::to_float(p.s[(int64_t)chunk * 64 + pos]);
+#pragma unroll
+        for (int t = 0; t < MT; ++t) accm[j][t][reg] *= sv;
+      }
+    }
+  }
+
+  // ---- cross-wave (intra-workgroup) k reduction ----
+  if constexpr (WK > 1) {
+    float* red = reinterpret_cast<float*>(lds);
+    __syncthreads();  // nobody reads the operand images any more
+    if (wk > 0) {
+      float* dst = red + (int64_t)((wk - 1) * WN + wn) * (4 * MT * 4) * 64;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+          for (int reg = 0; reg < 4; ++reg) dst[((j * MT + t) * 4 + reg) * 64 + lane] = accm[j][t][reg];
+    }
+    __syncthreads();
+    if (wk == 0) {
+#pragma unroll
+      for (int kk = 1; kk < WK; ++kk) {
+        const float* src = red + (int64_t)((kk - 1) * WN + wn) * (4 * MT * 4) * 64;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) accm[j][t][reg] += src[((j * MT + t) * 4 + reg) * 64 + lane];
+      }
+    }
+  }
+  const bool writer = (wk == 0) && chunk_ok;
+
+  // ---- epilogue ----
+  if (p.splits == 1) {
+    if (!writer) return;
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+      const int m = m0 + t * 16 + r;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int n = chunk * 64 + j * 16 + 4 * g;
+        const f32x4_t o = accm[j][t];
+        uint2 pk;
+        pk.x = T::pack2(o[0], o[1]);
+        pk.y = T::pack2(o[2], o[3]);
+        *reinterpret_cast<uint2*>(p.c + (int64_t)m * p.N + n) = pk;
+      }
+    }
+    return;
+  }
+  // split-K across workgroups: sc1 slabs, ticket, the last workgroup of the tile reduces (see above)
+  const int64_t slab_bytes = (int64_t)p.splits * p.M * p.N * 4;
+  __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p.slab, 0, (int)slab_bytes, 0x00020000);
+  if (writer) {
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+      const int m = m0 + t * 16 + r;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int n = chunk * 64 + j * 16 + 4 * g;
+        const int off = (int)((((int64_t)split * p.M + m) * p.N + n) * 4);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, accm[j][t]), rs, off, 0, 16);
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __shared__ int ticket_s;
+  __syncthreads();
+  const int tile = blockIdx.z * gridDim.x + blockIdx.x;
+  if (threadIdx.x == 0)
+    ticket_s = __hip_atomic_fetch_add(p.tickets + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  if (ticket_s != p.splits - 1) return;
+  if (threadIdx.x == 0)
+    __hip_atomic_store(p.tickets + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  splitk_reduce_tile<T>(p, rs, m0, MP, blockIdx.x * (WN * 64), WN * 64, reinterpret_cast<f32x4_t*>(lds));
+}
+
+// ---------------------------------------------------------------------------------------------
 // gptq_marlin_repack: GPTQ [K/pack, N] -> Marlin [K/16, N*16/pack].  One thread per output int32.
 template <int BITS>
 __global__ void marlin_repack_kernel(const uint32_t* __restrict__ qw, const int* __restrict__ perm,
@@ -908,6 +1218,7 @@ struct GemmPlan {
   int mt, wn, wm, wk;  // kernel shape
   int splits, k_per_wg, m_blocks, n_blocks;
   int lds_kind;  // 0: register kernel (16-row tiles); 1: LDS kernel 4x1 (32 rows); 2: 2x2 (64 rows)
+  int tall;      // 1: tall register tile (64 columns x 16 mt rows per wave); wn, wk, mt say which
 };
 
 static int env_int(const char* name, int dflt) {
@@ -922,6 +1233,34 @@ static GemmPlan make_plan(int M, int N, int K, int64_t tickets_len, bool allow_l
   GemmPlan pl;
   const int n_chunks = N / 64;
   pl.lds_kind = 0;
+  pl.tall = 0;
+  // M >= 17, K in whole 256-k rings per wave: the tall register tile
+  if (allow_lds && M >= env_int("NMV_W4_TALL_MIN_M", 17) && K % 256 == 0 && env_int("NMV_W4_TALL", 1)) {
+    pl.tall = 1;
+    pl.wm = 1;
+    pl.mt = env_int("NMV_W4_TALL_MT", 2);
+    const int rows = 16 * pl.mt;
+    pl.m_blocks = (M + rows - 1) / rows;
+    // wide N: two chunks per workgroup, two k groups; narrow N: one chunk, four k groups (the
+    // in-workgroup k reduction goes through LDS and saves split-K slabs)
+    int wk = n_chunks * pl.m_blocks >= 256 ? 2 : 4;
+    wk = env_int("NMV_W4_TALL_WK", wk);
+    while (wk > 1 && K % (256 * wk) != 0) wk >>= 1;
+    pl.wk = wk;
+    pl.wn = 4 / wk;
+    pl.n_blocks = (n_chunks + pl.wn - 1) / pl.wn;
+    const int unit = 256 * wk;
+    const int k_units = K / unit;
+    const int base_wgs = pl.n_blocks * pl.m_blocks;
+    int splits = std::max(1, env_int("NMV_W4_TALL_WGS", 512) / base_wgs);
+    splits = std::min(splits, env_int("NMV_W4_TALL_MAX_SPLITS", 8));
+    splits = env_int("NMV_W4_SPLITS", splits);
+    splits = std::max(1, std::min(splits, k_units));
+    if ((int64_t)base_wgs > tickets_len) splits = 1;
+    pl.k_per_wg = ((k_units + splits - 1) / splits) * unit;
+    pl.splits = (K + pl.k_per_wg - 1) / pl.k_per_wg;
+    return pl;
+  }
   const int lds_min_m = env_int("NMV_W4_LDS_MIN_M", 17);
   if (allow_lds && M >= lds_min_m && K % 256 == 0) {
     // shared-dequantisation tile: 128 columns x 32 rows (<= 32 rows) or x 64 rows
@@ -976,6 +1315,17 @@ template <typename T, int GS>
 static int launch_gemm_gs(const GemmPlan& pl, const GemmParams& p, hipStream_t s) {
   dim3 grid(pl.n_blocks, pl.splits, pl.m_blocks), block(GT);
   if constexpr (GS == 0 || GS == 128) {
+    if (pl.tall) {
+#define NMV_W4_TALL_CASE(mt_, wn_, wk_)                                                        \
+  if (pl.mt == mt_ && pl.wn == wn_ && pl.wk == wk_) {                                          \
+    hipLaunchKernelGGL((w4a16_gemm_tall_kernel<T, mt_, wn_, wk_, GS>), grid, block, 0, s, p);  \
+    return 0;                                                                                  \
+  }
+      NMV_W4_TALL_CASE(2, 4, 1) NMV_W4_TALL_CASE(2, 2, 2) NMV_W4_TALL_CASE(2, 1, 4)
+      NMV_W4_TALL_CASE(4, 4, 1) NMV_W4_TALL_CASE(4, 2, 2) NMV_W4_TALL_CASE(4, 1, 4)
+#undef NMV_W4_TALL_CASE
+      return -1;
+    }
     const int pad = env_int("NMV_W4_LDS_PAD", 0);  // experiments: extra LDS lowers the occupancy
     if (pl.lds_kind == 1) {
       hipLaunchKernelGGL((w4a16_gemm_lds_kernel<T, 4, 1, GS>), grid, block, pad, s, p);
@@ -986,7 +1336,7 @@ static int launch_gemm_gs(const GemmPlan& pl, const GemmParams& p, hipStream_t s
       return 0;
     }
   }
-  if (pl.lds_kind != 0) return -1;
+  if (pl.lds_kind != 0 || pl.tall) return -1;
 #define NMV_W4_CASE(MT_, WN_, WM_, WK_)                                                         \
   if (pl.mt == MT_ && pl.wn == WN_ && pl.wm == WM_ && pl.wk == WK_) {                           \
     hipLaunchKernelGGL((w4a16_gemm_kernel<T, MT_, WN_, WM_, WK_, GS>), grid, block, 0, s, p);   \
