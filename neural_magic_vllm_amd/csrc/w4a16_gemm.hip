@@ -881,15 +881,20 @@ __global__ __launch_bounds__(GT, 2) void w4a16_gemm_lds_kernel(const GemmParams 
 // ahead in an 8-VGPR-per-stage ring; activations are staged through LDS as in the 16-row kernel;
 // group scales come through LDS with them.  Main loop: branch-free, whole rings (the plan only
 // picks this kernel when every wave's k range is a multiple of 256).
-constexpr int TS_K = 64;       // k per stage
-constexpr int TRING = 4;       // ring slots (stages)
+// Stage = 64 k (two MFMA k-steps) for the 32-row tile, 32 k for the 64-row tile: a 64-row k-step
+// carries 20 MFMAs, so the same look-ahead in time needs half the k -- and half the ring and
+// staging registers, which is what lets 144 accumulator VGPRs fit under 256.
 
 template <typename T, int MT, int WN, int WK, int GS>
 __global__ __launch_bounds__(GT, 2) void w4a16_gemm_tall_kernel(const GemmParams p) {
   static_assert(WN * WK == 4, "4 waves per workgroup");
   static_assert(GS == 0 || GS == 128, "one scale group per two stages, or channelwise");
   constexpr int MP = 16 * MT;                  // rows per workgroup
-  constexpr int A_U4 = 2 * 4 * MP;             // uint4 per (stage, k-group): [k-step][g][row]
+  constexpr int KSS = MT == 4 ? 1 : 2;         // MFMA k-steps per stage
+  constexpr int TS_K = 32 * KSS;               // k per stage
+  constexpr int SPG = 4 / KSS;                 // stages per 128-k scale group
+  constexpr int PPR = 4 * KSS;                 // 16-byte activation pieces per row and stage
+  constexpr int A_U4 = KSS * 4 * MP;           // uint4 per (stage, k-group): [k-step][g][row]
   constexpr int SC_U4 = 4 * 8;                 // one scale group: [k-group * WN + wn] x 128 B
   constexpr int MAIN_U4 = 2 * WK * A_U4 + 2 * SC_U4;
   constexpr int RED_U4 = (WK > 1) ? (WK - 1) * WN * MT * 256 : 0;
@@ -910,7 +915,7 @@ __global__ __launch_bounds__(GT, 2) void w4a16_gemm_tall_kernel(const GemmParams
   const int split = blockIdx.y;
   const int k_wg0 = split * p.k_per_wg;
   const int k_wg1 = min(k_wg0 + p.k_per_wg, p.K);
-  const int k_per_wave = (k_wg1 - k_wg0) / WK;      // multiple of 256 (make_plan)
+  const int k_per_wave = (k_wg1 - k_wg0) / WK;      // multiple of 4 stages (make_plan)
   const int k_w0 = k_wg0 + wk * k_per_wave;
   const int n_stages = k_per_wave / TS_K;           // multiple of 4
   // a stage index past the end (the ring's look-ahead) re-reads the last stage; never consumed
@@ -920,10 +925,10 @@ __global__ __launch_bounds__(GT, 2) void w4a16_gemm_tall_kernel(const GemmParams
   const int64_t row_u4 = p.N >> 1;
   const uint4* bp = p.b + (int64_t)(chunk_ok ? chunk : 0) * 32 + (n_in * 4 + g) +
                     ((int64_t)(k_w0 >> 4) + blk) * row_u4;
-  auto load_w = [&](int st, uint4 (&w)[2]) {
-    const uint4* q = bp + (int64_t)min(st, st_last) * (4 * row_u4);
-    w[0] = q[0];
-    w[1] = q[2 * row_u4];
+  auto load_w = [&](int st, uint4 (&w)[KSS]) {
+    const uint4* q = bp + (int64_t)min(st, st_last) * (2 * KSS * row_u4);
+#pragma unroll
+    for (int ks = 0; ks < KSS; ++ks) w[ks] = q[ks * 2 * row_u4];
   };
   const uint32_t kmask = __builtin_amdgcn_readfirstlane(W4<T>::MASK);
   uint32_t kmagic = W4<T>::MAGIC;
@@ -933,14 +938,14 @@ __global__ __launch_bounds__(GT, 2) void w4a16_gemm_tall_kernel(const GemmParams
   const bool odd_lane = blk != 0;
 
   // ---- activations (+ the scale rows of the group) -> registers -> LDS ----
-  constexpr int A_CHUNKS = WK * MP * 8;                    // 16-byte pieces per stage
+  constexpr int A_CHUNKS = WK * MP * PPR;                  // 16-byte pieces per stage
   constexpr int APT = (A_CHUNKS + GT - 1) / GT;
   static_assert(A_CHUNKS % GT == 0, "no tail");
   const uint16_t* ap[APT];
 #pragma unroll
   for (int i = 0; i < APT; ++i) {
     const int id = threadIdx.x + i * GT;
-    const int c8 = id & 7, row = (id >> 3) % MP, kg = (id >> 3) / MP;
+    const int c8 = id % PPR, row = (id / PPR) % MP, kg = (id / PPR) / MP;
     ap[i] = p.a + (int64_t)min(m0 + row, p.M - 1) * p.K + (k_wg0 + kg * k_per_wave) + c8 * 8;
   }
   auto load_a = [&](int st, uint4 (&av)[APT]) {
@@ -954,7 +959,7 @@ __global__ __launch_bounds__(GT, 2) void w4a16_gemm_tall_kernel(const GemmParams
 #pragma unroll
     for (int i = 0; i < APT; ++i) {
       const int id = threadIdx.x + i * GT;
-      const int c8 = id & 7, row = (id >> 3) % MP, kg = (id >> 3) / MP;
+      const int c8 = id % PPR, row = (id / PPR) % MP, kg = (id / PPR) / MP;
       const int ks = c8 >> 2, cc = c8 & 3;
       const int e0 = ((buf * WK + kg) * A_U4 + (ks * 4 + 0) * MP + row) * 4 + cc;
       base[e0] = av[i].x;
@@ -1016,7 +1021,7 @@ __global__ __launch_bounds__(GT, 2) void w4a16_gemm_tall_kernel(const GemmParams
   };
 
   // ---- prologue ----
-  uint4 w0[2], w1[2], w2[2], w3[2];
+  uint4 w0[KSS], w1[KSS], w2[KSS], w3[KSS];
   uint4 ar[APT];
   uint4 scr = make_uint4(0, 0, 0, 0);
   load_a(0, ar);
@@ -1032,18 +1037,20 @@ __global__ __launch_bounds__(GT, 2) void w4a16_gemm_tall_kernel(const GemmParams
   // one stage (U = position in the ring: buffer parity and the scale-group schedule are static):
   // fetch the activations of stage st+1 and the weights of stage st+3 (into the slot stage st-1
   // just released), multiply stage st, park stage st+1's activations, barrier
-  auto stage = [&](auto u_tag, int st, const uint4 (&wc)[2], uint4 (&wfree)[2]) {
+  auto stage = [&](auto u_tag, int st, const uint4 (&wc)[KSS], uint4 (&wfree)[KSS]) {
     constexpr int U = decltype(u_tag)::value;
     constexpr int buf = U & 1;
-    constexpr int gbuf = (U >> 1) & 1;            // scale buffer of the group of this stage
+    constexpr bool closes = (U + 1) % SPG == 0;   // last stage of a scale group
+    // scale buffer of this stage's group: static for 2 groups per ring, else by ring parity
+    const int gbuf = SPG == 2 ? ((U >> 1) & 1) : ((st >> 2) & 1);
     load_a(st + 1, ar);
-    if constexpr ((U & 1) == 1) scr = load_sc(st + 1);   // next stage opens a group
+    if constexpr (closes) scr = load_sc(st + 1);  // the next stage opens a group
     load_w(st + 3, wfree);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const int kstep = U * 2 + ks;
-      const bool first = kstep % 4 == 0;          // static after unrolling
+    for (int ks = 0; ks < KSS; ++ks) {
+      const int kstep = (U % SPG) * KSS + ks;     // k-step inside the group
+      const bool first = kstep == 0;              // static after unrolling
       uint4 af[MT];
 #pragma unroll
       for (int t = 0; t < MT; ++t) af[t] = a_s[(buf * WK + wk) * A_U4 + (ks * 4 + g) * MP + t * 16 + r];
@@ -1060,14 +1067,17 @@ __global__ __launch_bounds__(GT, 2) void w4a16_gemm_tall_kernel(const GemmParams
                                     and_or(__builtin_amdgcn_alignbit(o, o, rot_hi), kmask, kmagic));
 #pragma unroll
         for (int t = 0; t < MT; ++t) accg[j][t] = W4<T>::mfma(wv, af[t], first ? zero4 : accg[j][t]);
+        // 64-row tile: at the register limit -- keep the scheduler from expanding all four column
+        // tiles ahead of the MFMAs (that costs 16+ live VGPRs and spills)
+        if constexpr (MT == 4) __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
       for (int t = 0; t < MT; ++t) accs[t] = W4<T>::mfma(ones, af[t], first ? zero4 : accs[t]);
-      if (kstep % 4 == 3) flush(gbuf);
+      if (kstep == 3) flush(gbuf);
     }
     __builtin_amdgcn_sched_barrier(0);
     store_a(buf ^ 1, ar);
-    if constexpr ((U & 1) == 1) store_sc(gbuf ^ 1, scr);
+    if constexpr (closes) store_sc(gbuf ^ 1, scr);
     __syncthreads();
   };
   for (int st = 0; st < n_stages; st += 4) {
@@ -1238,18 +1248,19 @@ static GemmPlan make_plan(int M, int N, int K, int64_t tickets_len, bool allow_l
   if (allow_lds && M >= env_int("NMV_W4_TALL_MIN_M", 17) && K % 256 == 0 && env_int("NMV_W4_TALL", 1)) {
     pl.tall = 1;
     pl.wm = 1;
-    pl.mt = env_int("NMV_W4_TALL_MT", 2);
+    pl.mt = env_int("NMV_W4_TALL_MT", M <= 64 ? 2 : 4);  // measured: 64-row tile wins only past M = 64
     const int rows = 16 * pl.mt;
     pl.m_blocks = (M + rows - 1) / rows;
     // wide N: two chunks per workgroup, two k groups; narrow N: one chunk, four k groups (the
     // in-workgroup k reduction goes through LDS and saves split-K slabs)
     int wk = n_chunks * pl.m_blocks >= 256 ? 2 : 4;
     wk = env_int("NMV_W4_TALL_WK", wk);
-    while (wk > 1 && K % (256 * wk) != 0) wk >>= 1;
+    const int ring_k = pl.mt == 4 ? 128 : 256;  // 4 stages of 32 / 64 k
+    while (wk > 1 && K % (ring_k * wk) != 0) wk >>= 1;
     pl.wk = wk;
     pl.wn = 4 / wk;
     pl.n_blocks = (n_chunks + pl.wn - 1) / pl.wn;
-    const int unit = 256 * wk;
+    const int unit = ring_k * wk;
     const int k_units = K / unit;
     const int base_wgs = pl.n_blocks * pl.m_blocks;
     int splits = std::max(1, env_int("NMV_W4_TALL_WGS", 512) / base_wgs);
