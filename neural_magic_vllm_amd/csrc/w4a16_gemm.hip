@@ -940,11 +940,13 @@ __global__ __launch_bounds__(GT, 2) void w4a16_gemm_tall_kernel(const GemmParams
   // ---- activations (+ the scale rows of the group) -> registers -> LDS ----
   constexpr int A_CHUNKS = WK * MP * PPR;                  // 16-byte pieces per stage
   constexpr int APT = (A_CHUNKS + GT - 1) / GT;
-  static_assert(A_CHUNKS % GT == 0, "no tail");
+  // fewer pieces than threads (16 rows, one k group): the upper threads repeat the lower ones'
+  // pieces -- same value to the same LDS word, no branch in the loop
+  static_assert(A_CHUNKS % GT == 0 || A_CHUNKS < GT, "no ragged tail");
   const uint16_t* ap[APT];
 #pragma unroll
   for (int i = 0; i < APT; ++i) {
-    const int id = threadIdx.x + i * GT;
+    const int id = (threadIdx.x + i * GT) % A_CHUNKS;
     const int c8 = id % PPR, row = (id / PPR) % MP, kg = (id / PPR) / MP;
     ap[i] = p.a + (int64_t)min(m0 + row, p.M - 1) * p.K + (k_wg0 + kg * k_per_wave) + c8 * 8;
   }
@@ -958,7 +960,7 @@ __global__ __launch_bounds__(GT, 2) void w4a16_gemm_tall_kernel(const GemmParams
     uint32_t* base = reinterpret_cast<uint32_t*>(a_s);
 #pragma unroll
     for (int i = 0; i < APT; ++i) {
-      const int id = threadIdx.x + i * GT;
+      const int id = (threadIdx.x + i * GT) % A_CHUNKS;
       const int c8 = id % PPR, row = (id / PPR) % MP, kg = (id / PPR) / MP;
       const int ks = c8 >> 2, cc = c8 & 3;
       const int e0 = ((buf * WK + kg) * A_U4 + (ks * 4 + 0) * MP + row) * 4 + cc;
@@ -1244,16 +1246,17 @@ static GemmPlan make_plan(int M, int N, int K, int64_t tickets_len, bool allow_l
   const int n_chunks = N / 64;
   pl.lds_kind = 0;
   pl.tall = 0;
-  // M >= 17, K in whole 256-k rings per wave: the tall register tile
-  if (allow_lds && M >= env_int("NMV_W4_TALL_MIN_M", 17) && K % 256 == 0 && env_int("NMV_W4_TALL", 1)) {
+  // K in whole 256-k rings per wave, group 128 / channelwise, no act-order: the tall register
+  // tile (measured faster than the kernels below at every M on the Llama-3-8B shapes)
+  if (allow_lds && M >= env_int("NMV_W4_TALL_MIN_M", 1) && K % 256 == 0 && env_int("NMV_W4_TALL", 1)) {
     pl.tall = 1;
     pl.wm = 1;
-    pl.mt = env_int("NMV_W4_TALL_MT", M <= 64 ? 2 : 4);  // measured: 64-row tile wins only past M = 64
+    pl.mt = env_int("NMV_W4_TALL_MT", M <= 16 ? 1 : M <= 64 ? 2 : 4);  // measured: 64-row tile wins only past M = 64
     const int rows = 16 * pl.mt;
     pl.m_blocks = (M + rows - 1) / rows;
     // wide N: two chunks per workgroup, two k groups; narrow N: one chunk, four k groups (the
     // in-workgroup k reduction goes through LDS and saves split-K slabs)
-    int wk = n_chunks * pl.m_blocks >= 256 ? 2 : 4;
+    int wk = (M > 32 && n_chunks * pl.m_blocks >= 256) ? 2 : 4;
     wk = env_int("NMV_W4_TALL_WK", wk);
     const int ring_k = pl.mt == 4 ? 128 : 256;  // 4 stages of 32 / 64 k
     while (wk > 1 && K % (ring_k * wk) != 0) wk >>= 1;
@@ -1332,6 +1335,7 @@ static int launch_gemm_gs(const GemmPlan& pl, const GemmParams& p, hipStream_t s
     hipLaunchKernelGGL((w4a16_gemm_tall_kernel<T, mt_, wn_, wk_, GS>), grid, block, 0, s, p);  \
     return 0;                                                                                  \
   }
+      NMV_W4_TALL_CASE(1, 4, 1) NMV_W4_TALL_CASE(1, 2, 2) NMV_W4_TALL_CASE(1, 1, 4)
       NMV_W4_TALL_CASE(2, 4, 1) NMV_W4_TALL_CASE(2, 2, 2) NMV_W4_TALL_CASE(2, 1, 4)
       NMV_W4_TALL_CASE(4, 4, 1) NMV_W4_TALL_CASE(4, 2, 2) NMV_W4_TALL_CASE(4, 1, 4)
 #undef NMV_W4_TALL_CASE
