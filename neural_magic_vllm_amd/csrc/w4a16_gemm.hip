@@ -509,378 +509,26 @@ __global__ __launch_bounds__(GT) void w4a16_gemm_kernel(const GemmParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// M >= 17: the 128-column x 64-row (or 32-row) workgroup tile with SHARED dequantisation.
+// The default kernel: "tall" register tile -- one wave = ONE 64-column chunk x 16 MT rows
+// (MT = 1 for M <= 16, 2 up to 64, 4 beyond).
 //
-// The register-only kernel above re-expands the same weights once per 16-row block (4x at M = 64,
-// M/16 x in prefill).  Here a workgroup expands every weight ONCE per 64 (32) rows:
-//   * wave w streams chunk (w & 1), k-step (w >> 1) of the 64-deep stage: one 16-byte Marlin
-//     vector per thread; v_permlane32_swap gives every lane the raw words of both k-tiles, the
-//     lower half-wave expands the block-0 columns, the upper one block 1, so a lane owns a whole
-//     16-byte MFMA operand and the wave stores 1 KiB contiguous per ds_write_b128 into the image
-//     [k-step][16-column tile][k-quad g][column r] (conflict-free for the store's 8-lane groups and
-//     for ds_read_b128's 16-lane groups: a tile read is lane l -> 16 l);
-//   * the 4 waves are arranged WNN x WMM; a wave owns (128/WNN) columns x 32 rows: 12 (6)
-//     ds_read_b128 and 20 (12) MFMAs per stage, accumulators 72 (40) VGPRs, two workgroups/CU;
-//   * weights run 4 stages (256 k) ahead in a register ring, activations 2; the main loop has no
-//     branches and no load-dependent selects (unconditional clamped loads, whole 256-k rings:
-//     the plan only picks this kernel for K % 256 == 0);
-//   * zero point (S-MFMA), group scales in fp32 at the group boundary, sc1 slabs + ticket +
-//     fixed-order reduction are the same as above.
-// Measured (MI355X, Llama-3-8B gate_up 4096 x 28672, g128): M = 64 42.5 us vs 45.8 us for the
-// register kernel, M = 32 31.3 vs 31.8, M = 2048 727 vs 1061 us.  Ablations: with
-// MFMA + LDS reads removed 31 us, with the expansion removed 41 us, loads + barrier alone 26 us:
-// the stage chain is serial and the load skeleton is latency-bound at ~24 KB in flight per CU.
-// Next step: raw weights and activations through LDS-DMA rings (no VGPR cost for depth).
-#ifndef NMV_ABL
-#define NMV_ABL 0  // experiments only: 1 no A loads, 2 no MFMA/ds_read, 3 no W expansion, 4 no W loads
-#endif
-#ifndef NMV_LDS_MID_BARRIER
-#define NMV_LDS_MID_BARRIER 0
-#endif
-constexpr int LSTAGE_K = 64;                 // k per stage (2 MFMA k-steps)
-constexpr int LKSTEPS = LSTAGE_K / 32;
-constexpr int LNT = 128;                     // columns per workgroup
-
-template <typename T, int WNN, int WMM, int GS>
-__global__ __launch_bounds__(GT, 2) void w4a16_gemm_lds_kernel(const GemmParams p) {
-  static_assert(WNN * WMM == 4, "4 waves per workgroup");
-  static_assert(GS == 0 || GS == 128, "the scale schedule below is one group per two stages");
-  constexpr int MT = 2;                       // 16-row tiles per wave
-  constexpr int MROWS = 32 * WMM;             // rows per workgroup
-  constexpr int WAVE_N = LNT / WNN;           // columns per wave
-  constexpr int NTW = WAVE_N / 16;            // column tiles per wave
-  constexpr int W_U4 = LKSTEPS * LNT * 4;     // uint4 per weight stage buffer (16 KB)
-  constexpr int A_U4 = LKSTEPS * 4 * MROWS;   // uint4 per activation stage buffer
-  constexpr int APT = (MROWS * 8 + GT - 1) / GT;  // activation 16-byte chunks per thread and stage
-  constexpr int FLUSH_KS = GS == 0 ? 4 : GS / 32;  // k-steps per scale group (1, 2 or 4)
-  __shared__ __attribute__((aligned(16))) uint4 lds[2 * W_U4 + 2 * A_U4];
-  uint4* w_s = lds;
-  uint4* a_s = lds + 2 * W_U4;
-
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wn = wave % WNN, wm = wave / WNN;
-  const int r = lane & 15, g = lane >> 4;
-  const int n_chunks = p.N >> 6;
-  const int chunk0 = blockIdx.x * 2;
-  const int m0 = blockIdx.z * MROWS;
-  const int split = blockIdx.y;
-  const int k0 = split * p.k_per_wg;
-  const int k1 = min(k0 + p.k_per_wg, p.K);
-  const int n_stages = (max(k1 - k0, 0) + LSTAGE_K - 1) / LSTAGE_K;
-
-  // ---- loader roles ----
-  // Every global load of the main loop is unconditional (addresses clamped into the tensors) and
-  // the loop body has no branches: a uniform branch around a load makes the compiler's s_waitcnt
-  // placement fall back to vmcnt(0) at the join, which serialises the whole prefetch ring.
-  // Out-of-range k / rows are neutralised through the ACTIVATIONS only (zero operands); weights
-  // are always finite (16 + q), so whatever they are multiplied with zero they contribute zero.
-  // wave w streams chunk (w & 1), k-step (w >> 1): lanes 0-31 the even k-tile, lanes 32-63 the
-  // odd one (two 512-byte runs per load instruction)
-  // half-wave lane li takes vector (li & 7) * 4 + (li >> 3): k-quad q = li >> 3 of column
-  // n_in = li & 7, so that each 8-lane store group below lands on 128 contiguous bytes
-  const int li = lane & 31, lhalf = lane >> 5, lc = wave & 1, lks = wave >> 1;
-  const int lq = li >> 3, ln_in = li & 7;
-  const int lkt = lks * 2 + lhalf;
-  const int64_t row_u4 = p.N >> 1;
-  // K % 64 == 0 on this path (see make_plan): stages are whole; a stage index past the end of K
-  // re-reads the last stage of the tensor (cache hit) and is multiplied by zero activations
-  const int st_last = __builtin_amdgcn_readfirstlane(((p.K - k0) >> 6) - 1);
-  // De-phasing: every workgroup walks the same activation rows, whose row stride (2 K bytes) is a
-  // multiple of the L2 channel interleave, so workgroups marching in lock-step all pull their
-  // activation slices through ONE L2 channel of the XCD (measured: ~128 B/clk for the whole XCD,
-  // 4x slower than the weight stream).  Workgroup number i of an XCD therefore starts its k loop
-  // i scale-groups (128 k = 256 B = one channel) further on and wraps around.  The order of the
-  // fp32 accumulation becomes a function of the block index: still fixed for a given launch shape.
-  const int n_pad = n_stages;  // whole rings: k1 - k0 is a multiple of 256
-  const int wg_linear = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-  const int rot = n_pad > 0 ? 2 * ((wg_linear >> 3) % (n_pad >> 1)) : 0;
-  auto eff = [&](int st) -> int {
-    const int se = st + rot;
-    return se >= n_pad ? se - n_pad : se;
-  };
-  const uint4* bp = p.b + (int64_t)min(chunk0 + lc, n_chunks - 1) * 32 + (ln_in * 4 + lq) +
-                    ((int64_t)(k0 >> 4) + lkt) * row_u4;
-  auto load_w = [&](int st) -> uint4 {
-    if (NMV_ABL == 4) return make_uint4(st, lane, st, lane);
-    return bp[(int64_t)min(eff(st), st_last) * (4 * row_u4)];
-  };
-  const uint16_t* ap[APT];
-#pragma unroll
-  for (int i = 0; i < APT; ++i) {
-    const int id = threadIdx.x + i * GT;   // MROWS * 8 is a multiple of 256: no tail
-    const int m = m0 + (id >> 3);
-    ap[i] = p.a + (int64_t)min(m, p.M - 1) * p.K + k0 + (id & 7) * 8;
-  }
-  auto load_a = [&](int st, uint4 (&av)[APT]) {
-    const int off = min(eff(st), st_last) * LSTAGE_K;
-#pragma unroll
-    for (int i = 0; i < APT; ++i) {
-      if (NMV_ABL == 1) av[i] = make_uint4(off, off, off, off);
-      else av[i] = ld16(ap[i] + off);
-    }
-  };
-  const uint32_t kmask = __builtin_amdgcn_readfirstlane(W4<T>::MASK);
-  uint32_t kmagic = W4<T>::MAGIC;
-  asm volatile("" : "+v"(kmagic));
-  // Expand one stage into LDS.  v_permlane32_swap hands every lane the raw words of BOTH k-tiles
-  // of its vector; the lower half-wave then expands the columns of block 0 (nibbles 0,1,4,5), the
-  // upper half-wave those of block 1 (nibbles 2,3,6,7 = the same expansion of x >> 8), so each
-  // lane owns a complete 16-byte MFMA operand (8 k of one column) and the wave writes 1 KiB
-  // contiguous per ds_write_b128: no bank conflicts.
-  const uint32_t blk_shift = lhalf * 8;
-  auto store_w = [&](int buf, uint4 x) {
-    const uint32_t xs[4] = {x.x, x.y, x.z, x.w};
-    // image: [k-step][16-column tile][k-quad g][column r] x 16 B, i.e. a wave's operand read of
-    // one tile is lane l -> 16 l (conflict-free for ds_read_b128's lane groups)
-    uint4* dst = w_s + buf * W_U4 + (lks * (LNT / 16) + lc * 4) * 64 + lq * 16 + lhalf * 8 + ln_in;
-    if (NMV_ABL == 3 || NMV_ABL == 9) { asm volatile("" :: "v"(x.x), "v"(x.y), "v"(x.z), "v"(x.w)); return; }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const auto eo = __builtin_amdgcn_permlane32_swap(xs[j], xs[j], false, false);
-      const uint32_t e = eo[0] >> blk_shift;  // even k-tile
-      const uint32_t o = eo[1] >> blk_shift;  // odd k-tile
-      dst[j * 64] = make_uint4(W4<T>::lo0(e, kmask, kmagic), W4<T>::hi0(e, kmask, kmagic),
-                                   W4<T>::lo0(o, kmask, kmagic), W4<T>::hi0(o, kmask, kmagic));
-    }
-  };
-  // No masking anywhere: rows past M are clamped duplicates of row M-1 and only feed output rows
-  // that are never stored; k ranges are whole rings (K % 256 == 0, see make_plan), so there are no
-  // stages past k1 to neutralise.
-  auto store_a = [&](int buf, const uint4 (&av)[APT]) {
-    uint32_t* base = reinterpret_cast<uint32_t*>(a_s + buf * A_U4);
-#pragma unroll
-    for (int i = 0; i < APT; ++i) {
-      const int id = threadIdx.x + i * GT;
-      const int c8 = id & 7, row = id >> 3;
-      const int ks = c8 >> 2, cc = c8 & 3;
-      const int e0 = ((ks * 4 + 0) * MROWS + row) * 4 + cc;
-      base[e0] = av[i].x;
-      base[e0 + 4 * MROWS] = av[i].y;
-      base[e0 + 8 * MROWS] = av[i].z;
-      base[e0 + 12 * MROWS] = av[i].w;
-    }
-  };
-
-  // ---- accumulators ----
-  f32x4_t accm[NTW][MT], accg[NTW][MT], accs[MT];
-  const f32x4_t zero4 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int v = 0; v < NTW; ++v)
-#pragma unroll
-    for (int t = 0; t < MT; ++t) { accm[v][t] = zero4; accg[v][t] = zero4; }
-#pragma unroll
-  for (int t = 0; t < MT; ++t) accs[t] = zero4;
-
-  // output-fragment geometry of this lane: columns n_w0 + 16 T + 4 g + reg, rows m_w0 + 16 t + r
-  const int n_w0 = blockIdx.x * LNT + wn * WAVE_N;
-  const int m_w0 = m0 + wm * 32;
-  const int out_chunk = n_w0 >> 6;
-  const bool out_ok = n_w0 < p.N;  // N % 64 == 0 and WAVE_N divides 64: all or nothing
-  const int tile_off = (n_w0 & 63) >> 4;
-  // grouped scale layout: element (4 (g&1) + reg) * 8 + 2 (tile_off + T) + (g >> 1) of the chunk
-  // per (reg, tile v) the lane wants element 2 (tile_off + v) + (g >> 1): dword v of the NTW
-  // dwords that start at element 2 tile_off, upper or lower half by lane
-  const uint16_t* sp = p.s + (int64_t)(out_ok ? out_chunk : 0) * 64 + (g & 1) * 32 + 2 * tile_off;
-  const uint32_t sc_shift = (g >> 1) * 16;
-  auto load_scales = [&](int k_abs, uint32_t (&sv)[4][NTW]) {
-    if constexpr (GS != 0) {
-      const uint16_t* sg = sp + (int64_t)(min(k_abs, p.K - 1) / GS) * p.N;
-#pragma unroll
-      for (int reg = 0; reg < 4; ++reg) {
-        if constexpr (NTW == 4) {
-          const uint4 x = ld16(sg + reg * 8);
-          sv[reg][0] = x.x; sv[reg][1] = x.y; sv[reg][2] = x.z; sv[reg][3] = x.w;
-        } else {
-          const uint2 x = *reinterpret_cast<const uint2*>(sg + reg * 8);
-          sv[reg][0] = x.x; sv[reg][1] = x.y;
-        }
-      }
-    }
-  };
-  auto flush = [&](const uint32_t (&sv)[4][NTW]) {
-    float zs[MT];
-#pragma unroll
-    for (int t = 0; t < MT; ++t) zs[t] = -W4_ZP * accs[t][0];
-#pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-#pragma unroll
-      for (int v = 0; v < NTW; ++v) {
-        float scv = 1.f;
-        if constexpr (GS != 0) scv = T::to_float((uint16_t)(sv[reg][v] >> sc_shift));
-#pragma unroll
-        for (int t = 0; t < MT; ++t) {
-          const float dlt = accg[v][t][reg] + zs[t];
-          if constexpr (GS != 0) accm[v][t][reg] = fmaf(scv, dlt, accm[v][t][reg]);
-          else accm[v][t][reg] += dlt;
-        }
-      }
-    }
-  };
-
-  // ---- prologue: four stages of global loads in flight, stage 0 parked in LDS ----
-  uint4 wr0, wr1, wr2, wr3;
-  uint4 ar0[APT], ar1[APT];  // activations come from L2: two stages ahead are enough
-  uint32_t sc[4][NTW], sc2[4][NTW];  // scales of the open group / the one after it (alternating)
-  load_a(0, ar0);
-  wr0 = load_w(0);
-  wr1 = load_w(1);
-  wr2 = load_w(2);
-  wr3 = load_w(3);
-  load_scales(k0 + eff(0) * LSTAGE_K, sc);
-  store_w(0, wr0); store_a(0, ar0);
-  load_a(1, ar1);
-  __syncthreads();
-  const uint4 ones = make_uint4(W4<T>::ONES, W4<T>::ONES, W4<T>::ONES, W4<T>::ONES);
-
-  // one stage (U = its position in the 4-stage ring, so the scale-group schedule is static):
-  // refill the ring slot that just became free with stage st+4, multiply stage st out of LDS,
-  // then expand stage st+1 (ring slot `nw`) into the other LDS buffer.  k0 is a multiple of 128
-  // and the loop runs whole rings (256 k), so every scale group closes inside the loop; stages
-  // past k1 multiply zero activations.
-  auto stage = [&](auto u_tag, int st, uint4& freew, uint4 (&freea)[APT], const uint4& nw,
-                   const uint4 (&na)[APT], const uint32_t (&sc_use)[4][NTW],
-                   uint32_t (&sc_load)[4][NTW]) {
-    constexpr int U = decltype(u_tag)::value;
-    constexpr int buf = U & 1;
-    // a stage that closes a scale group fetches the NEXT group's scales first, ahead of its ring
-    // refill: by the time they are used (next flush) every load older than them has to be back
-    // anyway for the LDS expansion, so the ring never waits on their account
-    constexpr bool closes_group = ((U + 1) * LKSTEPS) % FLUSH_KS == 0;
-    if constexpr (closes_group && GS != 0) load_scales(k0 + eff(st + 1) * LSTAGE_K, sc_load);
-    load_a(st + 2, freea);  // ahead of the weight refill: in-order vmcnt then never makes the
-    freew = load_w(st + 4);   // weight ring wait for more than W(st + 3) on account of A
-
-    // keep the scheduler from hoisting the expansion of later ring slots up here (that would
-    // make this stage wait for loads issued one stage ago) and from sinking the refill
-    __builtin_amdgcn_sched_barrier(0);
-    const uint4* wb = w_s + buf * W_U4;
-    const uint4* ab = a_s + buf * A_U4;
-#pragma unroll
-    for (int ks = 0; ks < LKSTEPS; ++ks) {
-      if (NMV_ABL == 2 || NMV_ABL == 9) break;
-      const int kstep = U * LKSTEPS + ks;             // static after unrolling
-      const bool first = kstep % FLUSH_KS == 0;
-      const bool last = (kstep + 1) % FLUSH_KS == 0;
-      uint4 af[MT];
-#pragma unroll
-      for (int t = 0; t < MT; ++t) af[t] = ab[(ks * 4 + g) * MROWS + wm * 32 + t * 16 + r];
-#pragma unroll
-      for (int v = 0; v < NTW; ++v) {
-        const uint4 wf = wb[(ks * (LNT / 16) + wn * NTW + v) * 64 + lane];
-#pragma unroll
-        for (int t = 0; t < MT; ++t)
-          accg[v][t] = W4<T>::mfma(wf, af[t], first ? zero4 : accg[v][t]);
-      }
-#pragma unroll
-      for (int t = 0; t < MT; ++t) accs[t] = W4<T>::mfma(ones, af[t], first ? zero4 : accs[t]);
-      if (last) flush(sc_use);
-    }
-    if (NMV_LDS_MID_BARRIER) __builtin_amdgcn_sched_barrier(0);
-    store_w(buf ^ 1, nw);
-    if (NMV_ABL == 8) asm volatile("" :: "v"(na[0].x), "v"(na[0].y), "v"(na[0].z), "v"(na[0].w));
-    else store_a(buf ^ 1, na);
-    __builtin_amdgcn_sched_barrier(0);
-    if (NMV_ABL != 7) __syncthreads();
-  };
-  const int n_rings = NMV_ABL == 5 ? 0 : n_pad >> 2;
-  for (int it = 0; it < n_rings; ++it) {
-    const int st = it * 4;
-    stage(std::integral_constant<int, 0>{}, st, wr0, ar0, wr1, ar1, sc, sc2);
-    stage(std::integral_constant<int, 1>{}, st + 1, wr1, ar1, wr2, ar0, sc, sc2);
-    stage(std::integral_constant<int, 2>{}, st + 2, wr2, ar0, wr3, ar1, sc2, sc);
-    stage(std::integral_constant<int, 3>{}, st + 3, wr3, ar1, wr0, ar0, sc2, sc);
-  }
-
-  if (GS == 0 && out_ok) {
-#pragma unroll
-    for (int v = 0; v < NTW; ++v) {
-#pragma unroll
-      for (int reg = 0; reg < 4; ++reg) {
-        const int c64 = (tile_off + v) * 16 + 4 * g + reg;
-        const int c = c64 & 31;
-        const int pos = (c64 >> 5) * 32 + ((c & 7) >> 1) * 8 + 2 * (c >> 3) + (c & 1);
-        const float sv = T::to_float(p.s[(int64_t)out_chunk * 64 + pos]);
-#pragma unroll
-        for (int t = 0; t < MT; ++t) accm[v][t][reg] *= sv;
-      }
-    }
-  }
-
-  // ---- epilogue ----
-  if (NMV_ABL == 6) {
-    float acc = 0.f;
-#pragma unroll
-    for (int t = 0; t < MT; ++t)
-#pragma unroll
-      for (int v = 0; v < NTW; ++v) acc += accm[v][t][0] + accm[v][t][1] + accm[v][t][2] + accm[v][t][3];
-    if (acc == 12345.678f) p.c[0] = 1;
-    return;
-  }
-  if (p.splits == 1) {
-    if (!out_ok) return;
-#pragma unroll
-    for (int t = 0; t < MT; ++t) {
-      const int m = m_w0 + t * 16 + r;
-      if (m >= p.M) continue;
-#pragma unroll
-      for (int v = 0; v < NTW; ++v) {
-        const int n = n_w0 + v * 16 + 4 * g;
-        const f32x4_t o = accm[v][t];
-        uint2 pk;
-        pk.x = T::pack2(o[0], o[1]);
-        pk.y = T::pack2(o[2], o[3]);
-        *reinterpret_cast<uint2*>(p.c + (int64_t)m * p.N + n) = pk;
-      }
-    }
-    return;
-  }
-  // split-K: write-through slabs, ticket, the last workgroup of the tile reduces (see above)
-  const int64_t slab_bytes = (int64_t)p.splits * p.M * p.N * 4;
-  __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p.slab, 0, (int)slab_bytes, 0x00020000);
-  if (out_ok) {
-#pragma unroll
-    for (int t = 0; t < MT; ++t) {
-      const int m = m_w0 + t * 16 + r;
-      if (m >= p.M) continue;
-#pragma unroll
-      for (int v = 0; v < NTW; ++v) {
-        const int n = n_w0 + v * 16 + 4 * g;
-        const int off = (int)((((int64_t)split * p.M + m) * p.N + n) * 4);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, accm[v][t]), rs, off, 0, 16);
-      }
-    }
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __shared__ int ticket_s;
-  __syncthreads();
-  const int tile = blockIdx.z * gridDim.x + blockIdx.x;
-  if (threadIdx.x == 0)
-    ticket_s = __hip_atomic_fetch_add(p.tickets + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __syncthreads();
-  if (ticket_s != p.splits - 1) return;
-  if (threadIdx.x == 0)
-    __hip_atomic_store(p.tickets + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __syncthreads();  // the operand images are dead: reuse them for the partial sums
-  splitk_reduce_tile<T>(p, rs, m0, MROWS, blockIdx.x * LNT, LNT, reinterpret_cast<f32x4_t*>(lds));
-}
-
-// ---------------------------------------------------------------------------------------------
-// M >= 17, "tall" register tile: one wave = ONE 64-column chunk x 16 MT rows (MT = 2 or 4).
-//
-// The 16-row kernel re-expands every weight once per 16 rows; the LDS kernel below expands once per
-// workgroup but pays a serial barrier chain per 64 k.  Here the expansion is shared the cheap way:
-// the wave that expanded a weight multiplies it against ALL its MT row tiles, straight from
-// registers -- no LDS round trip and no barrier for the weights.  A 64-column chunk has 16-column
-// MFMA tiles j = 0..3 whose rows are r = 8 blk + n_in, so lane (r, g) needs the blk half of Marlin
-// vector (n_in, q = g) from both k-tiles of the 32-deep step.  Lanes r and r^8 want the two halves of
-// the same two vectors: the blk-0 lane loads the even k-tile, the blk-1 lane the odd one (every
-// byte is loaded once, one 16-byte load per lane and k-step), they swap through one DPP row
-// rotate (row_ror:8), and each lane expands its own half with per-lane rotate amounts
-// (v_alignbit_b32 + v_and_or_b32 = 2 ops per 2 weights, as everywhere).  Weights run RING-1 stages
-// ahead in an 8-VGPR-per-stage ring; activations are staged through LDS as in the 16-row kernel;
-// group scales come through LDS with them.  Main loop: branch-free, whole rings (the plan only
-// picks this kernel when every wave's k range is a multiple of 256).
+// The 16-row kernel above re-expands every weight once per 16 rows and prefetches one 128-k stage.
+// A workgroup-shared expansion through LDS (tried: 128 x 64 tile, weights expanded once per
+// workgroup into an MFMA-operand image) removes the redundancy but pays a serial
+// wait -> ds_read -> MFMA -> expand -> ds_write -> barrier chain per 64 k and ended up no faster
+// (DESIGN.md 3.3).  Here the expansion is shared the cheap way: the wave that expanded a weight
+// multiplies it against ALL its MT row tiles, straight from registers -- no LDS round trip and no
+// barrier for the weights.  A 64-column chunk has 16-column MFMA tiles j = 0..3 whose rows are
+// r = 8 blk + n_in, so lane (r, g) needs the blk half of Marlin vector (n_in, q = g) from both
+// k-tiles of the 32-deep step.  Lanes r and r^8 want the two halves of the same two vectors: the
+// blk-0 lane loads the even k-tile, the blk-1 lane the odd one (every byte is loaded once, one
+// 16-byte load per lane and k-step), they swap through one DPP row rotate (row_ror:8), and each
+// lane expands its own half with per-lane rotate amounts (v_alignbit_b32 + v_and_or_b32 = 2 ops
+// per 2 weights, as everywhere).  Weights run 3 stages ahead in a 4-slot register ring of 4-8
+// VGPRs per slot; activations are staged through LDS as in the 16-row kernel and the group's scale
+// rows travel with them.  The 4 waves split N (WN) and K (WK); the in-workgroup K reduction goes
+// through LDS, so narrow projections need few split-K slabs.  Main loop: branch-free, whole rings
+// (the plan only picks this kernel when every wave's k range is a multiple of 4 stages).
 // Stage = 64 k (two MFMA k-steps) for the 32-row tile, 32 k for the 64-row tile: a 64-row k-step
 // carries 20 MFMAs, so the same look-ahead in time needs half the k -- and half the ring and
 // staging registers, which is what lets 144 accumulator VGPRs fit under 256.
@@ -1229,7 +877,6 @@ __global__ void marlin_repack_kernel(const uint32_t* __restrict__ qw, const int*
 struct GemmPlan {
   int mt, wn, wm, wk;  // kernel shape
   int splits, k_per_wg, m_blocks, n_blocks;
-  int lds_kind;  // 0: register kernel (16-row tiles); 1: LDS kernel 4x1 (32 rows); 2: 2x2 (64 rows)
   int tall;      // 1: tall register tile (64 columns x 16 mt rows per wave); wn, wk, mt say which
 };
 
@@ -1241,14 +888,13 @@ static int env_int(const char* name, int dflt) {
 // Pick the workgroup shape and the split-K factor.  Decode-sized GEMMs (M <= 64) last only a
 // few microseconds at HBM speed, so the plan aims at >= ~2 workgroups per CU while keeping the
 // fp32 partial traffic (splits * M * N * 4 B) well below the weight bytes (K * N / 2).
-static GemmPlan make_plan(int M, int N, int K, int64_t tickets_len, bool allow_lds = false) {
+static GemmPlan make_plan(int M, int N, int K, int64_t tickets_len, bool allow_tall = false) {
   GemmPlan pl;
   const int n_chunks = N / 64;
-  pl.lds_kind = 0;
   pl.tall = 0;
   // K in whole 256-k rings per wave, group 128 / channelwise, no act-order: the tall register
   // tile (measured faster than the kernels below at every M on the Llama-3-8B shapes)
-  if (allow_lds && M >= env_int("NMV_W4_TALL_MIN_M", 1) && K % 256 == 0 && env_int("NMV_W4_TALL", 1)) {
+  if (allow_tall && M >= env_int("NMV_W4_TALL_MIN_M", 1) && K % 256 == 0 && env_int("NMV_W4_TALL", 1)) {
     pl.tall = 1;
     pl.wm = 1;
     pl.mt = env_int("NMV_W4_TALL_MT", M <= 16 ? 1 : M <= 64 ? 2 : 4);  // measured: 64-row tile wins only past M = 64
@@ -1268,28 +914,6 @@ static GemmPlan make_plan(int M, int N, int K, int64_t tickets_len, bool allow_l
     const int base_wgs = pl.n_blocks * pl.m_blocks;
     int splits = std::max(1, env_int("NMV_W4_TALL_WGS", 512) / base_wgs);
     splits = std::min(splits, env_int("NMV_W4_TALL_MAX_SPLITS", 8));
-    splits = env_int("NMV_W4_SPLITS", splits);
-    splits = std::max(1, std::min(splits, k_units));
-    if ((int64_t)base_wgs > tickets_len) splits = 1;
-    pl.k_per_wg = ((k_units + splits - 1) / splits) * unit;
-    pl.splits = (K + pl.k_per_wg - 1) / pl.k_per_wg;
-    return pl;
-  }
-  const int lds_min_m = env_int("NMV_W4_LDS_MIN_M", 17);
-  if (allow_lds && M >= lds_min_m && K % 256 == 0) {
-    // shared-dequantisation tile: 128 columns x 32 rows (<= 32 rows) or x 64 rows
-    pl.lds_kind = env_int("NMV_W4_LDS_KIND", (M <= 32) ? 1 : 2);
-    pl.mt = 2; pl.wm = pl.lds_kind; pl.wn = 4 / pl.wm; pl.wk = 1;
-    const int rows = 32 * pl.wm;
-    pl.m_blocks = (M + rows - 1) / rows;
-    pl.n_blocks = (n_chunks + 1) / 2;
-    const int unit = 256;  // whole prefetch rings
-    const int k_units = (K + unit - 1) / unit;
-    const int base_wgs = pl.n_blocks * pl.m_blocks;
-    // one resident wave of workgroups (2 per CU); more than 8 slabs per tile costs more in the
-    // reduction than the extra parallelism returns (measured on the Llama-3-8B shapes, M = 64)
-    int splits = std::max(1, env_int("NMV_W4_LDS_WGS", 512) / base_wgs);
-    splits = std::min(splits, env_int("NMV_W4_LDS_MAX_SPLITS", 8));
     splits = env_int("NMV_W4_SPLITS", splits);
     splits = std::max(1, std::min(splits, k_units));
     if ((int64_t)base_wgs > tickets_len) splits = 1;
@@ -1341,17 +965,8 @@ static int launch_gemm_gs(const GemmPlan& pl, const GemmParams& p, hipStream_t s
 #undef NMV_W4_TALL_CASE
       return -1;
     }
-    const int pad = env_int("NMV_W4_LDS_PAD", 0);  // experiments: extra LDS lowers the occupancy
-    if (pl.lds_kind == 1) {
-      hipLaunchKernelGGL((w4a16_gemm_lds_kernel<T, 4, 1, GS>), grid, block, pad, s, p);
-      return 0;
-    }
-    if (pl.lds_kind == 2) {
-      hipLaunchKernelGGL((w4a16_gemm_lds_kernel<T, 2, 2, GS>), grid, block, pad, s, p);
-      return 0;
-    }
   }
-  if (pl.lds_kind != 0 || pl.tall) return -1;
+  if (pl.tall) return -1;
 #define NMV_W4_CASE(MT_, WN_, WM_, WK_)                                                         \
   if (pl.mt == MT_ && pl.wn == WN_ && pl.wm == WM_ && pl.wk == WK_) {                           \
     hipLaunchKernelGGL((w4a16_gemm_kernel<T, MT_, WN_, WM_, WK_, GS>), grid, block, 0, s, p);   \
@@ -1461,10 +1076,10 @@ extern "C" int nmv_gptq_marlin_gemm(void* c, const void* a, const int32_t* b_q_w
     NMV_LAUNCH_CHECK();
     return NMV_OK;
   }
-  // the shared-dequantisation kernel covers the prevalent formats (group 128 / channelwise, no
-  // act-order gather); everything else stays on the register kernel
-  const bool allow_lds = !has_act_order && (group_size == 0 || group_size == 128);
-  const GemmPlan pl = make_plan(size_m, size_n, size_k, workspace ? workspace_len : 0, allow_lds);
+  // the tall kernel covers the prevalent formats (group 128 / channelwise, no act-order gather);
+  // groups of 32 / 64 and act-order stay on the 16-row kernel
+  const bool allow_tall = !has_act_order && (group_size == 0 || group_size == 128);
+  const GemmPlan pl = make_plan(size_m, size_n, size_k, workspace ? workspace_len : 0, allow_tall);
   const int64_t need = pl.splits > 1 ? (int64_t)pl.splits * size_m * size_n * 4 : 0;
   NMV_CHECK(need < (int64_t)1 << 31, "gptq_marlin_gemm: split-K slab too large");
   NMV_CHECK(scratch_bytes >= need && (need == 0 || scratch != nullptr),

@@ -77,6 +77,49 @@ def test_marlin_gemm(gpu_device, k, n, m, group_size, dtype):
     assert ref_math.compute_max_diff(c, ref) < 6e-3
 
 
+TALL_CASES = [  # (rows per wave / 16, k groups per workgroup, M values that pick or fit the tile)
+    (1, 1, [1, 9, 16]), (1, 2, [3, 16]), (1, 4, [1, 12]),
+    (2, 1, [17, 33]), (2, 2, [20, 64]), (2, 4, [31, 47]),
+    (4, 1, [40, 65]), (4, 2, [64, 130]), (4, 4, [33, 100]),
+]
+
+
+@pytest.mark.parametrize("mt,wk,ms", TALL_CASES)
+@pytest.mark.parametrize("k,n", [(1024, 64), (2048, 448)])
+@pytest.mark.parametrize("group_size", [-1, 128])
+@pytest.mark.parametrize("dtype", [torch.half, torch.bfloat16])
+def test_marlin_gemm_tall_variants(gpu_device, monkeypatch, mt, wk, ms, k, n, group_size, dtype):
+    """every instantiation of the default (tall register tile) kernel, forced through its
+    development knobs: tile height x in-workgroup k split, ragged M, with and without split-K"""
+    monkeypatch.setenv("NMV_W4_TALL_MT", str(mt))
+    monkeypatch.setenv("NMV_W4_TALL_WK", str(wk))
+    for m in ms:
+        for splits in (None, 2):
+            if splits:
+                monkeypatch.setenv("NMV_W4_SPLITS", str(splits))
+            else:
+                monkeypatch.delenv("NMV_W4_SPLITS", raising=False)
+            pr = helpers.make_w4a16_problem(5, m, k, n, 4, group_size, False, dtype)
+            c = hip_gemm(pr, m, n, k, 4, gpu_device)
+            ref = oracle.gptq_marlin_gemm(pr["a"], pr["marlin_q_w"], pr["marlin_s"], None, None, 4, m, n, k)
+            assert not torch.isnan(c.float()).any()
+            assert ref_math.compute_max_diff(c, ref) < 6e-3, (m, splits)
+
+
+@pytest.mark.parametrize("m", [1, 40])
+def test_marlin_gemm_16row_kernel_still_covered(gpu_device, monkeypatch, m):
+    """NMV_W4_TALL=0 routes group-128 problems to the 16-row kernel (the path of groups 32/64,
+    act-order and K % 256 != 0): same answer within rounding"""
+    k, n = 1024, 448
+    pr = helpers.make_w4a16_problem(6, m, k, n, 4, 128, False, torch.bfloat16)
+    c_tall = hip_gemm(pr, m, n, k, 4, gpu_device)
+    monkeypatch.setenv("NMV_W4_TALL", "0")
+    c_16 = hip_gemm(pr, m, n, k, 4, gpu_device)
+    ref = oracle.gptq_marlin_gemm(pr["a"], pr["marlin_q_w"], pr["marlin_s"], None, None, 4, m, n, k)
+    assert ref_math.compute_max_diff(c_16, ref) < 6e-3
+    assert ref_math.compute_max_diff(c_tall, c_16) < 6e-3
+
+
 @pytest.mark.parametrize("k,n", [(1024, 256), (640, 448)])
 @pytest.mark.parametrize("m", [1, 26])
 @pytest.mark.parametrize("group_size", [32, 128])
