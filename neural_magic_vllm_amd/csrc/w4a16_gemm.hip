@@ -583,7 +583,6 @@ __global__ __launch_bounds__(GT, 2) void w4a16_gemm_tall_kernel(const GemmParams
   asm volatile("" : "+v"(kmagic));
   const uint32_t rot_lo = blk ? W4<T>::ROT_LO1 : W4<T>::ROT_LO0;
   const uint32_t rot_hi = blk ? W4<T>::ROT_HI1 : W4<T>::ROT_HI0;
-  const bool odd_lane = blk != 0;
 
   // ---- activations (+ the scale rows of the group) -> registers -> LDS ----
   constexpr int A_CHUNKS = WK * MP * PPR;                  // 16-byte pieces per stage
@@ -707,10 +706,11 @@ __global__ __launch_bounds__(GT, 2) void w4a16_gemm_tall_kernel(const GemmParams
       const uint32_t own[4] = {wc[ks].x, wc[ks].y, wc[ks].z, wc[ks].w};
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        // partner lane r^8 holds the other k-tile of the same vector
-        const uint32_t oth = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)own[j], 0x128, 0xf, 0xf, false);
-        const uint32_t e = odd_lane ? oth : own[j];   // even k-tile
-        const uint32_t o = odd_lane ? own[j] : oth;   // odd k-tile
+        // partner lane r^8 holds the other k-tile of the same vector: one DPP move per k-tile,
+        // row_ror:8 with a bank mask so that only the half-row that needs the partner's word takes
+        // it (banks 2,3 = lanes 8..15 = blk 1 for the even k-tile, banks 0,1 for the odd one)
+        const uint32_t e = (uint32_t)__builtin_amdgcn_update_dpp((int)own[j], (int)own[j], 0x128, 0xf, 0xc, false);
+        const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp((int)own[j], (int)own[j], 0x128, 0xf, 0x3, false);
         const uint4 wv = make_uint4(and_or(__builtin_amdgcn_alignbit(e, e, rot_lo), kmask, kmagic),
                                     and_or(__builtin_amdgcn_alignbit(e, e, rot_hi), kmask, kmagic),
                                     and_or(__builtin_amdgcn_alignbit(o, o, rot_lo), kmask, kmagic),
