@@ -46,7 +46,13 @@ struct PAGeom {
   static constexpr int RPL = WAVE / CPR;            // V rows covered by one wave-load
   static constexpr int NVL = (HEAD_SIZE + RPL - 1) / RPL;  // wave-loads per block
   static constexpr int WB = PA_WIN / BLOCK_SIZE;    // blocks per window
-  static constexpr int KG = NKC < 8 ? NKC : 8;      // K chunks in flight per lane
+#ifndef NMV_PA_KG
+#define NMV_PA_KG 8
+#endif
+#ifndef NMV_PA_VG
+#define NMV_PA_VG 4
+#endif
+  static constexpr int KG = NKC < NMV_PA_KG ? NKC : NMV_PA_KG;  // K chunks in flight per lane
   static_assert(HEAD_SIZE % EPC == 0, "head size must be a multiple of x");
   static_assert(PA_WIN % BLOCK_SIZE == 0, "block size must divide the window");
 };
@@ -115,7 +121,15 @@ __global__ __launch_bounds__(PA_THREADS) void paged_attention_kernel(
   }
 
   const int* block_table = block_tables + (int64_t)seq_idx * max_num_blocks_per_seq;
-  const int n_win = (end_tok - start_tok + PA_WIN - 1) / PA_WIN;
+  // Each wave takes a CONTIGUOUS run of KV blocks, the runs differing by at most one block
+  // (start_tok is block aligned: partitions are multiples of the block size).  Dealing 64-token
+  // windows round-robin instead leaves 9 windows as 3+2+2+2: the first wave then sets the time of
+  // the workgroup, +25..50 % just past every multiple of 256 tokens.
+  const int n_blk = (end_tok - start_tok + BLOCK_SIZE - 1) / BLOCK_SIZE;
+  const int blk_lo = (n_blk / PA_WAVES) * wave + min(wave, n_blk % PA_WAVES);
+  const int blk_cnt = n_blk / PA_WAVES + (wave < n_blk % PA_WAVES ? 1 : 0);
+  const int w_tok0 = start_tok + blk_lo * BLOCK_SIZE;                       // this wave's tokens:
+  const int w_tok1 = min(w_tok0 + blk_cnt * BLOCK_SIZE, end_tok);           // [w_tok0, w_tok1)
   const float qk_scale = FP8 ? scale * kv_scale : scale;
   const int64_t head_off_bytes = (int64_t)kv_head * kv_head_stride * G::CB;
   const int64_t block_stride_bytes = kv_block_stride * G::CB;
@@ -124,20 +138,19 @@ __global__ __launch_bounds__(PA_THREADS) void paged_attention_kernel(
   const int cpr_idx = lane % G::CPR;
   const int row_l = lane / G::CPR;
 
-  auto phys_of = [&](int w) -> int {
-    const int tok = min(start_tok + w * PA_WIN + lane, end_tok - 1);
+  auto phys_of = [&](int wstart) -> int {
+    const int tok = min(wstart + lane, w_tok1 - 1);
     return block_table[tok / BLOCK_SIZE];
   };
-  int phys = wave < n_win ? phys_of(wave) : 0;
+  int phys = w_tok0 < w_tok1 ? phys_of(w_tok0) : 0;
 
-  for (int w = wave; w < n_win; w += PA_WAVES) {
-    const int wstart = start_tok + w * PA_WIN;
+  for (int wstart = w_tok0; wstart < w_tok1; wstart += PA_WIN) {
     const int tok = wstart + lane;
-    const bool valid = tok < end_tok;
-    const int tok_c = valid ? tok : end_tok - 1;
+    const bool valid = tok < w_tok1;
+    const int tok_c = valid ? tok : w_tok1 - 1;
     const int boff = tok_c % BLOCK_SIZE;
     // block-table lookup of the NEXT window issued before this window's loads are consumed
-    const int phys_next = (w + PA_WAVES < n_win) ? phys_of(w + PA_WAVES) : 0;
+    const int phys_next = (wstart + PA_WIN < w_tok1) ? phys_of(wstart + PA_WIN) : 0;
 
     // ================= Q.K^T : lane = token =================
     const uint8_t* kp = k_cache + (int64_t)phys * block_stride_bytes + head_off_bytes + boff * 16;
@@ -213,7 +226,7 @@ __global__ __launch_bounds__(PA_THREADS) void paged_attention_kernel(
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
     // ================= P.V : lanes re-mapped onto V's [row][token] layout =================
-    const int win_tokens = min(end_tok - wstart, PA_WIN);
+    const int win_tokens = min(w_tok1 - wstart, PA_WIN);
     const int nb = (win_tokens + BLOCK_SIZE - 1) / BLOCK_SIZE;
 #pragma unroll
     for (int b = 0; b < G::WB; ++b) {
@@ -234,7 +247,7 @@ __global__ __launch_bounds__(PA_THREADS) void paged_attention_kernel(
           pp[h][j] = t.x; pp[h][j + 1] = t.y; pp[h][j + 2] = t.z; pp[h][j + 3] = t.w;
         }
       }
-      constexpr int VG = G::NVL < 4 ? G::NVL : 4;  // V wave-loads in flight per lane
+      constexpr int VG = G::NVL < NMV_PA_VG ? G::NVL : NMV_PA_VG;  // V wave-loads in flight per lane
 #pragma unroll
       for (int i0 = 0; i0 < G::NVL; i0 += VG) {
         uint32_t vraw[VG][4];

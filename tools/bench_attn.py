@@ -1,0 +1,73 @@
+"""GPU microbenchmark of paged_attention_v1/v2 at Llama-3-8B geometry (32 q heads, 8 kv heads,
+D=128, block 16), hipGraph-timed; KV caches sized past the Infinity Cache and block tables random.
+usage: python tools/bench_attn.py [--cases B:L,B:L,...] [--kv auto|fp8]"""
+import argparse
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from neural_magic_vllm_amd import _custom_ops as ops  # noqa: E402
+from neural_magic_vllm_amd.attention.ops.paged_attn import PagedAttention  # noqa: E402
+
+
+def bench(b, L, dev, kv, iters=20, nq=32, nkv=8, d=128, bs=16):
+    blocks_per_seq = (L + bs - 1) // bs
+    nb = max(b * blocks_per_seq * 2, (640 << 20) // (2 * nkv * d * bs * (1 if kv == "fp8" else 2)))
+    cdt = torch.uint8 if kv == "fp8" else torch.bfloat16
+    x = 16 // (1 if kv == "fp8" else 2)
+    g = torch.Generator(device=dev).manual_seed(0)
+    if kv == "fp8":
+        kc = torch.randint(0, 120, (nb, nkv, d // x, bs, x), dtype=torch.uint8, device=dev, generator=g)
+        vc = torch.randint(0, 120, (nb, nkv, d, bs), dtype=torch.uint8, device=dev, generator=g)
+    else:
+        kc = (torch.rand((nb, nkv, d // x, bs, x), device=dev, generator=g) - 0.5).to(cdt)
+        vc = (torch.rand((nb, nkv, d, bs), device=dev, generator=g) - 0.5).to(cdt)
+    q = torch.randn((b, nq, d), device=dev, dtype=torch.bfloat16, generator=g) * 0.1
+    out = torch.empty_like(q)
+    seq_lens = torch.full((b, ), L, dtype=torch.int32, device=dev)
+    # distinct random blocks per (iteration, seq): every replayed call reads fresh HBM lines
+    tables = [torch.randperm(nb, device=dev, generator=g)[:b * blocks_per_seq].to(torch.int32)
+              .view(b, blocks_per_seq) for _ in range(iters)]
+
+    def run(i):
+        PagedAttention.forward_decode(q, kc, vc, tables[i], seq_lens, L, "fp8" if kv == "fp8" else "auto",
+                                      nkv, d**-0.5, None, 1.0, out=out) if False else \
+            ops.paged_attention_v1(out, q, kc, vc, nkv, d**-0.5, tables[i], seq_lens, bs, L, None,
+                                   "fp8" if kv == "fp8" else "auto", 1.0)
+
+    run(0)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        run(0)
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        for i in range(iters):
+            run(i)
+    graph.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    graph.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / iters * 1e3
+    alg = 2 * b * L * nkv * d * (1 if kv == "fp8" else 2)
+    return us, alg / us / 1e3
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", default="64:512,32:512,8:512,1:512,64:2048,8:8192")
+    ap.add_argument("--kv", default="auto")
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    for c in args.cases.split(","):
+        b, L = (int(v) for v in c.split(":"))
+        us, gbs = bench(b, L, dev, args.kv)
+        print(f"attn v1 B={b:3d} L={L:5d} kv={args.kv}  {us:8.1f} us  {gbs:7.0f} GB/s", flush=True)
