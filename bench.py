@@ -198,6 +198,12 @@ def main():
         runner.setup_batch(batch, args.context, steps + warmup + 8)
         runner.fill_context()
         graphed = False if args.no_graph else runner.capture()
+        if world > 1:  # every rank replays a graph, or none does
+            ok = torch.tensor([1 if graphed else 0], device=dev, dtype=torch.int32)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if graphed and int(ok.item()) == 0:
+                runner.graph = None
+                graphed = False
         for _ in range(warmup):
             runner.decode_step()
         torch.cuda.synchronize(dev)

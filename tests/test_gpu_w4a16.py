@@ -142,6 +142,18 @@ def test_marlin_gemm_llama_shapes(gpu_device, m, k, n):
     assert ref_math.compute_max_diff(c, ref) < 6e-3
 
 
+@pytest.mark.parametrize("tp", [2, 4, 8])
+@pytest.mark.parametrize("m", [1, 64])
+def test_marlin_gemm_tp_shard_shapes(gpu_device, tp, m):
+    """the per-rank shapes of Llama-3-8B under tensor parallelism (column-parallel qkv / gate_up:
+    N / tp; row-parallel o / down: K / tp) -- what `bench.py --gpus tp` launches on every rank"""
+    for k, n in [(4096, 6144 // tp), (4096 // tp, 4096), (4096, 28672 // tp), (14336 // tp, 4096)]:
+        pr = helpers.make_w4a16_problem(7, m, k, n, 4, 128, False, torch.bfloat16)
+        c = hip_gemm(pr, m, n, k, 4, gpu_device)
+        ref = oracle.gptq_marlin_gemm(pr["a"], pr["marlin_q_w"], pr["marlin_s"], None, None, 4, m, n, k)
+        assert ref_math.compute_max_diff(c, ref) < 6e-3, (tp, k, n)
+
+
 @pytest.mark.parametrize("dtype", [torch.half, torch.bfloat16])
 @pytest.mark.parametrize("group_size", [-1, 128])
 def test_marlin_gemm_one_hot_is_exact_dequant(gpu_device, dtype, group_size):
