@@ -154,6 +154,16 @@ def test_marlin_gemm_tp_shard_shapes(gpu_device, tp, m):
         assert ref_math.compute_max_diff(c, ref) < 6e-3, (tp, k, n)
 
 
+@pytest.mark.parametrize("m", [1, 64])
+def test_marlin_gemm_llama70b_tp8_shapes(gpu_device, m):
+    """BASELINE.json configs[4]: Llama-3-70B TP=8 per-rank projections"""
+    for k, n in [(8192, 1280), (1024, 8192), (8192, 7168), (3584, 8192)]:
+        pr = helpers.make_w4a16_problem(8, m, k, n, 4, 128, False, torch.bfloat16)
+        c = hip_gemm(pr, m, n, k, 4, gpu_device)
+        ref = oracle.gptq_marlin_gemm(pr["a"], pr["marlin_q_w"], pr["marlin_s"], None, None, 4, m, n, k)
+        assert ref_math.compute_max_diff(c, ref) < 6e-3, (k, n)
+
+
 @pytest.mark.parametrize("dtype", [torch.half, torch.bfloat16])
 @pytest.mark.parametrize("group_size", [-1, 128])
 def test_marlin_gemm_one_hot_is_exact_dequant(gpu_device, dtype, group_size):

@@ -11,7 +11,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from neural_magic_vllm_amd import _custom_ops as ops  # noqa: E402
 
-SHAPES = {"qkv": (4096, 6144), "o": (4096, 4096), "gate_up": (4096, 28672), "down": (14336, 4096)}
+SHAPES = {"qkv": (4096, 6144), "o": (4096, 4096), "gate_up": (4096, 28672), "down": (14336, 4096),
+          # Llama-3-70B, TP=8, per rank (BASELINE.json configs[4])
+          "qkv70": (8192, 1280), "o70": (1024, 8192), "gate_up70": (8192, 7168), "down70": (3584, 8192)}
+DEFAULT_SHAPES = "qkv,o,gate_up,down"
 
 
 def bench(name, k, n, m, dev, iters=40, gs=128):
@@ -55,7 +58,7 @@ if __name__ == "__main__":
     ap.add_argument("--sweep", action="store_true")
     ap.add_argument("--ms", default="1,16,32,64")
     ap.add_argument("--gs", type=int, default=128, help="group size; -1 = channelwise")
-    ap.add_argument("--shapes", default=",".join(SHAPES))
+    ap.add_argument("--shapes", default=DEFAULT_SHAPES)
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     ms = [int(x) for x in args.ms.split(",")]
