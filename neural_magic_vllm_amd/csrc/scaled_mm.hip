@@ -53,24 +53,31 @@ template <> struct Acc<true> {
 };
 
 constexpr int MM_THREADS = 256;
-constexpr int MM_UNROLL = 4;  // 64-byte k-steps in flight per lane
-
-template <typename T, bool FP8, int MT>
+// A wave owns NT 16-column tiles x MT 16-row tiles: every activation fragment it loads is used for
+// NT column tiles and every weight fragment for MT row tiles, so at M = 64 the activations are
+// re-read once per 64 columns instead of once per 16 (that re-read, 4x the weight bytes on the
+// wide projections, was what held the first version at 1.1-1.6 TB/s at M = 64).  UN 64-byte
+// k-steps are in flight per lane.
+template <typename T, bool FP8, int MT, int NT, int UN>
 __global__ __launch_bounds__(MM_THREADS) void scaled_mm_kernel(const MMParams p) {
   using A = Acc<FP8>;
-  __shared__ float red[3][MT][4][64];
+  __shared__ float red[3][NT][MT][4][64];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r = lane & 15, g = lane >> 4;
-  const int n0 = blockIdx.x * 16;
+  const int n0 = blockIdx.x * (16 * NT);
   const int m0 = blockIdx.y * (16 * MT);
   // K split over the 4 waves in multiples of 64
   const int ksteps = (p.K + 63) / 64;
   const int per_wave = (ksteps + 3) / 4;
   const int ks0 = wave * per_wave, ks1 = min(ks0 + per_wave, ksteps);
 
-  const int n_row = min(n0 + r, p.N - 1);
-  const uint8_t* wp = p.bt + (int64_t)n_row * p.ldb + g * 16;
+  const uint8_t* wp[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int n_row = min(n0 + j * 16 + r, p.N - 1);
+    wp[j] = p.bt + (int64_t)n_row * p.ldb + g * 16;
+  }
   const uint8_t* ap[MT];
   bool a_ok[MT];
 #pragma unroll
@@ -79,90 +86,105 @@ __global__ __launch_bounds__(MM_THREADS) void scaled_mm_kernel(const MMParams p)
     a_ok[t] = m < p.M;
     ap[t] = p.a + (int64_t)min(m, p.M - 1) * p.lda + g * 16;
   }
-  typename A::type acc[MT];
+  typename A::type acc[NT][MT];
 #pragma unroll
-  for (int t = 0; t < MT; ++t) acc[t] = A::zero();
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int t = 0; t < MT; ++t) acc[j][t] = A::zero();
 
-  for (int ks = ks0; ks < ks1; ks += MM_UNROLL) {
-    uint4 w[MM_UNROLL], x[MM_UNROLL][MT];
+  for (int ks = ks0; ks < ks1; ks += UN) {
+    uint4 w[UN][NT], x[UN][MT];
 #pragma unroll
-    for (int u = 0; u < MM_UNROLL; ++u) {
+    for (int u = 0; u < UN; ++u) {
       const int k = (ks + u) * 64 + g * 16;
       const bool ok = (ks + u) < ks1 && k < p.K;  // K % 16 == 0: a 16-byte chunk is all-or-nothing
-      w[u] = ok ? ld16(wp + (int64_t)(ks + u) * 64) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+        w[u][j] = ok ? ld16(wp[j] + (int64_t)(ks + u) * 64) : make_uint4(0, 0, 0, 0);
 #pragma unroll
       for (int t = 0; t < MT; ++t)
         x[u][t] = (ok && a_ok[t]) ? ld16(ap[t] + (int64_t)(ks + u) * 64) : make_uint4(0, 0, 0, 0);
     }
 #pragma unroll
-    for (int u = 0; u < MM_UNROLL; ++u)
+    for (int u = 0; u < UN; ++u)
 #pragma unroll
-      for (int t = 0; t < MT; ++t) acc[t] = A::mma(w[u], x[u][t], acc[t]);
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int t = 0; t < MT; ++t) acc[j][t] = A::mma(w[u][j], x[u][t], acc[j][t]);
   }
 
   // cross-wave K reduction in the accumulator's own type (int32 stays exact)
-  using elem_t = decltype(acc[0][0] + acc[0][0]);
-  elem_t (*redt)[MT][4][64] = reinterpret_cast<elem_t (*)[MT][4][64]>(red);
+  using elem_t = decltype(acc[0][0][0] + acc[0][0][0]);
+  elem_t (*redt)[NT][MT][4][64] = reinterpret_cast<elem_t (*)[NT][MT][4][64]>(red);
   if (wave > 0) {
 #pragma unroll
-    for (int t = 0; t < MT; ++t)
+    for (int j = 0; j < NT; ++j)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) redt[wave - 1][t][i][lane] = acc[t][i];
+      for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) redt[wave - 1][j][t][i][lane] = acc[j][t][i];
   }
   __syncthreads();
   if (wave != 0) return;
-  float facc[MT][4];
+
+  // epilogue: D[row = n_idx][col = m]; lane (m = l&15, g) holds n = n0 + 16 j + 4g + i
 #pragma unroll
-  for (int t = 0; t < MT; ++t)
+  for (int j = 0; j < NT; ++j) {
+    const int nb = n0 + j * 16 + 4 * g;
+    if (nb >= p.N) continue;
+    float bs[4], bv[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      elem_t v = acc[t][i];
-#pragma unroll
-      for (int ww = 0; ww < 3; ++ww) v += redt[ww][t][i][lane];
-      facc[t][i] = (float)v;
+      const int n = min(nb + i, p.N - 1);
+      bs[i] = p.b_scales[p.b_per_col ? n : 0];
+      bv[i] = p.bias ? T::to_float(reinterpret_cast<const uint16_t*>(p.bias)[n]) : 0.f;
     }
-
-  // epilogue: D[row = n_idx][col = m]; lane (m = l&15, g) holds n = n0 + 4g + i
-  const int nb = n0 + 4 * g;
-  if (nb >= p.N) return;
-  float bs[4], bv[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int n = min(nb + i, p.N - 1);
-    bs[i] = p.b_scales[p.b_per_col ? n : 0];
-    bv[i] = p.bias ? T::to_float(reinterpret_cast<const uint16_t*>(p.bias)[n]) : 0.f;
-  }
+    for (int t = 0; t < MT; ++t) {
+      const int m = m0 + t * 16 + r;
+      if (m >= p.M) continue;
+      const float as = p.a_scales[p.a_per_row ? m : 0];
+      float o[4];
 #pragma unroll
-  for (int t = 0; t < MT; ++t) {
-    const int m = m0 + t * 16 + r;
-    if (m >= p.M) continue;
-    const float as = p.a_scales[p.a_per_row ? m : 0];
-    float o[4];
+      for (int i = 0; i < 4; ++i) {
+        elem_t v = acc[j][t][i];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) o[i] = fmaf(as, bs[i] * facc[t][i], bv[i]);
-    uint16_t* dst = reinterpret_cast<uint16_t*>(p.out) + (int64_t)m * p.ldc + nb;
-    if (nb + 3 < p.N && (reinterpret_cast<uintptr_t>(dst) & 7) == 0) {
-      uint2 pk;
-      pk.x = T::pack2(o[0], o[1]);
-      pk.y = T::pack2(o[2], o[3]);
-      *reinterpret_cast<uint2*>(dst) = pk;
-    } else {
+        for (int ww = 0; ww < 3; ++ww) v += redt[ww][j][t][i][lane];
+        o[i] = fmaf(as, bs[i] * (float)v, bv[i]);
+      }
+      uint16_t* dst = reinterpret_cast<uint16_t*>(p.out) + (int64_t)m * p.ldc + nb;
+      if (nb + 3 < p.N && (reinterpret_cast<uintptr_t>(dst) & 7) == 0) {
+        uint2 pk;
+        pk.x = T::pack2(o[0], o[1]);
+        pk.y = T::pack2(o[2], o[3]);
+        *reinterpret_cast<uint2*>(dst) = pk;
+      } else {
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-        if (nb + i < p.N) dst[i] = T::from_float(o[i]);
+        for (int i = 0; i < 4; ++i)
+          if (nb + i < p.N) dst[i] = T::from_float(o[i]);
+      }
     }
   }
 }
 
 template <typename T, bool FP8>
 static void launch_mm(const MMParams& p, hipStream_t s) {
-  const int nblk = (p.N + 15) / 16;
-#define MM_CASE(MT_)                                                                           \
-  {                                                                                            \
-    dim3 grid(nblk, (p.M + 16 * MT_ - 1) / (16 * MT_));                                        \
-    hipLaunchKernelGGL((scaled_mm_kernel<T, FP8, MT_>), grid, dim3(MM_THREADS), 0, s, p);      \
+#define MM_CASE(MT_, NT_, UN_)                                                                       \
+  {                                                                                                  \
+    dim3 grid((p.N + 16 * NT_ - 1) / (16 * NT_), (p.M + 16 * MT_ - 1) / (16 * MT_));                 \
+    hipLaunchKernelGGL((scaled_mm_kernel<T, FP8, MT_, NT_, UN_>), grid, dim3(MM_THREADS), 0, s, p);  \
   }
-  if (p.M <= 16) MM_CASE(1) else if (p.M <= 32) MM_CASE(2) else MM_CASE(4)
+  // wide enough to keep >= ~256 workgroups: more columns per wave (activation reuse)
+  const int n16 = (p.N + 15) / 16;
+  // measured on the Llama-3-8B shapes: one column tile per wave is best at M <= 16 (weight
+  // streaming, 4.9 TB/s on gate_up), reuse pays from M = 32 on the wide projections
+  if (p.M <= 16) {
+    MM_CASE(1, 1, 4)
+  } else if (p.M <= 32) {
+    if (n16 >= 1024) MM_CASE(2, 2, 4) else MM_CASE(2, 1, 4)
+  } else {
+    if (n16 >= 1024) MM_CASE(4, 4, 2) else if (n16 >= 384) MM_CASE(4, 2, 2) else MM_CASE(4, 1, 4)
+  }
 #undef MM_CASE
 }
 
