@@ -198,7 +198,12 @@ int nmv_fp8_marlin_gemm(void* c, const void* a, const int32_t* b_q_weight, const
 int nmv_gptq_gemm(void* c, const void* a, const int32_t* b_q_weight, const int32_t* b_gptq_qzeros,
                   const void* b_gptq_scales, const int32_t* b_g_idx, int use_exllama, int bit,
                   int size_m, int size_n, int size_k, int num_groups, nmv_dtype_t dtype,
-                  void* stream);
+                  void* scratch, int64_t scratch_bytes, void* stream);
+
+/* fp32 split-K slabs of gptq_gemm / awq_gemm (4-bit, no act-order: the streaming kernel); the
+ * reference allocates its own [split_k, M, N] partials per call (gemm_kernels.cu:520-523).
+ * 0 when no scratch is needed. */
+int64_t nmv_wq_gemm_scratch_bytes(int size_m, int size_n, int size_k);
 
 /* gptq_shuffle  (q_gemm.cu:1848-1856): in place; q_perm NULL = no act-order.  tmp: scratch of
  * the size of q_weight (needed only with q_perm). */
@@ -209,7 +214,7 @@ int nmv_gptq_shuffle(int32_t* q_weight, const int32_t* q_perm, int32_t* tmp, int
  * qweight int32 [K, N/8], qzeros int32 [G, N/8], scales [G, N]. */
 int nmv_awq_gemm(void* c, const void* a, const int32_t* qweight, const void* scales,
                  const int32_t* qzeros, int size_m, int size_n, int size_k, int num_groups,
-                 nmv_dtype_t dtype, void* stream);
+                 nmv_dtype_t dtype, void* scratch, int64_t scratch_bytes, void* stream);
 
 /* awq_dequantize  (gemm_kernels.cu:436-490): out [K, N] */
 int nmv_awq_dequantize(void* out, const int32_t* qweight, const void* scales, const int32_t* qzeros,

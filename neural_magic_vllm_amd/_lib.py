@@ -61,9 +61,10 @@ SIGNATURES = {
                                   _I, _P]),
     "nmv_marlin_gemm": (_I, [_P, _P, _P, _P, _P, _L, _P, _L, _I, _I, _I, _I, _I, _P]),
     "nmv_fp8_marlin_gemm": (_I, [_P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _P]),
-    "nmv_gptq_gemm": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "nmv_gptq_gemm": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _L, _P]),
+    "nmv_wq_gemm_scratch_bytes": (_L, [_I, _I, _I]),
     "nmv_gptq_shuffle": (_I, [_P, _P, _P, _I, _I, _I, _P]),
-    "nmv_awq_gemm": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "nmv_awq_gemm": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _L, _P]),
     "nmv_awq_dequantize": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "nmv_scaled_int8_quant": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "nmv_scaled_fp8_quant": (_I, [_P, _P, _P, _L, _I, _I, _P]),

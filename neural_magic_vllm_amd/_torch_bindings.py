@@ -298,11 +298,15 @@ def gptq_gemm(a, b_q_weight, b_gptq_qzeros, b_gptq_scales, b_g_idx, use_exllama,
     if has_idx:
         _req(b_g_idx.numel() == size_k and b_g_idx.dtype == torch.int32, "g_idx must be int32 [K]")
     c = torch.empty((size_m, size_n), dtype=a.dtype, device=a.device)
+    lib = _lib.load()
+    nbytes = int(lib.nmv_wq_gemm_scratch_bytes(size_m, size_n, size_k))
+    scratch = torch.empty((nbytes, ), dtype=torch.uint8, device=a.device) if nbytes else None
     with device_guard(a):
-        check(_lib.load().nmv_gptq_gemm(ptr(c), ptr(a), ptr(b_q_weight), ptr(b_gptq_qzeros),
-                                        ptr(b_gptq_scales), ptr(b_g_idx) if has_idx else None,
-                                        int(use_exllama), bit, size_m, size_n, size_k,
-                                        b_gptq_scales.shape[0], dtype_code(a.dtype), stream_of(a)))
+        check(lib.nmv_gptq_gemm(ptr(c), ptr(a), ptr(b_q_weight), ptr(b_gptq_qzeros),
+                                ptr(b_gptq_scales), ptr(b_g_idx) if has_idx else None,
+                                int(use_exllama), bit, size_m, size_n, size_k,
+                                b_gptq_scales.shape[0], dtype_code(a.dtype),
+                                ptr(scratch) if nbytes else None, nbytes, stream_of(a)))
     return c
 
 
@@ -332,11 +336,14 @@ def awq_gemm(input, kernel, scaling_factors, zeros, split_k_iters) -> torch.Tens
          and zeros.is_contiguous(), "awq_gemm: tensors must be contiguous")
     _req(scaling_factors.dtype == input.dtype, "scales must have the activation dtype")
     c = torch.empty((size_m, size_n), dtype=input.dtype, device=input.device)
+    lib = _lib.load()
+    nbytes = int(lib.nmv_wq_gemm_scratch_bytes(size_m, size_n, size_k))
+    scratch = torch.empty((nbytes, ), dtype=torch.uint8, device=input.device) if nbytes else None
     with device_guard(input):
-        check(_lib.load().nmv_awq_gemm(ptr(c), ptr(input), ptr(kernel), ptr(scaling_factors),
-                                       ptr(zeros), size_m, size_n, size_k,
-                                       scaling_factors.shape[0], dtype_code(input.dtype),
-                                       stream_of(input)))
+        check(lib.nmv_awq_gemm(ptr(c), ptr(input), ptr(kernel), ptr(scaling_factors),
+                               ptr(zeros), size_m, size_n, size_k,
+                               scaling_factors.shape[0], dtype_code(input.dtype),
+                               ptr(scratch) if nbytes else None, nbytes, stream_of(input)))
     return c
 
 

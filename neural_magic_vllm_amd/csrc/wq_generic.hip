@@ -14,6 +14,8 @@
 // accumulation, one rounding of the result -- the reference's reconstruct-then-GEMM numerics
 // (q_gemm.cu:1496-1499, awq.py:166-170).  Correctness-first path: bounded by the LDS round trip,
 // not tuned to the HBM roofline like the Marlin kernel; DESIGN.md section 3.5.
+#include <algorithm>
+
 #include "common.h"
 
 namespace nmv {
@@ -186,6 +188,166 @@ __global__ __launch_bounds__(256) void wq_gemm_kernel(const WqParams p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Streaming kernel for the two checkpoint layouts that matter in practice: 4-bit GPTQ without
+// act-order (exllama layout: int32 [K/8, N], 8 consecutive k of one column per word) and AWQ
+// (int32 [K, N/8], 8 columns of one k per word, nibble order {0,4,1,5,2,6,3,7}).
+// Same numerics as wq_gemm_kernel (w = (q - z) * s rounded to the model dtype, fp32 accumulate),
+// but the packed words are streamed ONCE with 16-byte coalesced loads into a raw LDS image
+// (double-buffered, 128 k x 64 columns = 4 KiB per stage), each lane then pulls the 8 codes of
+// its MFMA operand out of LDS (GPTQ: one word; AWQ: one nibble of 8 words, a broadcast read),
+// scales / zero points are fetched once per 32-k step, activations come straight from global
+// memory in natural k order, and K is split over workgroups (fp32 slabs summed in split order by
+// wq_reduce_kernel: deterministic).  ~40x the throughput of the element-wise kernel above.
+constexpr int WS_K = 128;  // k per stage
+
+template <typename T, int FMT, int MT>
+__global__ __launch_bounds__(256) void wq_stream_kernel(const WqParams p, float* __restrict__ slab,
+                                                        int k_per_wg) {
+  static_assert(FMT == WQ_GPTQ || FMT == WQ_AWQ, "4-bit GPTQ / AWQ only");
+  __shared__ __attribute__((aligned(16))) uint32_t raw[2][1024];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r = lane & 15, g = lane >> 4;
+  const int n0 = blockIdx.x * 64;
+  const int m0 = blockIdx.z * (16 * MT);
+  const int kb = blockIdx.y * k_per_wg;
+  const int ke = min(kb + k_per_wg, p.K);
+  const int n_stages = (ke - kb) / WS_K;
+  const int col = wave * 16 + r;       // column of this lane inside the 64-column tile
+  const int n = n0 + col;              // N % 64 == 0: always in range
+
+  // ---- raw stage loader: one 16-byte piece per thread ----
+  const uint32_t* src;
+  int64_t src_stage_stride;
+  int lds_idx;
+  if constexpr (FMT == WQ_GPTQ) {
+    src = p.qweight + (int64_t)(kb / 8 + (threadIdx.x >> 4)) * p.N + n0 + (threadIdx.x & 15) * 4;
+    src_stage_stride = (int64_t)(WS_K / 8) * p.N;
+    lds_idx = (threadIdx.x >> 4) * 64 + (threadIdx.x & 15) * 4;     // [16 word rows][64 columns]
+  } else {
+    src = p.qweight + (int64_t)(kb + (threadIdx.x >> 1)) * (p.N / 8) + n0 / 8 + (threadIdx.x & 1) * 4;
+    src_stage_stride = (int64_t)WS_K * (p.N / 8);
+    lds_idx = (threadIdx.x >> 1) * 8 + (threadIdx.x & 1) * 4;       // [128 k rows][8 words]
+  }
+  const int awq_shift = 4 * (((col & 1) << 2) | ((col & 7) >> 1));  // nibble of this column
+  const uint16_t* a_row[MT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t)
+    a_row[t] = p.a + (int64_t)min(m0 + t * 16 + r, p.M - 1) * p.K + kb + g * 8;
+
+  f32x4_t acc[MT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  uint4 nxt = make_uint4(0, 0, 0, 0);
+  if (n_stages > 0) {
+    const uint4 first = *reinterpret_cast<const uint4*>(src);
+    *reinterpret_cast<uint4*>(&raw[0][lds_idx]) = first;
+  }
+  __syncthreads();
+  for (int st = 0; st < n_stages; ++st) {
+    const int buf = st & 1;
+    const int k0 = kb + st * WS_K;
+    if (st + 1 < n_stages) nxt = *reinterpret_cast<const uint4*>(src + (st + 1) * src_stage_stride);
+    // scales, zero points and activation fragments of the 4 k-steps: all loads issued up front
+    float sc[4], zp[4];
+    uint4 af[4][MT];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int grp = (k0 + ks * 32 + g * 8) / p.group_size;
+      sc[ks] = T::to_float(p.scales[(int64_t)grp * p.N + n]);
+      zp[ks] = wq_zero<FMT>(p, grp, n);
+#pragma unroll
+      for (int t = 0; t < MT; ++t) af[ks][t] = ld16(a_row[t] + st * WS_K + ks * 32);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      uint32_t q[8];
+      if constexpr (FMT == WQ_GPTQ) {
+        const uint32_t x = raw[buf][(ks * 4 + g) * 64 + col];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) q[i] = (x >> (4 * i)) & 0xf;
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) q[i] = (raw[buf][(ks * 32 + g * 8 + i) * 8 + (col >> 3)] >> awq_shift) & 0xf;
+      }
+      uint32_t pk[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        pk[e] = T::pack2(((float)q[2 * e] - zp[ks]) * sc[ks], ((float)q[2 * e + 1] - zp[ks]) * sc[ks]);
+      const uint4 wf = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+#pragma unroll
+      for (int t = 0; t < MT; ++t) acc[t] = Mfma16<T>::run(wf, af[ks][t], acc[t]);
+    }
+    if (st + 1 < n_stages) *reinterpret_cast<uint4*>(&raw[buf ^ 1][lds_idx]) = nxt;
+    __syncthreads();
+  }
+  // D[row = column index][col = m]: lane (m = r, g) holds columns n0 + 16 wave + 4 g + i
+  const int nb = n0 + wave * 16 + 4 * g;
+#pragma unroll
+  for (int t = 0; t < MT; ++t) {
+    const int m = m0 + t * 16 + r;
+    if (m >= p.M) continue;
+    if (gridDim.y == 1) {
+      uint2 pk;
+      pk.x = T::pack2(acc[t][0], acc[t][1]);
+      pk.y = T::pack2(acc[t][2], acc[t][3]);
+      *reinterpret_cast<uint2*>(p.c + (int64_t)m * p.N + nb) = pk;
+    } else {
+      *reinterpret_cast<f32x4_t*>(slab + ((int64_t)blockIdx.y * p.M + m) * p.N + nb) = acc[t];
+    }
+  }
+}
+
+// out[m][n] = sum over splits (ascending) of slab[split][m][n], rounded once
+template <typename T>
+__global__ void wq_reduce_kernel(const float* __restrict__ slab, uint16_t* __restrict__ out,
+                                 int64_t mn, int splits) {
+  const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i >= mn) return;
+  f32x4_t s = *reinterpret_cast<const f32x4_t*>(slab + i);
+  for (int k = 1; k < splits; ++k) s += *reinterpret_cast<const f32x4_t*>(slab + (int64_t)k * mn + i);
+  uint2 pk;
+  pk.x = T::pack2(s[0], s[1]);
+  pk.y = T::pack2(s[2], s[3]);
+  *reinterpret_cast<uint2*>(out + i) = pk;
+}
+
+struct WqStreamPlan { int mt, splits, k_per_wg; };
+static WqStreamPlan wq_stream_plan(int M, int N, int K) {
+  WqStreamPlan pl;
+  pl.mt = M <= 16 ? 1 : (M <= 32 ? 2 : 4);
+  const int base = (N / 64) * ((M + 16 * pl.mt - 1) / (16 * pl.mt));
+  const int k_units = K / WS_K;
+  int splits = std::max(1, std::min(512 / std::max(base, 1), 16));
+  splits = std::min(splits, std::max(1, k_units / 2));
+  pl.k_per_wg = ((k_units + splits - 1) / splits) * WS_K;
+  pl.splits = (K + pl.k_per_wg - 1) / pl.k_per_wg;
+  return pl;
+}
+// the streaming kernel's domain: 4 bits, no act-order, whole stages and tiles
+static bool wq_stream_ok(const WqParams& p) {
+  return p.bits == 4 && p.g_idx == nullptr && p.perm == nullptr && p.K % WS_K == 0 && p.N % 64 == 0 &&
+         p.group_size % 32 == 0 && p.group_size > 0;
+}
+
+template <typename T, int FMT>
+static int launch_wq_stream(const WqParams& p, float* slab, int64_t slab_bytes, hipStream_t s) {
+  const WqStreamPlan pl = wq_stream_plan(p.M, p.N, p.K);
+  if (pl.splits > 1 && (slab == nullptr || slab_bytes < (int64_t)pl.splits * p.M * p.N * 4)) return -2;
+  dim3 grid(p.N / 64, pl.splits, (p.M + 16 * pl.mt - 1) / (16 * pl.mt));
+  if (pl.mt == 1) hipLaunchKernelGGL((wq_stream_kernel<T, FMT, 1>), grid, dim3(256), 0, s, p, slab, pl.k_per_wg);
+  else if (pl.mt == 2) hipLaunchKernelGGL((wq_stream_kernel<T, FMT, 2>), grid, dim3(256), 0, s, p, slab, pl.k_per_wg);
+  else hipLaunchKernelGGL((wq_stream_kernel<T, FMT, 4>), grid, dim3(256), 0, s, p, slab, pl.k_per_wg);
+  if (pl.splits > 1) {
+    const int64_t mn = (int64_t)p.M * p.N;
+    hipLaunchKernelGGL((wq_reduce_kernel<T>), dim3((unsigned)cdiv64(mn / 4, 256)), dim3(256), 0, s,
+                       slab, p.c, mn, pl.splits);
+  }
+  return 0;
+}
+
 // [K, N] dense reconstruction (awq_dequantize; also a debugging aid for the other formats)
 template <typename T, int FMT>
 __global__ void wq_dequant_kernel(const WqParams p, uint16_t* __restrict__ out) {
@@ -252,11 +414,17 @@ int wq_marlin_fallback(void* c, const void* a, const int32_t* b_q_weight, const 
 
 using namespace nmv;
 
+extern "C" int64_t nmv_wq_gemm_scratch_bytes(int size_m, int size_n, int size_k) {
+  if (size_m <= 0 || size_n <= 0 || size_k <= 0 || size_k % WS_K != 0 || size_n % 64 != 0) return 0;
+  const WqStreamPlan pl = wq_stream_plan(size_m, size_n, size_k);
+  return pl.splits > 1 ? (int64_t)pl.splits * size_m * size_n * 4 : 0;
+}
+
 extern "C" int nmv_gptq_gemm(void* c, const void* a, const int32_t* b_q_weight,
                              const int32_t* b_gptq_qzeros, const void* b_gptq_scales,
                              const int32_t* b_g_idx, int use_exllama, int bit, int size_m,
                              int size_n, int size_k, int num_groups, nmv_dtype_t dtype,
-                             void* stream) {
+                             void* scratch, int64_t scratch_bytes, void* stream) {
   NMV_CHECK(dtype == NMV_F16 || dtype == NMV_BF16, "gptq_gemm: unsupported dtype %d", (int)dtype);
   NMV_CHECK(bit == 2 || bit == 4 || bit == 8, "gptq_gemm: %d-bit weights are not supported on gfx950 (2, 4, 8 are)", bit);
   NMV_CHECK(size_k % 32 == 0 && num_groups >= 1 && size_k % num_groups == 0, "gptq_gemm: bad K / groups");
@@ -268,8 +436,16 @@ extern "C" int nmv_gptq_gemm(void* c, const void* a, const int32_t* b_q_weight,
              (const uint16_t*)b_gptq_scales, use_exllama ? nullptr : b_g_idx,
              use_exllama ? b_g_idx : nullptr, (uint16_t*)c, size_m, size_n, size_k, bit,
              size_k / num_groups, num_groups};
-  const int rc = dtype == NMV_F16 ? launch_wq_fmt<F16>(WQ_GPTQ, p, (hipStream_t)stream)
-                                  : launch_wq_fmt<BF16>(WQ_GPTQ, p, (hipStream_t)stream);
+  int rc;
+  if (wq_stream_ok(p)) {
+    rc = dtype == NMV_F16
+             ? launch_wq_stream<F16, WQ_GPTQ>(p, (float*)scratch, scratch_bytes, (hipStream_t)stream)
+             : launch_wq_stream<BF16, WQ_GPTQ>(p, (float*)scratch, scratch_bytes, (hipStream_t)stream);
+    NMV_CHECK(rc != -2, "gptq_gemm: scratch too small (see nmv_wq_gemm_scratch_bytes)");
+  } else {
+    rc = dtype == NMV_F16 ? launch_wq_fmt<F16>(WQ_GPTQ, p, (hipStream_t)stream)
+                          : launch_wq_fmt<BF16>(WQ_GPTQ, p, (hipStream_t)stream);
+  }
   NMV_CHECK(rc == 0, "gptq_gemm: launch failed");
   NMV_LAUNCH_CHECK();
   return NMV_OK;
@@ -294,7 +470,8 @@ extern "C" int nmv_gptq_shuffle(int32_t* q_weight, const int32_t* q_perm, int32_
 
 extern "C" int nmv_awq_gemm(void* c, const void* a, const int32_t* qweight, const void* scales,
                             const int32_t* qzeros, int size_m, int size_n, int size_k,
-                            int num_groups, nmv_dtype_t dtype, void* stream) {
+                            int num_groups, nmv_dtype_t dtype, void* scratch,
+                            int64_t scratch_bytes, void* stream) {
   NMV_CHECK(dtype == NMV_F16 || dtype == NMV_BF16, "awq_gemm: unsupported dtype %d", (int)dtype);
   NMV_CHECK(size_n % 8 == 0 && size_k % 32 == 0 && num_groups >= 1 && size_k % num_groups == 0,
             "awq_gemm: bad shape (N %% 8, K %% 32, K %% groups)");
@@ -302,8 +479,16 @@ extern "C" int nmv_awq_gemm(void* c, const void* a, const int32_t* qweight, cons
   WqParams p{(const uint16_t*)a, (const uint32_t*)qweight, (const uint32_t*)qzeros,
              (const uint16_t*)scales, nullptr, nullptr, (uint16_t*)c, size_m, size_n, size_k, 4,
              size_k / num_groups, num_groups};
-  const int rc = dtype == NMV_F16 ? launch_wq_fmt<F16>(WQ_AWQ, p, (hipStream_t)stream)
-                                  : launch_wq_fmt<BF16>(WQ_AWQ, p, (hipStream_t)stream);
+  int rc;
+  if (wq_stream_ok(p)) {
+    rc = dtype == NMV_F16
+             ? launch_wq_stream<F16, WQ_AWQ>(p, (float*)scratch, scratch_bytes, (hipStream_t)stream)
+             : launch_wq_stream<BF16, WQ_AWQ>(p, (float*)scratch, scratch_bytes, (hipStream_t)stream);
+    NMV_CHECK(rc != -2, "awq_gemm: scratch too small (see nmv_wq_gemm_scratch_bytes)");
+  } else {
+    rc = dtype == NMV_F16 ? launch_wq_fmt<F16>(WQ_AWQ, p, (hipStream_t)stream)
+                          : launch_wq_fmt<BF16>(WQ_AWQ, p, (hipStream_t)stream);
+  }
   NMV_CHECK(rc == 0, "awq_gemm: launch failed");
   NMV_LAUNCH_CHECK();
   return NMV_OK;

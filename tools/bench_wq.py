@@ -1,0 +1,69 @@
+"""hipGraph-timed microbenchmark of the generic weight-only formats (csrc/wq_generic.hip): GPTQ
+(exllama layout), AWQ and 8-bit Marlin, random codes, group 128.
+usage: python tools/bench_wq.py [--ms 1,64] [--shapes gate_up,o]"""
+import argparse
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from neural_magic_vllm_amd import _custom_ops as ops  # noqa: E402
+
+SHAPES = {"qkv": (4096, 6144), "o": (4096, 4096), "gate_up": (4096, 28672), "down": (14336, 4096)}
+
+
+def timed(fn, iters=20):
+    fn(0)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        fn(0)
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for i in range(iters):
+            fn(i)
+    g.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--ms", default="1,64")
+    ap.add_argument("--shapes", default="o,gate_up")
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    gs = 128
+    gen = torch.Generator(device=dev).manual_seed(0)
+
+    def ri(shape):
+        return torch.randint(-2**31, 2**31 - 1, shape, dtype=torch.int32, device=dev, generator=gen)
+
+    for name in args.shapes.split(","):
+        k, n = SHAPES[name]
+        ncopy = max(2, (600 << 20) // (k * n // 2))
+        sc = (torch.rand((k // gs, n), device=dev, generator=gen) * 0.01).half()
+        g_idx = (torch.arange(k, device=dev) // gs).to(torch.int32)
+        gq = [ri((k // 8, n)) for _ in range(ncopy)]
+        gz = ri((k // gs, n // 8))
+        aq = [ri((k, n // 8)) for _ in range(ncopy)]
+        m8 = [ri((k // 16, n * 4)) for _ in range(max(2, ncopy // 2))]
+        wsp = torch.zeros(n // 64 * 16, dtype=torch.int32, device=dev)
+        e = torch.empty(0, dtype=torch.int32, device=dev)
+        for m in [int(x) for x in args.ms.split(",")]:
+            a = torch.randn((m, k), device=dev, dtype=torch.half)
+            t_gptq = timed(lambda i: ops.gptq_gemm(a, gq[i % ncopy], gz, sc, e, True, 4))
+            t_awq = timed(lambda i: ops.awq_gemm(a, aq[i % ncopy], sc, gz, 8))
+            t_m8 = timed(lambda i: ops.gptq_marlin_gemm(a, m8[i % len(m8)], sc, e, e, wsp, 8, m, n, k, True))
+            b4, b8 = k * n // 2, k * n
+            print(f"{name:8s} M={m:3d}  gptq4 {t_gptq:8.1f} us {b4 / t_gptq / 1e3:6.0f} GB/s   awq4 {t_awq:8.1f} us "
+                  f"{b4 / t_awq / 1e3:6.0f} GB/s   marlin8 {t_m8:8.1f} us {b8 / t_m8 / 1e3:6.0f} GB/s", flush=True)
