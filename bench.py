@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sweep", action="store_true")
     ap.add_argument("--kv-cache-dtype", default="auto")
+    ap.add_argument("--quant", default="w4a16", choices=["w4a16", "w8a8"],
+                    help="w4a16 = the BASELINE metric (configs[2]); w8a8 = configs[3] (parity/bench case)")
     return ap.parse_args()
 
 
@@ -190,7 +192,8 @@ def main():
         nd.initialize_model_parallel(world, backend="nccl", local_rank=local_rank)
     from neural_magic_vllm_amd.worker import decode_runner as dr
     arch = {"llama3-8b": dr.LLAMA3_8B, "llama3-70b": dr.LLAMA3_70B, "tiny": dr.TINY}[args.model]
-    quant = dict(method="gptq_marlin", bits=4, group_size=128)
+    quant = (dict(method="gptq_marlin", bits=4, group_size=128) if args.quant == "w4a16"
+             else dict(method="w8a8", bits=8, group_size=-1))
     runner = dr.DecodeRunner(arch, dev, torch.bfloat16, quant,
                              dr.CacheConfig(16, args.kv_cache_dtype))
 
@@ -228,23 +231,29 @@ def main():
     value = args.batch * args.steps / dt
 
     out = {
-        "metric": "decode tokens/sec, Llama-3-8B w4a16 (GPTQ-marlin g128), bf16 activations",
+        "metric": ("decode tokens/sec, Llama-3-8B w4a16 (GPTQ-marlin g128), bf16 activations"
+                   if args.quant == "w4a16" else
+                   "decode tokens/sec, Llama-3-8B w8a8 (int8 per-channel x dynamic per-token int8)"),
         "value": round(value, 1), "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-        "scaling": "strong", "vs_baseline": None, "dtype": "bf16",
-        "data": "synthetic (random-init N(0,0.02) weights quantised to int4 g128, random KV context)",
-        "config": {"workload": f"{args.model} w4a16 decode step, batch {args.batch}, "
+        "scaling": "strong", "vs_baseline": None, "dtype": "bf16" if args.quant == "w4a16" else "int8",
+        "data": ("synthetic (random-init N(0,0.02) weights quantised to int4 g128, random KV context)"
+                 if args.quant == "w4a16" else
+                 "synthetic (random-init N(0,0.02) weights quantised to int8 per channel, random KV context)"),
+        "config": {"workload": f"{args.model} {args.quant} decode step, batch {args.batch}, "
                                f"context {args.context} tokens/seq, block 16, kv {args.kv_cache_dtype}",
                    "global_batch": args.batch, "context_len": args.context,
                    "parallelism": f"tp{world}", "hip_graph": graphed},
     }
     if rank == 0:
         wb = runner.weight_bytes_per_step()
-        kvb = 2 * args.context * runner.num_kv_heads * arch.head_dim * 2 * args.batch * arch.num_hidden_layers
+        kv_elem = 1 if args.kv_cache_dtype.startswith("fp8") else 2
+        kvb = 2 * args.context * runner.num_kv_heads * arch.head_dim * kv_elem * args.batch * arch.num_hidden_layers
         out["step_roofline"] = {"weight_bytes": wb, "kv_bytes": kvb,
                                 "hbm_bound_ms": round((wb + kvb) / (HBM_PEAK_GBS * 1e9) * 1e3, 4),
                                 "frac_of_hbm_bound": round((wb + kvb) / (HBM_PEAK_GBS * 1e9) / (ms_per_step * 1e-3), 4)}
-        out["roofline"] = gemm_roofline(runner, args.batch, dev)
+        if args.quant == "w4a16":
+            out["roofline"] = gemm_roofline(runner, args.batch, dev)
     if rank == 0 and world == 1 and not args.no_sweep:
         out["ttft_ms_p50"] = {"prompt_tokens": args.context, "batch": 1,
                               "value": ttft(runner, dev, args.context)}

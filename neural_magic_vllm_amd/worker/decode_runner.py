@@ -99,6 +99,13 @@ def synthetic_llama_weights(arch: LlamaArch, dtype: torch.dtype, device, quant: 
         if quant is None:
             yield prefix + ".weight", w.t().contiguous().to(dtype)
             return
+        if quant.get("method") == "w8a8":
+            # compressed-tensors W8A8: int8 [out, in], per-output-channel fp32 scales, symmetric
+            wt = w.t().contiguous()
+            ws = wt.abs().amax(dim=1, keepdim=True).clamp_min(1e-8) / 127.0
+            yield prefix + ".weight", torch.clamp(torch.round(wt / ws), -127, 127).to(torch.int8)
+            yield prefix + ".weight_scale", ws.to(torch.float32)
+            return
         qw, s, g_idx = gptq_quantize_on_device(w.to(dtype), quant["bits"], quant["group_size"])
         yield prefix + ".qweight", qw
         yield prefix + ".scales", s
@@ -133,7 +140,16 @@ class DecodeRunner:
         self.tp_size = get_tensor_model_parallel_world_size()
         self.tp_rank = get_tensor_model_parallel_rank()
         quant_config = None
-        if quant is not None:
+        if quant is not None and quant.get("method") == "w8a8":
+            # BASELINE.json configs[3]: int8 weights (per channel) x int8 activations (dynamic per token)
+            quant_config = get_quantization_config("compressed-tensors").from_config({
+                "config_groups": {"group_0": {
+                    "targets": ["Linear"],
+                    "weights": dict(num_bits=8, type="int", strategy="channel", symmetric=True, dynamic=False),
+                    "input_activations": dict(num_bits=8, type="int", strategy="token", symmetric=True,
+                                              dynamic=True)}},
+                "ignore": ["lm_head"]})
+        elif quant is not None:
             quant_config = get_quantization_config(quant.get("method", "gptq_marlin")).from_config(
                 dict(bits=quant["bits"], group_size=quant["group_size"],
                      desc_act=quant.get("desc_act", False), sym=True))

@@ -20,8 +20,9 @@ def dequant_gptq(qweight, scales, bits=4):
 
 class RefLlama:
 
-    def __init__(self, arch, weights: Dict[str, torch.Tensor]):
+    def __init__(self, arch, weights: Dict[str, torch.Tensor], act_int8: bool = False):
         self.a = arch
+        self.act_int8 = act_int8
         self.w = {}
         for name, t in weights.items():
             self.w[name] = t
@@ -31,8 +32,15 @@ class RefLlama:
         if prefix not in self.lin:
             if prefix + ".qweight" in self.w:
                 self.lin[prefix] = dequant_gptq(self.w[prefix + ".qweight"], self.w[prefix + ".scales"])
+            elif prefix + ".weight_scale" in self.w:
+                # compressed-tensors W8A8: int8 [out, in] x per-channel fp32 scale (weights exact)
+                self.lin[prefix] = (self.w[prefix + ".weight"].float() * self.w[prefix + ".weight_scale"]).t()
             else:
                 self.lin[prefix] = self.w[prefix + ".weight"].float().t()
+        if self.act_int8 and prefix + ".weight_scale" in self.w:
+            # dynamic per-token int8 activations (int8_quant_kernels.cu:39-75): x ~ round(x/s)*s
+            s = x.abs().amax(dim=-1, keepdim=True).clamp_min(1e-12) / 127.0
+            x = torch.clamp(torch.round(x / s), -128, 127) * s
         return x @ self.lin[prefix]
 
     def rms(self, x, w):

@@ -20,12 +20,15 @@ def build(quant, gpu_device, arch=None):
     return arch, dict(weights), runner
 
 
-@pytest.mark.parametrize("quant", [dict(method="gptq_marlin", bits=4, group_size=128), None],
-                         ids=["w4a16", "bf16"])
+@pytest.mark.parametrize("quant", [dict(method="gptq_marlin", bits=4, group_size=128), None,
+                                   dict(method="w8a8", bits=8, group_size=-1)],
+                         ids=["w4a16", "bf16", "w8a8"])
 @pytest.mark.parametrize("use_graph", [False, True], ids=["eager", "hipgraph"])
 def test_tiny_llama_prefill_then_decode(gpu_device, quant, use_graph):
     arch, weights, runner = build(quant, gpu_device)
-    ref = RefLlama(arch, weights)
+    # W8A8 (BASELINE.json configs[3]): the reference applies the same dynamic per-token int8
+    # rounding to the activations, weights are exact int8 x fp32 scale
+    ref = RefLlama(arch, weights, act_int8=bool(quant) and quant.get("method") == "w8a8")
     batch, prompt_len, new_tokens = 3, 37, 6
     runner.setup_batch(batch, prompt_len, new_tokens + 4)
     g = torch.Generator().manual_seed(0)
