@@ -42,8 +42,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sweep", action="store_true")
     ap.add_argument("--kv-cache-dtype", default="auto")
-    ap.add_argument("--quant", default="w4a16", choices=["w4a16", "w8a8"],
-                    help="w4a16 = the BASELINE metric (configs[2]); w8a8 = configs[3] (parity/bench case)")
+    ap.add_argument("--quant", default="w4a16", choices=["w4a16", "w8a8", "bf16"],
+                    help="w4a16 = the BASELINE metric (configs[2]); w8a8 = configs[3]; bf16 = configs[1] "
+                         "(unquantised: library GEMMs + our attention / cache / glue kernels)")
     return ap.parse_args()
 
 
@@ -192,8 +193,8 @@ def main():
         nd.initialize_model_parallel(world, backend="nccl", local_rank=local_rank)
     from neural_magic_vllm_amd.worker import decode_runner as dr
     arch = {"llama3-8b": dr.LLAMA3_8B, "llama3-70b": dr.LLAMA3_70B, "tiny": dr.TINY}[args.model]
-    quant = (dict(method="gptq_marlin", bits=4, group_size=128) if args.quant == "w4a16"
-             else dict(method="w8a8", bits=8, group_size=-1))
+    quant = {"w4a16": dict(method="gptq_marlin", bits=4, group_size=128),
+             "w8a8": dict(method="w8a8", bits=8, group_size=-1), "bf16": None}[args.quant]
     runner = dr.DecodeRunner(arch, dev, torch.bfloat16, quant,
                              dr.CacheConfig(16, args.kv_cache_dtype))
 
@@ -231,15 +232,15 @@ def main():
     value = args.batch * args.steps / dt
 
     out = {
-        "metric": ("decode tokens/sec, Llama-3-8B w4a16 (GPTQ-marlin g128), bf16 activations"
-                   if args.quant == "w4a16" else
-                   "decode tokens/sec, Llama-3-8B w8a8 (int8 per-channel x dynamic per-token int8)"),
+        "metric": {"w4a16": "decode tokens/sec, Llama-3-8B w4a16 (GPTQ-marlin g128), bf16 activations",
+                   "w8a8": "decode tokens/sec, Llama-3-8B w8a8 (int8 per-channel x dynamic per-token int8)",
+                   "bf16": "decode tokens/sec, Llama-3-8B bf16 (unquantised)"}[args.quant],
         "value": round(value, 1), "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-        "scaling": "strong", "vs_baseline": None, "dtype": "bf16" if args.quant == "w4a16" else "int8",
-        "data": ("synthetic (random-init N(0,0.02) weights quantised to int4 g128, random KV context)"
-                 if args.quant == "w4a16" else
-                 "synthetic (random-init N(0,0.02) weights quantised to int8 per channel, random KV context)"),
+        "scaling": "strong", "vs_baseline": None, "dtype": "int8" if args.quant == "w8a8" else "bf16",
+        "data": {"w4a16": "synthetic (random-init N(0,0.02) weights quantised to int4 g128, random KV context)",
+                 "w8a8": "synthetic (random-init N(0,0.02) weights quantised to int8 per channel, random KV context)",
+                 "bf16": "synthetic (random-init N(0,0.02) bf16 weights, random KV context)"}[args.quant],
         "config": {"workload": f"{args.model} {args.quant} decode step, batch {args.batch}, "
                                f"context {args.context} tokens/seq, block 16, kv {args.kv_cache_dtype}",
                    "global_batch": args.batch, "context_len": args.context,
