@@ -221,6 +221,19 @@ int nmv_awq_dequantize(void* out, const int32_t* qweight, const void* scales, co
                        int size_n, int size_k, int num_groups, nmv_dtype_t dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Prompt (prefill) attention: varlen causal GQA flash-attention forward.
+ * (reference: the prompt branch of vllm/attention/backends/rocm_flash_attn.py:349-430, which
+ *  dispatches to Triton / CK flash-attention or torch SDPA; no C++ symbol exists there.)
+ * q [tokens, H, D], k / v [tokens, KVH, D], out [tokens, H, D]: token strides in elements (q, k, v
+ * may be slices of the fused qkv GEMM output); cu_seqlens int32 [num_seqs + 1] on the device.
+ * ---------------------------------------------------------------------------------------- */
+int nmv_prefill_attention_supported(int head_size);
+int nmv_prefill_attention(void* out, const void* q, const void* k, const void* v,
+                          const int32_t* cu_seqlens, int num_seqs, int max_seq_len, int num_heads,
+                          int num_kv_heads, int head_size, float scale, int64_t q_stride,
+                          int64_t kv_stride, int64_t o_stride, nmv_dtype_t dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * W8A8: activation quantisers and the scaled matmul
  * (csrc/ops.h:101-114,126-130; csrc/quantization/compressed_tensors/int8_quant_kernels.cu,
  *  csrc/quantization/fp8/common.cu, csrc/quantization/cutlass_w8a8/scaled_mm_entry.cu)

@@ -266,3 +266,16 @@ def get_device_attribute(attribute: int, device: int) -> int:
 
 def get_max_shared_memory_per_block_device_attribute(device: int) -> int:
     return torch.ops._C_cuda_utils.get_max_shared_memory_per_block_device_attribute(device)
+
+
+# prompt attention: not an op of the reference's _C library (it calls flash-attn / Triton / SDPA
+# from Python, rocm_flash_attn.py:349-430); exposed here for the attention backend
+def prefill_attention(out: torch.Tensor, query: torch.Tensor, key: torch.Tensor, value: torch.Tensor,
+                      cu_seqlens: torch.Tensor, max_seq_len: int, scale: float) -> None:
+    from neural_magic_vllm_amd import _torch_bindings as tb
+    tb.prefill_attention(out, query, key, value, cu_seqlens, max_seq_len, scale)
+
+
+def prefill_attention_supported(head_size: int) -> bool:
+    from neural_magic_vllm_amd import _torch_bindings as tb
+    return tb.prefill_attention_supported(head_size)

@@ -347,6 +347,29 @@ def awq_gemm(input, kernel, scaling_factors, zeros, split_k_iters) -> torch.Tens
     return c
 
 
+def prefill_attention(out, query, key, value, cu_seqlens, max_seq_len, scale) -> None:
+    """varlen causal GQA prompt attention (csrc/prefill_attention.hip); q [T, H, D], k/v [T, KVH, D]
+    (last dim contiguous, may be slices of qkv), cu_seqlens int32 [num_seqs + 1]"""
+    _req(query.dim() == 3 and key.dim() == 3 and value.dim() == 3 and out.dim() == 3, "prefill_attention: [T, H, D] tensors")
+    _req(query.stride(2) == 1 and key.stride(2) == 1 and value.stride(2) == 1 and out.stride(2) == 1,
+         "prefill_attention: head dim must be contiguous")
+    t, h, d = query.shape
+    kvh = key.shape[1]
+    _req(query.stride(1) == d and key.stride(1) == d and value.stride(1) == d and out.stride(1) == d,
+         "prefill_attention: heads must be packed")
+    _req(key.stride(0) == value.stride(0), "prefill_attention: k and v must share the token stride")
+    _req(cu_seqlens.dtype == torch.int32 and cu_seqlens.is_contiguous(), "cu_seqlens must be int32")
+    with device_guard(query):
+        check(_lib.load().nmv_prefill_attention(ptr(out), ptr(query), ptr(key), ptr(value), ptr(cu_seqlens),
+                                                cu_seqlens.numel() - 1, int(max_seq_len), h, kvh, d,
+                                                float(scale), query.stride(0), key.stride(0),
+                                                out.stride(0), dtype_code(query.dtype), stream_of(query)))
+
+
+def prefill_attention_supported(head_size: int) -> bool:
+    return bool(_lib.load().nmv_prefill_attention_supported(int(head_size)))
+
+
 def awq_dequantize(kernel, scaling_factors, zeros, split_k_iters, thx, thy) -> torch.Tensor:
     """csrc/quantization/awq/gemm_kernels.cu:436-490 -> [K, N]"""
     size_k, size_n = kernel.shape[0], kernel.shape[1] * 8

@@ -13,6 +13,7 @@ from typing import Any, Dict, List, Optional, Tuple, Type
 
 import torch
 
+from ... import _custom_ops as ops
 from ..ops.paged_attn import PagedAttention, PagedAttentionMetadata
 from .abstract import AttentionBackend, AttentionImpl, AttentionMetadata
 
@@ -164,11 +165,23 @@ class ROCmHipAttentionImpl(AttentionImpl):
                     and pm.block_tables is not None and pm.block_tables.numel() > 0 \
                     and bool((pm.context_lens_tensor > 0).any()):
                 raise NotImplementedError("prefix-enabled prefill is outside the hot-path scope")
-            output[:num_prefill_tokens] = _sdpa_prefill(query[:num_prefill_tokens],
-                                                        key[:num_prefill_tokens],
-                                                        value[:num_prefill_tokens], pm.seq_lens,
-                                                        self.num_queries_per_kv, self.scale,
-                                                        self.alibi_slopes)
+            if self.alibi_slopes is None and ops.prefill_attention_supported(self.head_size) \
+                    and query.dtype in (torch.float16, torch.bfloat16):
+                # the hand-written HIP flash-attention forward (csrc/prefill_attention.hip)
+                cu = pm.seq_start_loc
+                if cu is None or cu.dtype != torch.int32:
+                    cu = torch.tensor([0] + list(torch.tensor(pm.seq_lens).cumsum(0).tolist()),
+                                      dtype=torch.int32, device=query.device)
+                ops.prefill_attention(output[:num_prefill_tokens], query[:num_prefill_tokens],
+                                      key[:num_prefill_tokens], value[:num_prefill_tokens], cu,
+                                      pm.max_prefill_seq_len or max(pm.seq_lens), self.scale)
+            else:
+                # ALiBi prompts and head sizes other than 64 / 128: the reference's "naive" SDPA option
+                output[:num_prefill_tokens] = _sdpa_prefill(query[:num_prefill_tokens],
+                                                            key[:num_prefill_tokens],
+                                                            value[:num_prefill_tokens], pm.seq_lens,
+                                                            self.num_queries_per_kv, self.scale,
+                                                            self.alibi_slopes)
         if (dm := attn_metadata.decode_metadata) is not None:
             output[num_prefill_tokens:] = PagedAttention.forward_decode(
                 decode_query, key_cache, value_cache, dm.block_tables, dm.seq_lens_tensor,

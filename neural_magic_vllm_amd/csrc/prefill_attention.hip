@@ -1,0 +1,214 @@
+// Prompt (prefill) attention for gfx950: varlen, causal, GQA flash-attention forward on MFMA.
+//
+// Behavioural reference: the prompt branch of ROCmFlashAttentionImpl.forward
+// (/root/reference/vllm/attention/backends/rocm_flash_attn.py:349-430): causal attention of every
+// prompt over its own freshly computed K/V ([tokens, heads, head_size] views of the qkv GEMM
+// output), softmax scale `scale`, queries of a GQA group sharing one KV head.  The reference
+// dispatches this to Triton / CK flash-attention or torch SDPA; this is the hand-written HIP
+// replacement.  fp32 softmax and accumulation, P rounded to the model
+// dtype before P.V (flash-attention convention).
+//
+// Decomposition: one 256-thread workgroup per (64-query tile, head, prompt); wave w owns 16 query
+// rows.  Everything is computed TRANSPOSED so that no register shuffle is ever needed:
+//   S^T[key][q] = K . Q^T   -- MFMA 16x16x32 with K rows as the A operand (a lane loads 16 bytes =
+//                              8 head dims of one key straight from global memory) and the wave's
+//                              Q fragment (loaded once) as B.  A lane (q = l&15, g = l>>4) ends
+//                              up with keys 16 t + 4 g + i of ITS query row: row max / sum are a
+//                              per-lane loop plus two xor-shuffles (lanes q, q+16, q+32, q+48).
+//   O^T[d][q]  += V^T . P^T -- the probabilities of a lane, packed in pairs, ARE the B operand of
+//                              this MFMA (the k-slot order {4g..4g+3, 16+4g..16+4g+3} per 32 keys is
+//                              just a permutation of the contraction index); V^T comes from an LDS
+//                              copy of the 64-key V tile read with that same key order.
+// The rescale factor alpha, the running max and the row sum live per lane (its query row).
+#include "common.h"
+
+namespace nmv {
+
+constexpr int FA_QT = 64;   // queries per workgroup
+constexpr int FA_KT = 64;   // keys per iteration
+
+template <typename T> struct FaMfma;
+template <> struct FaMfma<BF16> {
+  static __device__ __forceinline__ f32x4_t run(uint4 a, uint4 b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+  }
+};
+template <> struct FaMfma<F16> {
+  static __device__ __forceinline__ f32x4_t run(uint4 a, uint4 b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+  }
+};
+
+struct FaParams {
+  const uint16_t* q;   // [tokens, H, D], token stride q_stride (elements)
+  const uint16_t* k;   // [tokens, KVH, D], token stride kv_stride
+  const uint16_t* v;
+  uint16_t* out;       // [tokens, H, D], token stride o_stride
+  const int* cu_seqlens;  // [num_seqs + 1] token offsets of the prompts
+  int64_t q_stride, kv_stride, o_stride;
+  int num_heads, num_kv_heads;
+  float scale;
+};
+
+template <typename T, int D>
+__global__ __launch_bounds__(256) void prefill_attention_kernel(const FaParams p) {
+  static_assert(D % 32 == 0 && D <= 256, "head size");
+  constexpr int DC = D / 32;          // 32-wide head-dim chunks (MFMA k-steps of Q.K^T)
+  constexpr int DT = D / 16;          // 16-wide head-dim tiles of the output
+  constexpr int VS = D + 8;           // LDS row stride of the V tile (elements): odd multiple of 16 B
+  __shared__ __attribute__((aligned(16))) uint16_t v_s[FA_KT * VS];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r = lane & 15, g = lane >> 4;
+  const int seq = blockIdx.z, head = blockIdx.y;
+  const int kv_head = head / (p.num_heads / p.num_kv_heads);
+  const int tok0 = p.cu_seqlens[seq];
+  const int L = p.cu_seqlens[seq + 1] - tok0;
+  const int qt0 = blockIdx.x * FA_QT;
+  if (qt0 >= L) return;  // uniform
+  const int q_row = qt0 + wave * 16 + r;           // this lane's query (prompt-relative)
+  const int q_row_c = min(q_row, L - 1);
+
+  // ---- Q fragment of the wave (B operand of S^T = K . Q^T): 8 head dims per lane and chunk ----
+  uint4 qf[DC];
+  {
+    const uint16_t* qp = p.q + (int64_t)(tok0 + q_row_c) * p.q_stride + (int64_t)head * D + g * 8;
+#pragma unroll
+    for (int c = 0; c < DC; ++c) qf[c] = ld16(qp + c * 32);
+  }
+  f32x4_t o[DT];
+#pragma unroll
+  for (int t = 0; t < DT; ++t) o[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  float m_run = -INFINITY, l_run = 0.f;   // per lane = per query row (l: this lane's share)
+
+  const uint16_t* kbase = p.k + (int64_t)tok0 * p.kv_stride + (int64_t)kv_head * D;
+  const uint16_t* vbase = p.v + (int64_t)tok0 * p.kv_stride + (int64_t)kv_head * D;
+  const int last_q = min(qt0 + FA_QT, L) - 1;      // causal: keys 0 .. last_q
+  const int n_kt = last_q / FA_KT + 1;
+  const float sc = p.scale;
+
+  for (int kt = 0; kt < n_kt; ++kt) {
+    const int k0 = kt * FA_KT;
+    // ---- V tile -> LDS (all 256 threads; rows past the prompt are clamped, masked via P = 0) ----
+    __syncthreads();  // previous tile's readers are done
+    {
+      constexpr int PIECES = FA_KT * D / 8;          // 16-byte pieces
+#pragma unroll
+      for (int i = 0; i < (PIECES + 255) / 256; ++i) {
+        const int id = threadIdx.x + i * 256;
+        if (id < PIECES) {
+          const int row = id / (D / 8), c8 = id % (D / 8);
+          const uint4 x = ld16(vbase + (int64_t)min(k0 + row, L - 1) * p.kv_stride + c8 * 8);
+          *reinterpret_cast<uint4*>(&v_s[row * VS + c8 * 8]) = x;
+        }
+      }
+    }
+    // ---- S^T = K . Q^T for the 4 key tiles ----
+    f32x4_t s[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      s[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      const uint16_t* kp = kbase + (int64_t)min(k0 + t * 16 + r, L - 1) * p.kv_stride + g * 8;
+#pragma unroll
+      for (int c = 0; c < DC; ++c) s[t] = FaMfma<T>::run(ld16(kp + c * 32), qf[c], s[t]);
+    }
+    // ---- scale, causal / length mask, online softmax (row = this lane's query) ----
+    const bool diag = k0 + FA_KT - 1 > qt0;   // uniform: only tiles that reach past the first query
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int key = k0 + t * 16 + 4 * g + i;
+        float x = s[t][i] * sc;
+        if (diag && (key > q_row || key >= L)) x = -INFINITY;
+        s[t][i] = x;
+        mx = fmaxf(mx, x);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);           // finite: key 0 is visible to every query
+    const float alpha = __expf(m_run - m_new);
+    float psum = 0.f;
+    uint32_t pp[8];                                  // packed P: [t][pair]
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      float e[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        e[i] = __expf(s[t][i] - m_new);
+        e[i] = T::to_float(T::from_float(e[i]));    // P in the model dtype, and the sum of the same
+        psum += e[i];
+      }
+      pp[2 * t] = T::pack2(e[0], e[1]);
+      pp[2 * t + 1] = T::pack2(e[2], e[3]);
+    }
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+#pragma unroll
+    for (int t = 0; t < DT; ++t) o[t] *= alpha;
+    __syncthreads();  // V tile is in LDS
+    // ---- O^T += V^T . P^T : two 32-key steps, DT output tiles ----
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+      const uint4 pb = make_uint4(pp[4 * st], pp[4 * st + 1], pp[4 * st + 2], pp[4 * st + 3]);
+#pragma unroll
+      for (int t = 0; t < DT; ++t) {
+        // A operand: V^T row d = 16 t + r, keys 32 st + {4g..4g+3, 16+4g..16+4g+3}
+        const uint16_t* vp = &v_s[(32 * st + 4 * g) * VS + 16 * t + r];
+        uint32_t a[4];
+        a[0] = (uint32_t)vp[0] | ((uint32_t)vp[VS] << 16);
+        a[1] = (uint32_t)vp[2 * VS] | ((uint32_t)vp[3 * VS] << 16);
+        a[2] = (uint32_t)vp[16 * VS] | ((uint32_t)vp[17 * VS] << 16);
+        a[3] = (uint32_t)vp[18 * VS] | ((uint32_t)vp[19 * VS] << 16);
+        o[t] = FaMfma<T>::run(make_uint4(a[0], a[1], a[2], a[3]), pb, o[t]);
+      }
+    }
+  }
+  // ---- normalise and store: lane (q = r, g) holds d = 16 t + 4 g + i of its row ----
+  l_run += __shfl_xor(l_run, 16, 64);
+  l_run += __shfl_xor(l_run, 32, 64);
+  if (q_row >= L) return;
+  const float inv = 1.f / l_run;
+  uint16_t* op = p.out + (int64_t)(tok0 + q_row) * p.o_stride + (int64_t)head * D + 4 * g;
+#pragma unroll
+  for (int t = 0; t < DT; ++t) {
+    uint2 pk;
+    pk.x = T::pack2(o[t][0] * inv, o[t][1] * inv);
+    pk.y = T::pack2(o[t][2] * inv, o[t][3] * inv);
+    *reinterpret_cast<uint2*>(op + 16 * t) = pk;
+  }
+}
+
+}  // namespace nmv
+
+using namespace nmv;
+
+extern "C" int nmv_prefill_attention_supported(int head_size) { return head_size == 64 || head_size == 128; }
+
+extern "C" int nmv_prefill_attention(void* out, const void* q, const void* k, const void* v,
+                                     const int32_t* cu_seqlens, int num_seqs, int max_seq_len,
+                                     int num_heads, int num_kv_heads, int head_size, float scale,
+                                     int64_t q_stride, int64_t kv_stride, int64_t o_stride,
+                                     nmv_dtype_t dtype, void* stream) {
+  NMV_CHECK(dtype == NMV_F16 || dtype == NMV_BF16, "prefill_attention: fp16 / bf16 only");
+  NMV_CHECK(head_size == 64 || head_size == 128, "prefill_attention: head size %d not built (64, 128)", head_size);
+  NMV_CHECK(num_kv_heads > 0 && num_heads % num_kv_heads == 0, "prefill_attention: heads %% kv_heads != 0");
+  NMV_CHECK(q_stride % 8 == 0 && kv_stride % 8 == 0 && o_stride % 4 == 0,
+            "prefill_attention: token strides must keep 16-byte (q, k, v) / 8-byte (out) alignment");
+  if (num_seqs <= 0 || max_seq_len <= 0) return NMV_OK;
+  FaParams p{(const uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v, (uint16_t*)out, cu_seqlens,
+             q_stride, kv_stride, o_stride, num_heads, num_kv_heads, scale};
+  dim3 grid((max_seq_len + FA_QT - 1) / FA_QT, num_heads, num_seqs), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == NMV_BF16) {
+    if (head_size == 64) hipLaunchKernelGGL((prefill_attention_kernel<BF16, 64>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((prefill_attention_kernel<BF16, 128>), grid, block, 0, s, p);
+  } else {
+    if (head_size == 64) hipLaunchKernelGGL((prefill_attention_kernel<F16, 64>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((prefill_attention_kernel<F16, 128>), grid, block, 0, s, p);
+  }
+  NMV_LAUNCH_CHECK();
+  return NMV_OK;
+}

@@ -1,0 +1,60 @@
+"""GPU parity of the prompt (prefill) flash-attention kernel against a plain fp32 reference:
+varlen batches, causal mask, GQA, q/k/v as strided slices of one qkv tensor (as the model passes
+them).  Recipe and tolerance follow the reference's tests/kernels/test_attention.py:321-387
+(ref_multi_query_kv_attention; atol/rtol 1e-3 for fp16, 1e-2-class for bf16)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def ref_attention(q, k, v, seq_lens, scale):
+    """q [T, H, D], k/v [T, KVH, D] fp32 on the CPU; causal softmax attention per prompt"""
+    out = torch.empty_like(q)
+    rep = q.shape[1] // k.shape[1]
+    start = 0
+    for L in seq_lens:
+        qs = q[start:start + L].transpose(0, 1)                       # [H, L, D]
+        ks = k[start:start + L].transpose(0, 1).repeat_interleave(rep, dim=0)
+        vs = v[start:start + L].transpose(0, 1).repeat_interleave(rep, dim=0)
+        s = (qs @ ks.transpose(1, 2)) * scale
+        s = s + torch.full((L, L), float("-inf")).triu(1)
+        out[start:start + L] = (torch.softmax(s, dim=-1) @ vs).transpose(0, 1)
+        start += L
+    return out
+
+
+@pytest.mark.parametrize("dtype", [torch.half, torch.bfloat16])
+@pytest.mark.parametrize("heads", [(32, 8), (8, 8), (12, 1)])
+@pytest.mark.parametrize("head_size", [64, 128])
+@pytest.mark.parametrize("seq_lens", [[1], [37, 64, 1, 200], [513], [65, 128, 129]])
+def test_prefill_attention(gpu_device, dtype, heads, head_size, seq_lens):
+    from neural_magic_vllm_amd import _custom_ops as ops
+    nq, nkv = heads
+    t = sum(seq_lens)
+    g = torch.Generator().manual_seed(0)
+    qkv = (torch.rand((t, (nq + 2 * nkv) * head_size), generator=g) * 2 - 1).to(dtype)
+    scale = head_size**-0.5
+    qkv_d = qkv.to(gpu_device)
+    q, k, v = qkv_d.split([nq * head_size, nkv * head_size, nkv * head_size], dim=-1)
+    q, k, v = q.view(t, nq, head_size), k.view(t, nkv, head_size), v.view(t, nkv, head_size)
+    out = torch.full((t, nq, head_size), float("nan"), dtype=dtype, device=gpu_device)
+    cu = torch.tensor([0] + torch.tensor(seq_lens).cumsum(0).tolist(), dtype=torch.int32, device=gpu_device)
+    ops.prefill_attention(out, q, k, v, cu, max(seq_lens), scale)
+    qc, kc, vc = qkv.float().split([nq * head_size, nkv * head_size, nkv * head_size], dim=-1)
+    ref = ref_attention(qc.view(t, nq, head_size), kc.view(t, nkv, head_size), vc.view(t, nkv, head_size),
+                        seq_lens, scale)
+    got = out.float().cpu()
+    assert not torch.isnan(got).any()
+    tol = 2e-3 if dtype == torch.half else 1.6e-2   # P and the output are rounded to the model dtype
+    torch.testing.assert_close(got, ref, atol=tol, rtol=tol)
+
+
+def test_prefill_attention_rejects_unsupported_head(gpu_device):
+    from neural_magic_vllm_amd import _custom_ops as ops
+    from neural_magic_vllm_amd._lib import NmvError
+    q = torch.zeros((4, 2, 80), dtype=torch.half, device=gpu_device)
+    cu = torch.tensor([0, 4], dtype=torch.int32, device=gpu_device)
+    assert not ops.prefill_attention_supported(80)
+    with pytest.raises(NmvError):
+        ops.prefill_attention(torch.empty_like(q), q, q, q, cu, 4, 1.0)

@@ -71,3 +71,44 @@ if __name__ == "__main__":
         b, L = (int(v) for v in c.split(":"))
         us, gbs = bench(b, L, dev, args.kv)
         print(f"attn v1 B={b:3d} L={L:5d} kv={args.kv}  {us:8.1f} us  {gbs:7.0f} GB/s", flush=True)
+
+
+def bench_prefill(L, nseq, dev, iters=10, nq=32, nkv=8, d=128):
+    """prompt attention: `nseq` prompts of L tokens; compares with torch SDPA on the same data"""
+    t = L * nseq
+    qkv = torch.randn((t, (nq + 2 * nkv) * d), device=dev, dtype=torch.bfloat16)
+    q, k, v = qkv.split([nq * d, nkv * d, nkv * d], dim=-1)
+    q, k, v = q.view(t, nq, d), k.view(t, nkv, d), v.view(t, nkv, d)
+    out = torch.empty((t, nq, d), device=dev, dtype=torch.bfloat16)
+    cu = torch.arange(0, t + 1, L, dtype=torch.int32, device=dev)
+
+    def timed(fn):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / iters * 1e3
+
+    us = timed(lambda: ops.prefill_attention(out, q, k, v, cu, L, d**-0.5))
+
+    def sdpa():
+        for s in range(nseq):
+            qs = q[s * L:(s + 1) * L].movedim(0, 1)
+            ks = k[s * L:(s + 1) * L].movedim(0, 1).repeat_interleave(nq // nkv, dim=0)
+            vs = v[s * L:(s + 1) * L].movedim(0, 1).repeat_interleave(nq // nkv, dim=0)
+            torch.nn.functional.scaled_dot_product_attention(qs, ks, vs, is_causal=True, scale=d**-0.5)
+
+    us_sdpa = timed(sdpa)
+    flops = 4.0 * nseq * L * L * nq * d / 2
+    return us, flops / us / 1e6, us_sdpa
+
+
+if __name__ == "__main__" and os.environ.get("NMV_BENCH_PREFILL"):
+    dev = torch.device("cuda:0")
+    for L, nseq in [(512, 1), (512, 8), (2048, 1), (8192, 1)]:
+        us, tf, us_sdpa = bench_prefill(L, nseq, dev)
+        print(f"prefill attn L={L:5d} x{nseq}  {us:9.1f} us  {tf:6.1f} TFLOP/s   torch SDPA {us_sdpa:9.1f} us", flush=True)
