@@ -124,7 +124,7 @@ def gemm_roofline(runner, batch, dev, groups=32):
 @torch.inference_mode()
 def ttft(runner, dev, prompt_len, runs=5):
     """p50 time to first token: one prompt of `prompt_len` tokens through the whole model (our
-    GEMM / norm / rope / cache-write kernels; prompt attention = torch SDPA)."""
+    GEMM / norm / rope / cache-write / prompt flash-attention kernels, launched eagerly)."""
     runner.setup_batch(1, prompt_len, 8)
     ts = []
     for i in range(runs + 1):
