@@ -39,6 +39,9 @@ template <> struct FaMfma<F16> {
   }
 };
 
+typedef short v4s_t __attribute__((ext_vector_type(4)));
+typedef v4s_t __attribute__((address_space(3))) lds_v4s_t;
+
 struct FaParams {
   const uint16_t* q;   // [tokens, H, D], token stride q_stride (elements)
   const uint16_t* k;   // [tokens, KVH, D], token stride kv_stride
@@ -67,6 +70,7 @@ __global__ __launch_bounds__(256) void prefill_attention_kernel(const FaParams p
   const int L = p.cu_seqlens[seq + 1] - tok0;
   const int qt0 = blockIdx.x * FA_QT;
   if (qt0 >= L) return;  // uniform
+  const int tr_off = (4 * g + (r >> 2)) * VS + 4 * (r & 3);  // this lane's address role in a tr read
   const int q_row = qt0 + wave * 16 + r;           // this lane's query (prompt-relative)
   const int q_row_c = min(q_row, L - 1);
 
@@ -155,14 +159,14 @@ __global__ __launch_bounds__(256) void prefill_attention_kernel(const FaParams p
       const uint4 pb = make_uint4(pp[4 * st], pp[4 * st + 1], pp[4 * st + 2], pp[4 * st + 3]);
 #pragma unroll
       for (int t = 0; t < DT; ++t) {
-        // A operand: V^T row d = 16 t + r, keys 32 st + {4g..4g+3, 16+4g..16+4g+3}
-        const uint16_t* vp = &v_s[(32 * st + 4 * g) * VS + 16 * t + r];
-        uint32_t a[4];
-        a[0] = (uint32_t)vp[0] | ((uint32_t)vp[VS] << 16);
-        a[1] = (uint32_t)vp[2 * VS] | ((uint32_t)vp[3 * VS] << 16);
-        a[2] = (uint32_t)vp[16 * VS] | ((uint32_t)vp[17 * VS] << 16);
-        a[3] = (uint32_t)vp[18 * VS] | ((uint32_t)vp[19 * VS] << 16);
-        o[t] = FaMfma<T>::run(make_uint4(a[0], a[1], a[2], a[3]), pb, o[t]);
+        // A operand: V^T row d = 16 t + r, keys 32 st + {4g..4g+3, 16+4g..16+4g+3}: two hardware
+        // transposed reads (ds_read_b64_tr_b16: per 16-lane group a 4-row x 16-column block of the
+        // row-major V tile comes back column-major; lane 4q+p supplies row q, columns 4p..4p+3)
+        const uint16_t* vp = &v_s[(32 * st) * VS + 16 * t + tr_off];
+        const v4s_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_t*)vp);
+        const v4s_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_t*)(vp + 16 * VS));
+        const uint2 lo2 = __builtin_bit_cast(uint2, lo), hi2 = __builtin_bit_cast(uint2, hi);
+        o[t] = FaMfma<T>::run(make_uint4(lo2.x, lo2.y, hi2.x, hi2.y), pb, o[t]);
       }
     }
   }
