@@ -533,12 +533,19 @@ __global__ __launch_bounds__(GT) void w4a16_gemm_kernel(const GemmParams p) {
 // carries 20 MFMAs, so the same look-ahead in time needs half the k -- and half the ring and
 // staging registers, which is what lets 144 accumulator VGPRs fit under 256.
 
-template <typename T, int MT, int WN, int WK, int GS>
+// PS ("prescale", the prefill variant): the group scale and the zero point are applied to the
+// expanded weights in fp32 and the product is rounded to the model dtype -- the reference Marlin
+// kernel's own semantics (gptq_marlin.cu:269-278) -- instead of in fp32 on the per-group
+// accumulators.  That costs 5 more VALU ops per weight pair but needs no group accumulators and
+// no sum-of-activations MFMA, which is what lets a wave carry 128 rows (MT = 8): in prefill the
+// expansion is then shared by 128 rows and the MFMA pipe, not the VALU, is the busy one.
+template <typename T, int MT, int WN, int WK, int GS, bool PS = false>
 __global__ __launch_bounds__(GT, 2) void w4a16_gemm_tall_kernel(const GemmParams p) {
   static_assert(WN * WK == 4, "4 waves per workgroup");
+  static_assert(MT <= 4 || PS, "128-row tiles only fit without the group accumulators");
   static_assert(GS == 0 || GS == 128, "one scale group per two stages, or channelwise");
   constexpr int MP = 16 * MT;                  // rows per workgroup
-  constexpr int KSS = MT == 4 ? 1 : 2;         // MFMA k-steps per stage
+  constexpr int KSS = MT >= 4 ? 1 : 2;         // MFMA k-steps per stage
   constexpr int TS_K = 32 * KSS;               // k per stage
   constexpr int SPG = 4 / KSS;                 // stages per 128-k scale group
   constexpr int PPR = 4 * KSS;                 // 16-byte activation pieces per row and stage
@@ -634,22 +641,30 @@ __global__ __launch_bounds__(GT, 2) void w4a16_gemm_tall_kernel(const GemmParams
   };
 
   // ---- accumulators ----
-  f32x4_t accm[4][MT], accg[4][MT], accs[MT];
+  constexpr int GT_ = PS ? 1 : MT;             // group accumulators exist only without PS
+  f32x4_t accm[4][MT], accg[4][GT_], accs[GT_];
   const f32x4_t zero4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int j = 0; j < 4; ++j)
 #pragma unroll
-    for (int t = 0; t < MT; ++t) { accm[j][t] = zero4; accg[j][t] = zero4; }
+    for (int t = 0; t < MT; ++t) accm[j][t] = zero4;
 #pragma unroll
-  for (int t = 0; t < MT; ++t) accs[t] = zero4;
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int t = 0; t < GT_; ++t) accg[j][t] = zero4;
+#pragma unroll
+  for (int t = 0; t < GT_; ++t) accs[t] = zero4;
+  // PS: scale and -24 * scale of this lane's four weight rows (columns 16 j + r) for the open group
+  float ps_s[4] = {1.f, 1.f, 1.f, 1.f}, ps_z[4] = {-W4_ZP, -W4_ZP, -W4_ZP, -W4_ZP};
 
   // output fragment of this lane: columns chunk*64 + 16 j + 4 g + reg, rows m0 + 16 t + r.
   // grouped scale layout: element (4 (g&1) + reg) * 8 + 2 j + (g >> 1) of the chunk's 64
   const uint32_t sc_shift = (g >> 1) * 16;
   auto flush = [&](int gbuf) {
-    float zs[MT];
+    if constexpr (PS) return;
+    float zs[GT_];
 #pragma unroll
-    for (int t = 0; t < MT; ++t) zs[t] = -W4_ZP * accs[t][0];
+    for (int t = 0; t < GT_; ++t) zs[t] = -W4_ZP * accs[t][0];
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
       uint4 d4 = make_uint4(0, 0, 0, 0);
@@ -660,7 +675,7 @@ __global__ __launch_bounds__(GT, 2) void w4a16_gemm_tall_kernel(const GemmParams
         float scv = 1.f;
         if constexpr (GS != 0) scv = T::to_float((uint16_t)(d[j] >> sc_shift));
 #pragma unroll
-        for (int t = 0; t < MT; ++t) {
+        for (int t = 0; t < GT_; ++t) {
           const float dlt = accg[j][t][reg] + zs[t];
           if constexpr (GS != 0) accm[j][t][reg] = fmaf(scv, dlt, accm[j][t][reg]);
           else accm[j][t][reg] += dlt;
@@ -700,6 +715,17 @@ __global__ __launch_bounds__(GT, 2) void w4a16_gemm_tall_kernel(const GemmParams
     for (int ks = 0; ks < KSS; ++ks) {
       const int kstep = (U % SPG) * KSS + ks;     // k-step inside the group
       const bool first = kstep == 0;              // static after unrolling
+      if constexpr (PS && GS != 0) {
+        if (first) {  // static: the group's scales of columns 16 j + r: element (r&7)*8 + 2 j + (r>>3)
+          const uint4 d4 = sc_s[gbuf * SC_U4 + (wk * WN + wn) * 8 + (r & 7)];
+          const uint32_t d[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            ps_s[j] = T::to_float((uint16_t)(d[j] >> ((r >> 3) * 16)));
+            ps_z[j] = -W4_ZP * ps_s[j];
+          }
+        }
+      }
       uint4 af[MT];
 #pragma unroll
       for (int t = 0; t < MT; ++t) af[t] = a_s[(buf * WK + wk) * A_U4 + (ks * 4 + g) * MP + t * 16 + r];
@@ -715,15 +741,29 @@ __global__ __launch_bounds__(GT, 2) void w4a16_gemm_tall_kernel(const GemmParams
                                     and_or(__builtin_amdgcn_alignbit(e, e, rot_hi), kmask, kmagic),
                                     and_or(__builtin_amdgcn_alignbit(o, o, rot_lo), kmask, kmagic),
                                     and_or(__builtin_amdgcn_alignbit(o, o, rot_hi), kmask, kmagic));
+        if constexpr (PS) {
+          // w = (16 + q) * s - 24 * s in fp32, one rounding to the model dtype
+          const uint32_t xs4[4] = {wv.x, wv.y, wv.z, wv.w};
+          uint32_t ws4[4];
 #pragma unroll
-        for (int t = 0; t < MT; ++t) accg[j][t] = W4<T>::mfma(wv, af[t], first ? zero4 : accg[j][t]);
-        // 64-row tile: at the register limit -- keep the scheduler from expanding all four column
+          for (int e = 0; e < 4; ++e)
+            ws4[e] = T::pack2(fmaf(lo_f<T>(xs4[e]), ps_s[j], ps_z[j]), fmaf(hi_f<T>(xs4[e]), ps_s[j], ps_z[j]));
+          const uint4 ws = make_uint4(ws4[0], ws4[1], ws4[2], ws4[3]);
+#pragma unroll
+          for (int t = 0; t < MT; ++t) accm[j][t] = W4<T>::mfma(ws, af[t], accm[j][t]);
+        } else {
+#pragma unroll
+          for (int t = 0; t < GT_; ++t) accg[j][t] = W4<T>::mfma(wv, af[t], first ? zero4 : accg[j][t]);
+        }
+        // 64+-row tiles: at the register limit -- keep the scheduler from expanding all four column
         // tiles ahead of the MFMAs (that costs 16+ live VGPRs and spills)
-        if constexpr (MT == 4) __builtin_amdgcn_sched_barrier(0);
+        if constexpr (MT >= 4) __builtin_amdgcn_sched_barrier(0);
       }
+      if constexpr (!PS) {
 #pragma unroll
-      for (int t = 0; t < MT; ++t) accs[t] = W4<T>::mfma(ones, af[t], first ? zero4 : accs[t]);
-      if (kstep == 3) flush(gbuf);
+        for (int t = 0; t < GT_; ++t) accs[t] = W4<T>::mfma(ones, af[t], first ? zero4 : accs[t]);
+        if (kstep == 3) flush(gbuf);
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
     store_a(buf ^ 1, ar);
@@ -897,14 +937,18 @@ static GemmPlan make_plan(int M, int N, int K, int64_t tickets_len, bool allow_t
   if (allow_tall && M >= env_int("NMV_W4_TALL_MIN_M", 1) && K % 256 == 0 && env_int("NMV_W4_TALL", 1)) {
     pl.tall = 1;
     pl.wm = 1;
-    pl.mt = env_int("NMV_W4_TALL_MT", M <= 16 ? 1 : M <= 64 ? 2 : 4);  // measured: 64-row tile wins only past M = 64
+    // 128-row prescale tile: measured to win from M = 1024 on every Llama-3-8B projection and from
+    // M = 384 on the wide ones (gate_up: 153 vs 176 us at M = 512, 481 vs 666 us at M = 2048)
+    const bool big = M >= 1024 || (M >= 384 && n_chunks >= 256);
+    pl.mt = env_int("NMV_W4_TALL_MT", M <= 16 ? 1 : M <= 64 ? 2 : big ? 8 : 4);  // measured: 64-row tile wins only past M = 64
     const int rows = 16 * pl.mt;
     pl.m_blocks = (M + rows - 1) / rows;
     // wide N: two chunks per workgroup, two k groups; narrow N: one chunk, four k groups (the
     // in-workgroup k reduction goes through LDS and saves split-K slabs)
     int wk = (M > 32 && n_chunks * pl.m_blocks >= 256) ? 2 : 4;
     wk = env_int("NMV_W4_TALL_WK", wk);
-    const int ring_k = pl.mt == 4 ? 128 : 256;  // 4 stages of 32 / 64 k
+    if (pl.mt == 8) wk = 1;                     // the 128-row tile exists as 4 chunks x 1 k group only
+    const int ring_k = pl.mt >= 4 ? 128 : 256;  // 4 stages of 32 / 64 k
     while (wk > 1 && K % (ring_k * wk) != 0) wk >>= 1;
     pl.wk = wk;
     pl.wn = 4 / wk;
@@ -963,6 +1007,11 @@ static int launch_gemm_gs(const GemmPlan& pl, const GemmParams& p, hipStream_t s
       NMV_W4_TALL_CASE(2, 4, 1) NMV_W4_TALL_CASE(2, 2, 2) NMV_W4_TALL_CASE(2, 1, 4)
       NMV_W4_TALL_CASE(4, 4, 1) NMV_W4_TALL_CASE(4, 2, 2) NMV_W4_TALL_CASE(4, 1, 4)
 #undef NMV_W4_TALL_CASE
+      if (pl.mt == 8 && pl.wn == 4 && pl.wk == 1) {
+        hipLaunchKernelGGL((w4a16_gemm_tall_kernel<T, 8, 4, 1, GS, true>), grid, block, 0, s, p);
+        return 0;
+      }
+
       return -1;
     }
   }

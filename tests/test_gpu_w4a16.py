@@ -81,6 +81,7 @@ TALL_CASES = [  # (rows per wave / 16, k groups per workgroup, M values that pic
     (1, 1, [1, 9, 16]), (1, 2, [3, 16]), (1, 4, [1, 12]),
     (2, 1, [17, 33]), (2, 2, [20, 64]), (2, 4, [31, 47]),
     (4, 1, [40, 65]), (4, 2, [64, 130]), (4, 4, [33, 100]),
+    (8, 1, [129, 300]),   # the 128-row prescale (prefill) tile
 ]
 
 
