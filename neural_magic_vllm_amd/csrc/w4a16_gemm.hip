@@ -91,6 +91,7 @@ struct GemmParams {
   float* slab;            // [splits, M, N] fp32 (used when splits > 1)
   int* tickets;           // [n_blocks * m_blocks] zero on entry / exit (the Marlin `workspace`)
   int M, N, K;
+  int bits;               // 4, or 8 (tall kernel only)
   int group_size;         // 32/64/128, or 0 = channelwise (one scale row)
   int k_per_wg;           // k range of one workgroup (multiple of WK*STAGE_K)
   int splits;
@@ -539,9 +540,19 @@ __global__ __launch_bounds__(GT) void w4a16_gemm_kernel(const GemmParams p) {
 // accumulators.  That costs 5 more VALU ops per weight pair but needs no group accumulators and
 // no sum-of-activations MFMA, which is what lets a wave carry 128 rows (MT = 8): in prefill the
 // expansion is then shared by 128 rows and the MFMA pipe, not the VALU, is the busy one.
-template <typename T, int MT, int WN, int WK, int GS, bool PS = false>
+// BITS = 8 (W8A16 GPTQ-Marlin): the same kernel on the 8-bit Marlin tensor (int32 [K/16, N*4], a
+// vector = 32 bytes = words (tile j, block) of one k-tile, bytes = k {2q, 2q+8, 2q+1, 2q+9}): a lane
+// loads the whole vector of its k-tile, the two lanes of a pair trade the words of the other block
+// through the same bank-masked DPP rotate, and a byte becomes a model-dtype number with one
+// v_perm_b32 per pair (fp16: 0x6400 | b = 1024 + b) or v_cvt_f32_ubyte + pack (bf16: b itself);
+// the zero point (128, resp. 1024 + 128) leaves through the sum-of-activations correction.
+template <typename T, int MT, int WN, int WK, int GS, bool PS = false, int BITS = 4>
 __global__ __launch_bounds__(GT, 2) void w4a16_gemm_tall_kernel(const GemmParams p) {
   static_assert(WN * WK == 4, "4 waves per workgroup");
+  static_assert(BITS == 4 || (BITS == 8 && !PS), "4-bit, or 8-bit without the prescale variant");
+  constexpr int WV = BITS / 4;                 // 16-byte loads per lane and k-step
+  // what the expanded numbers are offset by: 16 + 8 (4-bit), 128 (8-bit bf16), 1024 + 128 (8-bit fp16)
+  constexpr float ZPC = BITS == 4 ? W4_ZP : (std::is_same<T, F16>::value ? 1152.0f : 128.0f);
   static_assert(MT <= 4 || PS, "128-row tiles only fit without the group accumulators");
   static_assert(GS == 0 || GS == 128, "one scale group per two stages, or channelwise");
   constexpr int MP = 16 * MT;                  // rows per workgroup
@@ -577,13 +588,15 @@ __global__ __launch_bounds__(GT, 2) void w4a16_gemm_tall_kernel(const GemmParams
   const int st_last = __builtin_amdgcn_readfirstlane(n_stages - 1);
 
   // ---- weights: lane (blk, n_in, q = g) streams vector n_in*4+q of k-tile 2 ks + blk ----
-  const int64_t row_u4 = p.N >> 1;
-  const uint4* bp = p.b + (int64_t)(chunk_ok ? chunk : 0) * 32 + (n_in * 4 + g) +
+  const int64_t row_u4 = (int64_t)(p.N >> 1) * WV;
+  const uint4* bp = p.b + ((int64_t)(chunk_ok ? chunk : 0) * 32 + (n_in * 4 + g)) * WV +
                     ((int64_t)(k_w0 >> 4) + blk) * row_u4;
-  auto load_w = [&](int st, uint4 (&w)[KSS]) {
+  auto load_w = [&](int st, uint4 (&w)[KSS * WV]) {
     const uint4* q = bp + (int64_t)min(st, st_last) * (2 * KSS * row_u4);
 #pragma unroll
-    for (int ks = 0; ks < KSS; ++ks) w[ks] = q[ks * 2 * row_u4];
+    for (int ks = 0; ks < KSS; ++ks)
+#pragma unroll
+      for (int h = 0; h < WV; ++h) w[ks * WV + h] = q[ks * 2 * row_u4 + h];
   };
   const uint32_t kmask = __builtin_amdgcn_readfirstlane(W4<T>::MASK);
   uint32_t kmagic = W4<T>::MAGIC;
@@ -664,7 +677,7 @@ __global__ __launch_bounds__(GT, 2) void w4a16_gemm_tall_kernel(const GemmParams
     if constexpr (PS) return;
     float zs[GT_];
 #pragma unroll
-    for (int t = 0; t < GT_; ++t) zs[t] = -W4_ZP * accs[t][0];
+    for (int t = 0; t < GT_; ++t) zs[t] = -ZPC * accs[t][0];
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
       uint4 d4 = make_uint4(0, 0, 0, 0);
@@ -685,7 +698,7 @@ __global__ __launch_bounds__(GT, 2) void w4a16_gemm_tall_kernel(const GemmParams
   };
 
   // ---- prologue ----
-  uint4 w0[KSS], w1[KSS], w2[KSS], w3[KSS];
+  uint4 w0[KSS * WV], w1[KSS * WV], w2[KSS * WV], w3[KSS * WV];
   uint4 ar[APT];
   uint4 scr = make_uint4(0, 0, 0, 0);
   load_a(0, ar);
@@ -701,7 +714,7 @@ __global__ __launch_bounds__(GT, 2) void w4a16_gemm_tall_kernel(const GemmParams
   // one stage (U = position in the ring: buffer parity and the scale-group schedule are static):
   // fetch the activations of stage st+1 and the weights of stage st+3 (into the slot stage st-1
   // just released), multiply stage st, park stage st+1's activations, barrier
-  auto stage = [&](auto u_tag, int st, const uint4 (&wc)[KSS], uint4 (&wfree)[KSS]) {
+  auto stage = [&](auto u_tag, int st, const uint4 (&wc)[KSS * WV], uint4 (&wfree)[KSS * WV]) {
     constexpr int U = decltype(u_tag)::value;
     constexpr int buf = U & 1;
     constexpr bool closes = (U + 1) % SPG == 0;   // last stage of a scale group
@@ -729,18 +742,41 @@ __global__ __launch_bounds__(GT, 2) void w4a16_gemm_tall_kernel(const GemmParams
       uint4 af[MT];
 #pragma unroll
       for (int t = 0; t < MT; ++t) af[t] = a_s[(buf * WK + wk) * A_U4 + (ks * 4 + g) * MP + t * 16 + r];
-      const uint32_t own[4] = {wc[ks].x, wc[ks].y, wc[ks].z, wc[ks].w};
+      uint32_t own[4 * WV];
+#pragma unroll
+      for (int h = 0; h < WV; ++h) {
+        own[4 * h] = wc[ks * WV + h].x; own[4 * h + 1] = wc[ks * WV + h].y;
+        own[4 * h + 2] = wc[ks * WV + h].z; own[4 * h + 3] = wc[ks * WV + h].w;
+      }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         // partner lane r^8 holds the other k-tile of the same vector: one DPP move per k-tile,
         // row_ror:8 with a bank mask so that only the half-row that needs the partner's word takes
         // it (banks 2,3 = lanes 8..15 = blk 1 for the even k-tile, banks 0,1 for the odd one)
-        const uint32_t e = (uint32_t)__builtin_amdgcn_update_dpp((int)own[j], (int)own[j], 0x128, 0xf, 0xc, false);
-        const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp((int)own[j], (int)own[j], 0x128, 0xf, 0x3, false);
-        const uint4 wv = make_uint4(and_or(__builtin_amdgcn_alignbit(e, e, rot_lo), kmask, kmagic),
-                                    and_or(__builtin_amdgcn_alignbit(e, e, rot_hi), kmask, kmagic),
-                                    and_or(__builtin_amdgcn_alignbit(o, o, rot_lo), kmask, kmagic),
-                                    and_or(__builtin_amdgcn_alignbit(o, o, rot_hi), kmask, kmagic));
+        uint4 wv;
+        if constexpr (BITS == 4) {
+          const uint32_t e = (uint32_t)__builtin_amdgcn_update_dpp((int)own[j], (int)own[j], 0x128, 0xf, 0xc, false);
+          const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp((int)own[j], (int)own[j], 0x128, 0xf, 0x3, false);
+          wv = make_uint4(and_or(__builtin_amdgcn_alignbit(e, e, rot_lo), kmask, kmagic),
+                          and_or(__builtin_amdgcn_alignbit(e, e, rot_hi), kmask, kmagic),
+                          and_or(__builtin_amdgcn_alignbit(o, o, rot_lo), kmask, kmagic),
+                          and_or(__builtin_amdgcn_alignbit(o, o, rot_hi), kmask, kmagic));
+        } else {
+          // words (tile j, block 0 / 1) of the lane's own k-tile: the even k-tile's word of MY block
+          // is my own (block 0 lanes) or the partner's word 2j+1 (block 1 lanes), and vice versa
+          const uint32_t e = (uint32_t)__builtin_amdgcn_update_dpp((int)own[2 * j], (int)own[2 * j + 1], 0x128, 0xf, 0xc, false);
+          const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp((int)own[2 * j + 1], (int)own[2 * j], 0x128, 0xf, 0x3, false);
+          if constexpr (std::is_same<T, F16>::value) {
+            // bytes {0,2} / {1,3} next to 0x64: fp16 1024 + b, one v_perm_b32 per pair
+            wv = make_uint4(__builtin_amdgcn_perm(0x64646464u, e, 0x04020400u), __builtin_amdgcn_perm(0x64646464u, e, 0x04030401u),
+                            __builtin_amdgcn_perm(0x64646464u, o, 0x04020400u), __builtin_amdgcn_perm(0x64646464u, o, 0x04030401u));
+          } else {
+            auto pair = [](uint32_t x, int lo_byte, int hi_byte) -> uint32_t {
+              return BF16::pack2((float)((x >> (8 * lo_byte)) & 0xffu), (float)((x >> (8 * hi_byte)) & 0xffu));
+            };
+            wv = make_uint4(pair(e, 0, 2), pair(e, 1, 3), pair(o, 0, 2), pair(o, 1, 3));
+          }
+        }
         if constexpr (PS) {
           // w = (16 + q) * s - 24 * s in fp32, one rounding to the model dtype
           const uint32_t xs4[4] = {wv.x, wv.y, wv.z, wv.w};
@@ -928,7 +964,8 @@ static int env_int(const char* name, int dflt) {
 // Pick the workgroup shape and the split-K factor.  Decode-sized GEMMs (M <= 64) last only a
 // few microseconds at HBM speed, so the plan aims at >= ~2 workgroups per CU while keeping the
 // fp32 partial traffic (splits * M * N * 4 B) well below the weight bytes (K * N / 2).
-static GemmPlan make_plan(int M, int N, int K, int64_t tickets_len, bool allow_tall = false) {
+static GemmPlan make_plan(int M, int N, int K, int64_t tickets_len, bool allow_tall = false,
+                          int bits = 4) {
   GemmPlan pl;
   const int n_chunks = N / 64;
   pl.tall = 0;
@@ -940,7 +977,8 @@ static GemmPlan make_plan(int M, int N, int K, int64_t tickets_len, bool allow_t
     // 128-row prescale tile: measured to win from M = 1024 on every Llama-3-8B projection and from
     // M = 384 on the wide ones (gate_up: 153 vs 176 us at M = 512, 481 vs 666 us at M = 2048)
     const bool big = M >= 1024 || (M >= 384 && n_chunks >= 256);
-    pl.mt = env_int("NMV_W4_TALL_MT", M <= 16 ? 1 : M <= 64 ? 2 : big ? 8 : 4);  // measured: 64-row tile wins only past M = 64
+    pl.mt = env_int("NMV_W4_TALL_MT", M <= 16 ? 1 : M <= 64 ? 2 : big ? 8 : 4);
+    if (bits == 8 && pl.mt > 4) pl.mt = 4;       // no prescale variant for 8-bit codes  // measured: 64-row tile wins only past M = 64
     const int rows = 16 * pl.mt;
     pl.m_blocks = (M + rows - 1) / rows;
     // wide N: two chunks per workgroup, two k groups; narrow N: one chunk, four k groups (the
@@ -948,6 +986,7 @@ static GemmPlan make_plan(int M, int N, int K, int64_t tickets_len, bool allow_t
     int wk = (M > 32 && n_chunks * pl.m_blocks >= 256) ? 2 : 4;
     wk = env_int("NMV_W4_TALL_WK", wk);
     if (pl.mt == 8) wk = 1;                     // the 128-row tile exists as 4 chunks x 1 k group only
+    if (bits == 8 && pl.mt == 4 && wk == 4) wk = 2;  // 8-bit 64-row tile: registers allow 4x1 / 2x2
     const int ring_k = pl.mt >= 4 ? 128 : 256;  // 4 stages of 32 / 64 k
     while (wk > 1 && K % (ring_k * wk) != 0) wk >>= 1;
     pl.wk = wk;
@@ -997,6 +1036,18 @@ template <typename T, int GS>
 static int launch_gemm_gs(const GemmPlan& pl, const GemmParams& p, hipStream_t s) {
   dim3 grid(pl.n_blocks, pl.splits, pl.m_blocks), block(GT);
   if constexpr (GS == 0 || GS == 128) {
+    if (pl.tall && p.bits == 8) {
+#define NMV_W8_TALL_CASE(mt_, wn_, wk_)                                                                  \
+  if (pl.mt == mt_ && pl.wn == wn_ && pl.wk == wk_) {                                                    \
+    hipLaunchKernelGGL((w4a16_gemm_tall_kernel<T, mt_, wn_, wk_, GS, false, 8>), grid, block, 0, s, p);  \
+    return 0;                                                                                            \
+  }
+      NMV_W8_TALL_CASE(1, 4, 1) NMV_W8_TALL_CASE(1, 2, 2) NMV_W8_TALL_CASE(1, 1, 4)
+      NMV_W8_TALL_CASE(2, 4, 1) NMV_W8_TALL_CASE(2, 2, 2) NMV_W8_TALL_CASE(2, 1, 4)
+      NMV_W8_TALL_CASE(4, 4, 1) NMV_W8_TALL_CASE(4, 2, 2)
+#undef NMV_W8_TALL_CASE
+      return -1;
+    }
     if (pl.tall) {
 #define NMV_W4_TALL_CASE(mt_, wn_, wk_)                                                        \
   if (pl.mt == mt_ && pl.wn == wn_ && pl.wk == wk_) {                                          \
@@ -1081,7 +1132,10 @@ extern "C" int64_t nmv_gptq_marlin_gemm_scratch_bytes(int size_m, int size_n, in
   if (size_m <= 0 || size_n <= 0 || size_k <= 0) return 0;
   // upper bound over every plan the entry point may pick (the ticket array only lowers splits)
   int max_splits = make_plan(size_m, size_n, size_k, INT64_MAX, false).splits;
-  if (!has_act_order) max_splits = std::max(max_splits, make_plan(size_m, size_n, size_k, INT64_MAX, true).splits);
+  if (!has_act_order) {
+    max_splits = std::max(max_splits, make_plan(size_m, size_n, size_k, INT64_MAX, true, 4).splits);
+    max_splits = std::max(max_splits, make_plan(size_m, size_n, size_k, INT64_MAX, true, 8).splits);
+  }
   return max_splits > 1 ? (int64_t)max_splits * size_m * size_n * 4 : 0;
 }
 
@@ -1115,9 +1169,13 @@ extern "C" int nmv_gptq_marlin_gemm(void* c, const void* a, const int32_t* b_q_w
   NMV_CHECK(group_size == 0 || group_size == 32 || group_size == 64 || group_size == 128 ||
                 (has_act_order && !is_k_full),
             "Unsupported group_size = %d", group_size);
-  if (num_bits == 8 || (has_act_order && !is_k_full)) {
-    // 8-bit codes, and act-order on a K shard (irregular group runs: one scale row per k through
-    // g_idx), take the generic LDS-staged kernel; same math, not HBM-tuned yet
+  // 8-bit codes run the tall kernel when its conditions hold (group 128 / channelwise, no act-order,
+  // K in whole rings, at most 128 rows per launch block: M-tiles up to 64 rows exist for 8 bits)
+  const bool tall8 = num_bits == 8 && !has_act_order && (group_size == 0 || group_size == 128) &&
+                     size_k % 256 == 0 && env_int("NMV_W4_TALL", 1);
+  if ((num_bits == 8 && !tall8) || (has_act_order && !is_k_full)) {
+    // the remaining 8-bit cases, and act-order on a K shard (irregular group runs: one scale row per k
+    // through g_idx), take the generic LDS-staged kernel; same math, not HBM-tuned
     const int rc = wq_marlin_fallback(c, a, b_q_weight, b_scales, has_act_order ? g_idx : nullptr,
                                       has_act_order ? perm : nullptr, num_bits, size_m, size_n,
                                       size_k, num_groups, 0, dtype, (hipStream_t)stream);
@@ -1128,7 +1186,8 @@ extern "C" int nmv_gptq_marlin_gemm(void* c, const void* a, const int32_t* b_q_w
   // the tall kernel covers the prevalent formats (group 128 / channelwise, no act-order gather);
   // groups of 32 / 64 and act-order stay on the 16-row kernel
   const bool allow_tall = !has_act_order && (group_size == 0 || group_size == 128);
-  const GemmPlan pl = make_plan(size_m, size_n, size_k, workspace ? workspace_len : 0, allow_tall);
+  const GemmPlan pl = make_plan(size_m, size_n, size_k, workspace ? workspace_len : 0, allow_tall,
+                                num_bits);
   const int64_t need = pl.splits > 1 ? (int64_t)pl.splits * size_m * size_n * 4 : 0;
   NMV_CHECK(need < (int64_t)1 << 31, "gptq_marlin_gemm: split-K slab too large");
   NMV_CHECK(scratch_bytes >= need && (need == 0 || scratch != nullptr),
@@ -1143,6 +1202,7 @@ extern "C" int nmv_gptq_marlin_gemm(void* c, const void* a, const int32_t* b_q_w
   p.slab = (float*)scratch;
   p.tickets = workspace;
   p.M = size_m; p.N = size_n; p.K = size_k;
+  p.bits = num_bits;
   p.group_size = group_size;
   p.k_per_wg = pl.k_per_wg;
   p.splits = pl.splits;

@@ -89,9 +89,12 @@ TALL_CASES = [  # (rows per wave / 16, k groups per workgroup, M values that pic
 @pytest.mark.parametrize("k,n", [(1024, 64), (2048, 448)])
 @pytest.mark.parametrize("group_size", [-1, 128])
 @pytest.mark.parametrize("dtype", [torch.half, torch.bfloat16])
-def test_marlin_gemm_tall_variants(gpu_device, monkeypatch, mt, wk, ms, k, n, group_size, dtype):
+@pytest.mark.parametrize("bits", [4, 8])
+def test_marlin_gemm_tall_variants(gpu_device, monkeypatch, mt, wk, ms, k, n, group_size, dtype, bits):
     """every instantiation of the default (tall register tile) kernel, forced through its
-    development knobs: tile height x in-workgroup k split, ragged M, with and without split-K"""
+    development knobs: tile height x in-workgroup k split, ragged M, with and without split-K;
+    4-bit and 8-bit (W8A16) codes (the plan maps 8-bit requests for tiles it does not have --
+    128 rows, 64 rows x 4 k groups -- onto the nearest one it has)"""
     monkeypatch.setenv("NMV_W4_TALL_MT", str(mt))
     monkeypatch.setenv("NMV_W4_TALL_WK", str(wk))
     for m in ms:
@@ -100,9 +103,9 @@ def test_marlin_gemm_tall_variants(gpu_device, monkeypatch, mt, wk, ms, k, n, gr
                 monkeypatch.setenv("NMV_W4_SPLITS", str(splits))
             else:
                 monkeypatch.delenv("NMV_W4_SPLITS", raising=False)
-            pr = helpers.make_w4a16_problem(5, m, k, n, 4, group_size, False, dtype)
-            c = hip_gemm(pr, m, n, k, 4, gpu_device)
-            ref = oracle.gptq_marlin_gemm(pr["a"], pr["marlin_q_w"], pr["marlin_s"], None, None, 4, m, n, k)
+            pr = helpers.make_w4a16_problem(5, m, k, n, bits, group_size, False, dtype)
+            c = hip_gemm(pr, m, n, k, bits, gpu_device)
+            ref = oracle.gptq_marlin_gemm(pr["a"], pr["marlin_q_w"], pr["marlin_s"], None, None, bits, m, n, k)
             assert not torch.isnan(c.float()).any()
             assert ref_math.compute_max_diff(c, ref) < 6e-3, (m, splits)
 
