@@ -228,6 +228,19 @@ int nmv_awq_dequantize(void* out, const int32_t* qweight, const void* scales, co
  * may be slices of the fused qkv GEMM output); cu_seqlens int32 [num_seqs + 1] on the device.
  * ---------------------------------------------------------------------------------------- */
 int nmv_prefill_attention_supported(int head_size);
+/* Prefix-enabled prefill (PagedAttention.forward_prefix, vllm/attention/ops/paged_attn.py:184-216 ->
+ * Triton context_attention_fwd): the new tokens [query_start_loc[i], query_start_loc[i+1]) of sequence
+ * i attend causally to ALL its keys [0, seq_lens[i]) read from the paged cache (the backend has
+ * written the new tokens' K/V before the call); context_lens[i] = seq_lens[i] - new tokens.
+ * kv cache dtype auto (fp16 / bf16) only; layouts as paged_attention. */
+int nmv_prefix_prefill_attention(void* out, const void* q, const void* key_cache,
+                                 const void* value_cache, const int32_t* block_tables,
+                                 const int32_t* query_start_loc, const int32_t* seq_lens,
+                                 const int32_t* context_lens, int num_seqs, int max_query_len,
+                                 int max_blocks_per_seq, int block_size, int num_heads,
+                                 int num_kv_heads, int head_size, float scale, int64_t q_stride,
+                                 int64_t o_stride, int64_t kv_block_stride, int64_t kv_head_stride,
+                                 nmv_dtype_t dtype, void* stream);
 int nmv_prefill_attention(void* out, const void* q, const void* k, const void* v,
                           const int32_t* cu_seqlens, int num_seqs, int max_seq_len, int num_heads,
                           int num_kv_heads, int head_size, float scale, int64_t q_stride,

@@ -279,3 +279,12 @@ def prefill_attention(out: torch.Tensor, query: torch.Tensor, key: torch.Tensor,
 def prefill_attention_supported(head_size: int) -> bool:
     from neural_magic_vllm_amd import _torch_bindings as tb
     return tb.prefill_attention_supported(head_size)
+
+
+def prefix_prefill_attention(out: torch.Tensor, query: torch.Tensor, key_cache: torch.Tensor,
+                             value_cache: torch.Tensor, block_tables: torch.Tensor,
+                             query_start_loc: torch.Tensor, seq_lens: torch.Tensor,
+                             context_lens: torch.Tensor, max_query_len: int, scale: float) -> None:
+    from neural_magic_vllm_amd import _torch_bindings as tb
+    tb.prefix_prefill_attention(out, query, key_cache, value_cache, block_tables, query_start_loc,
+                                seq_lens, context_lens, max_query_len, scale)

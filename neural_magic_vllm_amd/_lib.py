@@ -64,6 +64,8 @@ SIGNATURES = {
     "nmv_gptq_gemm": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _L, _P]),
     "nmv_wq_gemm_scratch_bytes": (_L, [_I, _I, _I]),
     "nmv_prefill_attention_supported": (_I, [_I]),
+    "nmv_prefix_prefill_attention": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F,
+                                          _L, _L, _L, _L, _I, _P]),
     "nmv_prefill_attention": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _L, _L, _L, _I, _P]),
     "nmv_gptq_shuffle": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "nmv_awq_gemm": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _L, _P]),

@@ -366,6 +366,28 @@ def prefill_attention(out, query, key, value, cu_seqlens, max_seq_len, scale) ->
                                                 out.stride(0), dtype_code(query.dtype), stream_of(query)))
 
 
+def prefix_prefill_attention(out, query, key_cache, value_cache, block_tables, query_start_loc,
+                             seq_lens, context_lens, max_query_len, scale) -> None:
+    """PagedAttention.forward_prefix on the paged cache (csrc/prefill_attention.hip); query/out
+    [new tokens, H, D]; key_cache [NB, KVH, D/x, BS, x], value_cache [NB, KVH, D, BS] (16-bit)"""
+    _req(query.dim() == 3 and out.dim() == 3 and query.stride(2) == 1 and out.stride(2) == 1,
+         "prefix_prefill_attention: [T, H, D] tensors with a contiguous head dim")
+    t, h, d = query.shape
+    _req(query.stride(1) == d and out.stride(1) == d, "prefix_prefill_attention: heads must be packed")
+    _req(key_cache.dtype == query.dtype and value_cache.dtype == query.dtype,
+         "prefix_prefill_attention: kv cache dtype must be auto (the model dtype)")
+    nb, kvh, _, bs = value_cache.shape
+    for x in (block_tables, query_start_loc, seq_lens, context_lens):
+        _req(x.dtype == torch.int32 and x.is_contiguous(), "prefix_prefill_attention: int32 index tensors")
+    with device_guard(query):
+        check(_lib.load().nmv_prefix_prefill_attention(
+            ptr(out), ptr(query), ptr(key_cache), ptr(value_cache), ptr(block_tables),
+            ptr(query_start_loc), ptr(seq_lens), ptr(context_lens), seq_lens.numel(),
+            int(max_query_len), block_tables.shape[1], bs, h, kvh, d, float(scale), query.stride(0),
+            out.stride(0), value_cache.stride(0), value_cache.stride(1), dtype_code(query.dtype),
+            stream_of(query)))
+
+
 def prefill_attention_supported(head_size: int) -> bool:
     return bool(_lib.load().nmv_prefill_attention_supported(int(head_size)))
 

@@ -164,8 +164,15 @@ class ROCmHipAttentionImpl(AttentionImpl):
             if pm.context_lens_tensor is not None and kv_cache is not None \
                     and pm.block_tables is not None and pm.block_tables.numel() > 0 \
                     and bool((pm.context_lens_tensor > 0).any()):
-                raise NotImplementedError("prefix-enabled prefill is outside the hot-path scope")
-            if self.alibi_slopes is None and ops.prefill_attention_supported(self.head_size) \
+                # prefix-enabled prefill (chunked prefill / prefix caching): every key comes from
+                # the paged cache, which already holds the new tokens (written above)
+                if self.kv_cache_dtype != "auto":
+                    raise NotImplementedError("prefix-enabled prefill needs kv_cache_dtype auto")
+                output[:num_prefill_tokens] = PagedAttention.forward_prefix(
+                    query[:num_prefill_tokens], key[:num_prefill_tokens], value[:num_prefill_tokens],
+                    key_cache, value_cache, pm.block_tables, pm.query_start_loc, pm.seq_lens_tensor,
+                    pm.context_lens_tensor, pm.max_query_len, self.alibi_slopes, None, self.scale)
+            elif self.alibi_slopes is None and ops.prefill_attention_supported(self.head_size) \
                     and query.dtype in (torch.float16, torch.bfloat16):
                 # the hand-written HIP flash-attention forward (csrc/prefill_attention.hip)
                 cu = pm.seq_start_loc

@@ -89,6 +89,26 @@ class PagedAttention:
         return output
 
     @staticmethod
+    def forward_prefix(query: torch.Tensor, key: torch.Tensor, value: torch.Tensor,
+                       key_cache: torch.Tensor, value_cache: torch.Tensor,
+                       block_tables: torch.Tensor, query_start_loc: torch.Tensor,
+                       seq_lens_tensor: torch.Tensor, context_lens: torch.Tensor,
+                       max_query_len: int, alibi_slopes: Optional[torch.Tensor],
+                       sliding_window: Optional[int], scale: Optional[float] = None) -> torch.Tensor:
+        """prefix-enabled prefill (paged_attn.py:184-216).  `key` / `value` (the new tokens) are
+        accepted for signature parity; the backend has already written them into the cache, which
+        is where the kernel reads every key from (kv cache dtype auto)."""
+        if alibi_slopes is not None or sliding_window is not None:
+            raise NotImplementedError("prefix prefill: ALiBi / sliding window are not built on gfx950")
+        output = torch.empty_like(query)
+        head_size = query.shape[-1]
+        ops.prefix_prefill_attention(output, query, key_cache, value_cache, block_tables,
+                                     query_start_loc.to(torch.int32), seq_lens_tensor.to(torch.int32),
+                                     context_lens.to(torch.int32), max_query_len,
+                                     scale if scale is not None else head_size**-0.5)
+        return output
+
+    @staticmethod
     def swap_blocks(src_kv_cache: torch.Tensor, dst_kv_cache: torch.Tensor,
                     src_to_dst: torch.Tensor) -> None:
         ops.swap_blocks(src_kv_cache[0], dst_kv_cache[0], src_to_dst)

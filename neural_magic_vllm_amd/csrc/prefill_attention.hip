@@ -185,6 +185,145 @@ __global__ __launch_bounds__(256) void prefill_attention_kernel(const FaParams p
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Prefix-enabled prefill (chunked prefill / prefix caching): the new tokens of a prompt attend to
+// the cached context AND to themselves (causal).  Behavioural reference:
+// PagedAttention.forward_prefix (/root/reference/vllm/attention/ops/paged_attn.py:184-216) ->
+// context_attention_fwd (ops/prefix_prefill.py, Triton).  The backend writes the new tokens' K/V
+// into the paged cache before attention (rocm_flash_attn.py:318-331), so with an unquantised cache
+// every key -- context and new -- is read from the cache: K [NB, KVH, D/8, BS, 8] gives the 16-byte
+// MFMA operand of a key directly (8 head dims), V [NB, KVH, D, BS] gives the V^T operand of a head
+// dim as two 8-byte runs of 4 consecutive tokens; no LDS at all.  Same transposed formulation as
+// the kernel above.
+struct PfxParams {
+  const uint16_t* q;    // [new tokens, H, D]
+  uint16_t* out;
+  const uint16_t* kc;   // key cache
+  const uint16_t* vc;   // value cache
+  const int* block_tables;   // [num_seqs, max_blocks]
+  const int* q_start;        // [num_seqs + 1] offsets of the new tokens
+  const int* seq_lens;       // [num_seqs] context + new
+  const int* ctx_lens;       // [num_seqs]
+  int64_t q_stride, o_stride, kv_block_stride, kv_head_stride;  // elements
+  int max_blocks, block_size, num_heads, num_kv_heads;
+  float scale;
+};
+
+template <typename T, int D>
+__global__ __launch_bounds__(256) void prefix_attention_kernel(const PfxParams p) {
+  constexpr int DC = D / 32, DT = D / 16;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r = lane & 15, g = lane >> 4;
+  const int seq = blockIdx.z, head = blockIdx.y;
+  const int kv_head = head / (p.num_heads / p.num_kv_heads);
+  const int tok0 = p.q_start[seq];
+  const int q_len = p.q_start[seq + 1] - tok0;
+  const int L = p.seq_lens[seq];
+  const int ctx = p.ctx_lens[seq];
+  const int qt0 = blockIdx.x * FA_QT;
+  if (qt0 >= q_len) return;  // uniform
+  const int q_row = qt0 + wave * 16 + r;          // new-token index of this lane's query
+  const int q_pos = ctx + q_row;                  // its position in the sequence
+  const int* bt = p.block_tables + (int64_t)seq * p.max_blocks;
+  const int bs = p.block_size;
+  const int64_t head_off = (int64_t)kv_head * p.kv_head_stride;
+
+  uint4 qf[DC];
+  {
+    const uint16_t* qp = p.q + (int64_t)(tok0 + min(q_row, q_len - 1)) * p.q_stride + (int64_t)head * D + g * 8;
+#pragma unroll
+    for (int c = 0; c < DC; ++c) qf[c] = ld16(qp + c * 32);
+  }
+  f32x4_t o[DT];
+#pragma unroll
+  for (int t = 0; t < DT; ++t) o[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  float m_run = -INFINITY, l_run = 0.f;
+  const int last_pos = ctx + min(qt0 + FA_QT, q_len) - 1;   // causal: keys 0 .. last_pos (< L)
+  const int n_kt = last_pos / FA_KT + 1;
+  const float sc = p.scale;
+
+  for (int kt = 0; kt < n_kt; ++kt) {
+    const int k0 = kt * FA_KT;
+    // ---- S^T = K . Q^T, keys gathered through the block table ----
+    f32x4_t s[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      s[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      const int key = min(k0 + t * 16 + r, L - 1);
+      const uint16_t* kp = p.kc + (int64_t)bt[key / bs] * p.kv_block_stride + head_off + (key % bs) * 8;
+#pragma unroll
+      for (int c = 0; c < DC; ++c) s[t] = FaMfma<T>::run(ld16(kp + (int64_t)(c * 4 + g) * bs * 8), qf[c], s[t]);
+    }
+    const bool diag = k0 + FA_KT - 1 > ctx + qt0;   // uniform
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int key = k0 + t * 16 + 4 * g + i;
+        float x = s[t][i] * sc;
+        if (diag && (key > q_pos || key >= L)) x = -INFINITY;
+        s[t][i] = x;
+        mx = fmaxf(mx, x);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = __expf(m_run - m_new);
+    float psum = 0.f;
+    uint32_t pp[8];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      float e[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        e[i] = T::to_float(T::from_float(__expf(s[t][i] - m_new)));
+        psum += e[i];
+      }
+      pp[2 * t] = T::pack2(e[0], e[1]);
+      pp[2 * t + 1] = T::pack2(e[2], e[3]);
+    }
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+#pragma unroll
+    for (int t = 0; t < DT; ++t) o[t] *= alpha;
+    // ---- O^T += V^T . P^T: V^T row d = 16 t + r, keys 32 st + {4g..4g+3, 16+4g..16+4g+3} ----
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+      const uint4 pb = make_uint4(pp[4 * st], pp[4 * st + 1], pp[4 * st + 2], pp[4 * st + 3]);
+      const int ka = k0 + 32 * st + 4 * g, kb = ka + 16;
+      // tokens past the end of the sequence may be uninitialised cache (NaN x 0 = NaN): zero them
+      const int va = min(max(L - ka, 0), 4), vb = min(max(L - kb, 0), 4);
+      const uint2 ma = make_uint2(va >= 2 ? 0xffffffffu : (va == 1 ? 0xffffu : 0u),
+                                  va >= 4 ? 0xffffffffu : (va == 3 ? 0xffffu : 0u));
+      const uint2 mb = make_uint2(vb >= 2 ? 0xffffffffu : (vb == 1 ? 0xffffu : 0u),
+                                  vb >= 4 ? 0xffffffffu : (vb == 3 ? 0xffffu : 0u));
+      const int kac = min(ka, L - 1) & ~3, kbc = min(kb, L - 1) & ~3;
+      const uint16_t* vpa = p.vc + (int64_t)bt[kac / bs] * p.kv_block_stride + head_off + (kac % bs);
+      const uint16_t* vpb = p.vc + (int64_t)bt[kbc / bs] * p.kv_block_stride + head_off + (kbc % bs);
+#pragma unroll
+      for (int t = 0; t < DT; ++t) {
+        const uint2 xa = ld8(vpa + (int64_t)(16 * t + r) * bs);
+        const uint2 xb = ld8(vpb + (int64_t)(16 * t + r) * bs);
+        o[t] = FaMfma<T>::run(make_uint4(xa.x & ma.x, xa.y & ma.y, xb.x & mb.x, xb.y & mb.y), pb, o[t]);
+      }
+    }
+  }
+  l_run += __shfl_xor(l_run, 16, 64);
+  l_run += __shfl_xor(l_run, 32, 64);
+  if (q_row >= q_len) return;
+  const float inv = 1.f / l_run;
+  uint16_t* op = p.out + (int64_t)(tok0 + q_row) * p.o_stride + (int64_t)head * D + 4 * g;
+#pragma unroll
+  for (int t = 0; t < DT; ++t) {
+    uint2 pk;
+    pk.x = T::pack2(o[t][0] * inv, o[t][1] * inv);
+    pk.y = T::pack2(o[t][2] * inv, o[t][3] * inv);
+    *reinterpret_cast<uint2*>(op + 16 * t) = pk;
+  }
+}
+
 }  // namespace nmv
 
 using namespace nmv;
@@ -212,6 +351,36 @@ extern "C" int nmv_prefill_attention(void* out, const void* q, const void* k, co
   } else {
     if (head_size == 64) hipLaunchKernelGGL((prefill_attention_kernel<F16, 64>), grid, block, 0, s, p);
     else hipLaunchKernelGGL((prefill_attention_kernel<F16, 128>), grid, block, 0, s, p);
+  }
+  NMV_LAUNCH_CHECK();
+  return NMV_OK;
+}
+
+extern "C" int nmv_prefix_prefill_attention(void* out, const void* q, const void* key_cache,
+                                            const void* value_cache, const int32_t* block_tables,
+                                            const int32_t* query_start_loc, const int32_t* seq_lens,
+                                            const int32_t* context_lens, int num_seqs,
+                                            int max_query_len, int max_blocks_per_seq, int block_size,
+                                            int num_heads, int num_kv_heads, int head_size, float scale,
+                                            int64_t q_stride, int64_t o_stride, int64_t kv_block_stride,
+                                            int64_t kv_head_stride, nmv_dtype_t dtype, void* stream) {
+  NMV_CHECK(dtype == NMV_F16 || dtype == NMV_BF16, "prefix_prefill_attention: fp16 / bf16 only (kv cache dtype auto)");
+  NMV_CHECK(head_size == 64 || head_size == 128, "prefix_prefill_attention: head size %d not built (64, 128)", head_size);
+  NMV_CHECK(block_size == 8 || block_size == 16 || block_size == 32, "prefix_prefill_attention: block size %d", block_size);
+  NMV_CHECK(num_kv_heads > 0 && num_heads % num_kv_heads == 0, "prefix_prefill_attention: heads %% kv_heads != 0");
+  NMV_CHECK(q_stride % 8 == 0 && o_stride % 4 == 0, "prefix_prefill_attention: token strides break alignment");
+  if (num_seqs <= 0 || max_query_len <= 0) return NMV_OK;
+  PfxParams p{(const uint16_t*)q, (uint16_t*)out, (const uint16_t*)key_cache, (const uint16_t*)value_cache,
+              block_tables, query_start_loc, seq_lens, context_lens, q_stride, o_stride, kv_block_stride,
+              kv_head_stride, max_blocks_per_seq, block_size, num_heads, num_kv_heads, scale};
+  dim3 grid((max_query_len + FA_QT - 1) / FA_QT, num_heads, num_seqs), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == NMV_BF16) {
+    if (head_size == 64) hipLaunchKernelGGL((prefix_attention_kernel<BF16, 64>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((prefix_attention_kernel<BF16, 128>), grid, block, 0, s, p);
+  } else {
+    if (head_size == 64) hipLaunchKernelGGL((prefix_attention_kernel<F16, 64>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((prefix_attention_kernel<F16, 128>), grid, block, 0, s, p);
   }
   NMV_LAUNCH_CHECK();
   return NMV_OK;

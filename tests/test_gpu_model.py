@@ -106,3 +106,45 @@ def test_kv_cache_slots_bit_exact(gpu_device):
     assert got == sorted(exp.tolist())
     # the runner advanced its state on device
     assert torch.equal(runner.positions.cpu(), pos.cpu() + 1)
+
+
+def test_tiny_llama_chunked_prefill_matches_single_shot(gpu_device):
+    """prefix-enabled prefill end to end: a prompt fed in two chunks (the second one attends to the
+    first through the paged cache, PagedAttention.forward_prefix) must give the logits of the
+    single-shot prefill"""
+    from neural_magic_vllm_amd.attention.backends.rocm_hip_attn import ROCmHipAttentionMetadata
+    arch, weights, runner = build(None, gpu_device)
+    dev, bs = gpu_device, 16
+    batch, prompt_len, first = 2, 50, 32
+    runner.setup_batch(batch, prompt_len, 8)
+    g = torch.Generator().manual_seed(3)
+    prompts = torch.randint(0, arch.vocab_size, (batch, prompt_len), generator=g).to(dev)
+
+    def meta(lo, hi):
+        n = hi - lo
+        pos = torch.arange(lo, hi, device=dev)
+        blk = torch.gather(runner.block_tables.long(), 1, (pos // bs).expand(batch, -1))
+        slots = (blk * bs + pos % bs).view(-1)
+        cu = torch.arange(0, (batch + 1) * n, n, dtype=torch.int32, device=dev)
+        return ROCmHipAttentionMetadata(
+            num_prefills=batch, num_prefill_tokens=batch * n, num_decode_tokens=0, slot_mapping=slots,
+            seq_lens=[hi] * batch, seq_lens_tensor=torch.full((batch, ), hi, dtype=torch.int32, device=dev),
+            max_query_len=n, max_prefill_seq_len=hi, max_decode_seq_len=0, query_start_loc=cu,
+            seq_start_loc=torch.arange(0, (batch + 1) * hi, hi, dtype=torch.int32, device=dev),
+            context_lens_tensor=torch.full((batch, ), lo, dtype=torch.int32, device=dev),
+            block_tables=runner.block_tables if lo > 0 else runner.block_tables[:, :0],
+            use_cuda_graph=False), pos.repeat(batch)
+
+    with torch.inference_mode():
+        md, pos = meta(0, prompt_len)
+        full = runner.model(prompts.reshape(-1), pos, runner.kv_caches, md).view(batch, prompt_len, -1)
+        for kc in runner.kv_caches:   # forget the cache: the chunked run must rebuild it
+            kc.zero_()
+        md, pos = meta(0, first)
+        runner.model(prompts[:, :first].reshape(-1), pos, runner.kv_caches, md)
+        md, pos = meta(first, prompt_len)
+        part = runner.model(prompts[:, first:].reshape(-1), pos, runner.kv_caches, md)
+        part = part.view(batch, prompt_len - first, -1)
+    a, b = full[:, first:].float(), part.float()
+    rel = ((a - b).abs().mean() / a.abs().mean()).item()
+    assert rel < 1e-2, rel

@@ -58,3 +58,58 @@ def test_prefill_attention_rejects_unsupported_head(gpu_device):
     assert not ops.prefill_attention_supported(80)
     with pytest.raises(NmvError):
         ops.prefill_attention(torch.empty_like(q), q, q, q, cu, 4, 1.0)
+
+
+@pytest.mark.parametrize("dtype", [torch.half, torch.bfloat16])
+@pytest.mark.parametrize("heads", [(32, 8), (4, 4)])
+@pytest.mark.parametrize("head_size", [64, 128])
+@pytest.mark.parametrize("block_size", [8, 16, 32])
+def test_prefix_prefill_attention(gpu_device, dtype, heads, head_size, block_size):
+    """prefix-enabled prefill: the last q_len tokens of every sequence attend to the whole sequence
+    through the paged cache (written with reshape_and_cache, random block tables); the reference is
+    the full causal attention restricted to those rows"""
+    from neural_magic_vllm_amd import _custom_ops as ops
+    import helpers
+    nq, nkv = heads
+    seq_lens = [70, 33, 257, 16]
+    q_lens = [70 - 64, 33, 65, 1]          # context: 64, 0, 192, 15 tokens
+    g = torch.Generator().manual_seed(1)
+    scale = head_size**-0.5
+    total = sum(seq_lens)
+    q_all = (torch.rand((total, nq, head_size), generator=g) * 2 - 1).to(dtype)
+    k_all = (torch.rand((total, nkv, head_size), generator=g) * 2 - 1).to(dtype)
+    v_all = (torch.rand((total, nkv, head_size), generator=g) * 2 - 1).to(dtype)
+    nb = 64
+    max_blocks = (max(seq_lens) + block_size - 1) // block_size
+    perm = torch.randperm(nb * 4, generator=g)[:len(seq_lens) * max_blocks].view(len(seq_lens), max_blocks)
+    kshape, vshape = helpers.kv_cache_shapes(nb * 4, block_size, nkv, head_size, 2)
+    kc = torch.full(kshape, float("nan"), dtype=dtype, device=gpu_device)   # garbage outside the sequences
+    vc = torch.full(vshape, float("nan"), dtype=dtype, device=gpu_device)
+    slots, start = [], 0
+    for i, L in enumerate(seq_lens):
+        pos = torch.arange(L)
+        slots.append(perm[i][pos // block_size] * block_size + pos % block_size)
+    slots = torch.cat(slots).to(torch.int64).to(gpu_device)
+    ops.reshape_and_cache(k_all.to(gpu_device), v_all.to(gpu_device), kc, vc, slots, "auto", 1.0)
+    # queries = the last q_len tokens of every sequence
+    q_new, start = [], 0
+    for L, ql in zip(seq_lens, q_lens):
+        q_new.append(q_all[start + L - ql:start + L])
+        start += L
+    q_new = torch.cat(q_new).to(gpu_device)
+    out = torch.full_like(q_new, float("nan"))
+    qsl = torch.tensor([0] + torch.tensor(q_lens).cumsum(0).tolist(), dtype=torch.int32, device=gpu_device)
+    sl = torch.tensor(seq_lens, dtype=torch.int32, device=gpu_device)
+    cl = torch.tensor([L - ql for L, ql in zip(seq_lens, q_lens)], dtype=torch.int32, device=gpu_device)
+    ops.prefix_prefill_attention(out, q_new, kc, vc, perm.to(torch.int32).to(gpu_device), qsl, sl, cl,
+                                 max(q_lens), scale)
+    ref_full = ref_attention(q_all.float(), k_all.float(), v_all.float(), seq_lens, scale)
+    ref, start = [], 0
+    for L, ql in zip(seq_lens, q_lens):
+        ref.append(ref_full[start + L - ql:start + L])
+        start += L
+    ref = torch.cat(ref)
+    got = out.float().cpu()
+    assert not torch.isnan(got).any()
+    tol = 2e-3 if dtype == torch.half else 1.6e-2
+    torch.testing.assert_close(got, ref, atol=tol, rtol=tol)
