@@ -25,12 +25,17 @@
 // group boundary   acc_main += s[g,n] * (acc_group - 24 * S_group[m]).
 // fp32 scaling is strictly more accurate than the reference's half-precision (q-8)*s products.
 //
-// Decomposition: a 256-thread workgroup = 4 waves arranged WN x WM x WK; a wave owns
-// 128 columns x (16*MT) rows and walks its k range in 128-deep stages (8 x 16-byte weight loads
-// per lane per stage, the next stage's loads are issued before the current stage is consumed).
-// Activations of a stage go through LDS once per workgroup in MFMA-operand order.  Split-K
-// across workgroups writes fp32 slabs that a second tiny kernel sums in a fixed order
-// (bit-reproducible, unlike the reference's lock-based fp16 global reduce :1054-1110).
+// Two kernels live here:
+//   * w4a16_gemm_tall_kernel -- the default: one wave = one 64-column chunk x 16/32/64/128 rows,
+//     weights straight from registers for all its row tiles (a DPP exchange between lane pairs
+//     replaces the second load), 4-slot register ring, in-workgroup K split; 4- and 8-bit codes;
+//     group 128 / channelwise, no act-order, K in whole rings.
+//   * w4a16_gemm_kernel -- the first kernel of this round (a wave = 128 columns x 16 rows, the
+//     lane mapping described above): groups of 32 / 64, act-order with the full K, K % 256 != 0.
+// Both stage the activations of a stage through LDS once per workgroup in MFMA-operand order and
+// split K across workgroups into fp32 slabs that the LAST workgroup of a tile (ticket in the
+// Marlin `workspace`) sums in a fixed order inside the same launch: bit-reproducible, unlike the
+// reference's lock-based fp16 global reduce (:1054-1110).
 // HBM-bound for M <= 64: algorithmic bytes K*N/2 + (K/g)*N*2 + 2*M*K + 2*M*N.
 #include <type_traits>
 
