@@ -192,19 +192,34 @@ __global__ __launch_bounds__(256) void wq_gemm_kernel(const WqParams p) {
 // Streaming kernel for the two checkpoint layouts that matter in practice: 4-bit GPTQ without
 // act-order (exllama layout: int32 [K/8, N], 8 consecutive k of one column per word) and AWQ
 // (int32 [K, N/8], 8 columns of one k per word, nibble order {0,4,1,5,2,6,3,7}).
-// Same numerics as wq_gemm_kernel (w = (q - z) * s rounded to the model dtype, fp32 accumulate),
-// but the packed words are streamed ONCE with 16-byte coalesced loads into a raw LDS image
-// (double-buffered, 128 k x 64 columns = 4 KiB per stage), each lane then pulls the 8 codes of
-// its MFMA operand out of LDS (GPTQ: one word; AWQ: one nibble of 8 words, a broadcast read),
-// scales / zero points are fetched once per 32-k step, activations come straight from global
-// memory in natural k order, and K is split over workgroups (fp32 slabs summed in split order by
-// wq_reduce_kernel: deterministic).  ~40x the throughput of the element-wise kernel above.
+// The packed words are streamed ONCE with 16-byte coalesced loads into a raw LDS image
+// (double-buffered, 128 k x 64 columns = 4 KiB per stage); each lane pulls the 8 codes of its MFMA
+// operand out of LDS (GPTQ: one word; AWQ: one nibble of 8 words, a broadcast read) and expands
+// them with the exponent trick of w4a16_gemm.hip -- a nibble dropped into the top mantissa bits
+// of a bf16/fp16 with exponent 2^4 is exactly 16 + q.  Codes i and i+4 of a GPTQ word are 16 bits
+// apart, so ONE rotate + ONE v_and_or_b32 yields the pair (k_i, k_i+4): the operand's k order is
+// (0,4,1,5,2,6,3,7) and the activation fragment (natural order from global memory) is brought to
+// the same order with four v_perm_b32.  Zero point and scale are applied in fp32 per group on the
+// accumulators:  acc += s[n] * (acc_group - (16 + z[n]) * S_group[m]),  S from an all-ones MFMA
+// (more accurate than the reference's reconstruct-to-half-then-GEMM, q_gemm.cu:1496-1499).
+// K is split over workgroups (fp32 slabs summed in split order by wq_reduce_kernel: deterministic).
 constexpr int WS_K = 128;  // k per stage
+
+template <typename T> struct WqMagic;
+template <> struct WqMagic<BF16> {   // nibble -> mantissa bits [6:3] of each half, value 16 + q
+  static constexpr uint32_t MASK = 0x00780078u, MAGIC = 0x41804180u, ONES = 0x3F803F80u;
+  static constexpr int POS = 3;
+};
+template <> struct WqMagic<F16> {    // mantissa bits [9:6]
+  static constexpr uint32_t MASK = 0x03C003C0u, MAGIC = 0x4C004C00u, ONES = 0x3C003C00u;
+  static constexpr int POS = 6;
+};
 
 template <typename T, int FMT, int MT>
 __global__ __launch_bounds__(256) void wq_stream_kernel(const WqParams p, float* __restrict__ slab,
                                                         int k_per_wg) {
   static_assert(FMT == WQ_GPTQ || FMT == WQ_AWQ, "4-bit GPTQ / AWQ only");
+  using MG = WqMagic<T>;
   __shared__ __attribute__((aligned(16))) uint32_t raw[2][1024];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -214,8 +229,8 @@ __global__ __launch_bounds__(256) void wq_stream_kernel(const WqParams p, float*
   const int kb = blockIdx.y * k_per_wg;
   const int ke = min(kb + k_per_wg, p.K);
   const int n_stages = (ke - kb) / WS_K;
-  const int col = wave * 16 + r;       // column of this lane inside the 64-column tile
-  const int n = n0 + col;              // N % 64 == 0: always in range
+  const int col = wave * 16 + r;       // weight column of this lane (MFMA A-operand row)
+  const int nout = n0 + wave * 16 + 4 * g;   // first of this lane's 4 OUTPUT columns
 
   // ---- raw stage loader: one 16-byte piece per thread ----
   const uint32_t* src;
@@ -230,15 +245,45 @@ __global__ __launch_bounds__(256) void wq_stream_kernel(const WqParams p, float*
     src_stage_stride = (int64_t)WS_K * (p.N / 8);
     lds_idx = (threadIdx.x >> 1) * 8 + (threadIdx.x & 1) * 4;       // [128 k rows][8 words]
   }
-  const int awq_shift = 4 * (((col & 1) << 2) | ((col & 7) >> 1));  // nibble of this column
+  const uint32_t kmask = __builtin_amdgcn_readfirstlane(MG::MASK);
+  uint32_t kmagic = MG::MAGIC;
+  asm volatile("" : "+v"(kmagic));   // keep mask in an SGPR and magic in a VGPR: v_and_or_b32
+  // AWQ: rotate amounts that bring this column's nibble to the low / high half's mantissa field
+  const int awq_sh = 4 * (((col & 1) << 2) | ((col & 7) >> 1));
+  const uint32_t awq_rlo = (uint32_t)(awq_sh - MG::POS) & 31u;
+  const uint32_t awq_rhi = (uint32_t)(awq_sh - MG::POS - 16) & 31u;
+  const uint32_t mask_lo = kmask & 0xffffu, mask_hi = kmask & 0xffff0000u;
   const uint16_t* a_row[MT];
 #pragma unroll
   for (int t = 0; t < MT; ++t)
     a_row[t] = p.a + (int64_t)min(m0 + t * 16 + r, p.M - 1) * p.K + kb + g * 8;
 
-  f32x4_t acc[MT];
+  const f32x4_t zero4 = {0.f, 0.f, 0.f, 0.f};
+  f32x4_t acc[MT], accg[MT], accs[MT];
 #pragma unroll
-  for (int t = 0; t < MT; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  for (int t = 0; t < MT; ++t) { acc[t] = zero4; accg[t] = zero4; accs[t] = zero4; }
+  const uint4 ones = make_uint4(MG::ONES, MG::ONES, MG::ONES, MG::ONES);
+  const int flush_ks = min(p.group_size, WS_K) / 32;   // 1, 2 or 4 k-steps per scale group (uniform)
+
+  // acc += s[n] * (accg - (16 + z[n]) * S[m]) for this lane's 4 output columns, then reset
+  auto flush = [&](int k_abs) {
+    const int grp = k_abs / p.group_size;
+    const uint2 s2 = *reinterpret_cast<const uint2*>(p.scales + (int64_t)grp * p.N + nout);
+    const uint32_t zw = p.qzeros ? p.qzeros[(int64_t)grp * (p.N / 8) + (nout >> 3)] : 0x77777777u;
+    const float sc[4] = {lo_f<T>(s2.x), hi_f<T>(s2.x), lo_f<T>(s2.y), hi_f<T>(s2.y)};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = (nout & 7) + i;   // column inside the zero-point word (nout % 8 is 0 or 4)
+      int z;
+      if constexpr (FMT == WQ_GPTQ) z = (int)((zw >> (4 * c)) & 0xf) + 1;   // stored as zero - 1
+      else z = (int)((zw >> (4 * (((c & 1) << 2) | (c >> 1)))) & 0xf);
+      const float zc = -(16.0f + (float)z);
+#pragma unroll
+      for (int t = 0; t < MT; ++t) acc[t][i] = fmaf(sc[i], fmaf(zc, accs[t][0], accg[t][i]), acc[t][i]);
+    }
+#pragma unroll
+    for (int t = 0; t < MT; ++t) { accg[t] = zero4; accs[t] = zero4; }
+  };
 
   uint4 nxt = make_uint4(0, 0, 0, 0);
   if (n_stages > 0) {
@@ -250,41 +295,49 @@ __global__ __launch_bounds__(256) void wq_stream_kernel(const WqParams p, float*
     const int buf = st & 1;
     const int k0 = kb + st * WS_K;
     if (st + 1 < n_stages) nxt = *reinterpret_cast<const uint4*>(src + (st + 1) * src_stage_stride);
-    // scales, zero points and activation fragments of the 4 k-steps: all loads issued up front
-    float sc[4], zp[4];
-    uint4 af[4][MT];
+    uint4 af[4][MT];   // activation fragments of the 4 k-steps: all loads issued up front
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      const int grp = (k0 + ks * 32 + g * 8) / p.group_size;
-      sc[ks] = T::to_float(p.scales[(int64_t)grp * p.N + n]);
-      zp[ks] = wq_zero<FMT>(p, grp, n);
+    for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
       for (int t = 0; t < MT; ++t) af[ks][t] = ld16(a_row[t] + st * WS_K + ks * 32);
-    }
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      uint32_t q[8];
+      uint4 wf;
       if constexpr (FMT == WQ_GPTQ) {
         const uint32_t x = raw[buf][(ks * 4 + g) * 64 + col];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) q[i] = (x >> (4 * i)) & 0xf;
+        // code i sits at bit 4 i and must reach bit POS: rotate right by (4 i - POS) mod 32; code
+        // i + 4 follows 16 bits higher into the upper half
+        wf = make_uint4((__builtin_amdgcn_alignbit(x, x, (0 - MG::POS) & 31) & kmask) | kmagic,
+                        (__builtin_amdgcn_alignbit(x, x, (4 - MG::POS) & 31) & kmask) | kmagic,
+                        (__builtin_amdgcn_alignbit(x, x, (8 - MG::POS) & 31) & kmask) | kmagic,
+                        (__builtin_amdgcn_alignbit(x, x, (12 - MG::POS) & 31) & kmask) | kmagic);
       } else {
+        uint32_t w8[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) q[i] = (raw[buf][(ks * 32 + g * 8 + i) * 8 + (col >> 3)] >> awq_shift) & 0xf;
+        for (int i = 0; i < 8; ++i) w8[i] = raw[buf][(ks * 32 + g * 8 + i) * 8 + (col >> 3)];
+        uint32_t d[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const uint32_t lo = (__builtin_amdgcn_alignbit(w8[i], w8[i], awq_rlo) & mask_lo) | kmagic;
+          d[i] = (__builtin_amdgcn_alignbit(w8[i + 4], w8[i + 4], awq_rhi) & mask_hi) | lo;
+        }
+        wf = make_uint4(d[0], d[1], d[2], d[3]);
       }
-      uint32_t pk[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
-        pk[e] = T::pack2(((float)q[2 * e] - zp[ks]) * sc[ks], ((float)q[2 * e + 1] - zp[ks]) * sc[ks]);
-      const uint4 wf = make_uint4(pk[0], pk[1], pk[2], pk[3]);
-#pragma unroll
-      for (int t = 0; t < MT; ++t) acc[t] = Mfma16<T>::run(wf, af[ks][t], acc[t]);
+      for (int t = 0; t < MT; ++t) {
+        // activations to the operand's k order (0,4,1,5,2,6,3,7)
+        const uint4 x = af[ks][t];
+        const uint4 ap = make_uint4(__builtin_amdgcn_perm(x.z, x.x, 0x05040100u), __builtin_amdgcn_perm(x.z, x.x, 0x07060302u),
+                                    __builtin_amdgcn_perm(x.w, x.y, 0x05040100u), __builtin_amdgcn_perm(x.w, x.y, 0x07060302u));
+        accg[t] = Mfma16<T>::run(wf, ap, accg[t]);
+        accs[t] = Mfma16<T>::run(ones, ap, accs[t]);
+      }
+      if ((ks + 1) % flush_ks == 0) flush(k0 + ks * 32);   // uniform
     }
     if (st + 1 < n_stages) *reinterpret_cast<uint4*>(&raw[buf ^ 1][lds_idx]) = nxt;
     __syncthreads();
   }
-  // D[row = column index][col = m]: lane (m = r, g) holds columns n0 + 16 wave + 4 g + i
-  const int nb = n0 + wave * 16 + 4 * g;
+  // D[row = column index][col = m]: lane (m = r, g) holds columns nout + i
 #pragma unroll
   for (int t = 0; t < MT; ++t) {
     const int m = m0 + t * 16 + r;
@@ -293,9 +346,9 @@ __global__ __launch_bounds__(256) void wq_stream_kernel(const WqParams p, float*
       uint2 pk;
       pk.x = T::pack2(acc[t][0], acc[t][1]);
       pk.y = T::pack2(acc[t][2], acc[t][3]);
-      *reinterpret_cast<uint2*>(p.c + (int64_t)m * p.N + nb) = pk;
+      *reinterpret_cast<uint2*>(p.c + (int64_t)m * p.N + nout) = pk;
     } else {
-      *reinterpret_cast<f32x4_t*>(slab + ((int64_t)blockIdx.y * p.M + m) * p.N + nb) = acc[t];
+      *reinterpret_cast<f32x4_t*>(slab + ((int64_t)blockIdx.y * p.M + m) * p.N + nout) = acc[t];
     }
   }
 }
