@@ -173,6 +173,17 @@ int nmv_gptq_marlin_gemm(void* c, const void* a, const int32_t* b_q_weight, cons
                          int num_bits, int size_m, int size_n, int size_k, int num_groups,
                          int is_k_full, nmv_dtype_t dtype, void* stream);
 
+/* Marlin-format GEMM with per-(group, column) zero points -- not an op of nm-vllm 0.5.1 (later vLLM:
+ * awq_marlin): asymmetric AWQ / GPTQ checkpoints repacked once at load run the tuned Marlin kernel.
+ * b_zeros: z in the model dtype, [num_groups, N] in marlin_permute_scales order; 4-bit codes, group
+ * 128, K % 256 == 0; scratch as nmv_gptq_marlin_gemm.  c = a . ((q - z) * s). */
+int nmv_marlin_zp_gemm(void* c, const void* a, const int32_t* b_q_weight, const void* b_scales,
+                       const void* b_zeros, int32_t* workspace, int64_t workspace_len, void* scratch,
+                       int64_t scratch_bytes, int size_m, int size_n, int size_k, int num_groups,
+                       nmv_dtype_t dtype, void* stream);
+/* AWQ qweight int32 [K, N/8] -> Marlin int32 [K/16, N*2] (bit-exact code shuffle) */
+int nmv_awq_marlin_repack(int32_t* out, const int32_t* qweight, int size_k, int size_n, void* stream);
+
 /* marlin_gemm  (csrc/quantization/marlin/dense/marlin_cuda_kernel.cu:1045-1136): legacy Marlin
  * checkpoints, 4-bit, group -1 / 128; same tensors as nmv_gptq_marlin_gemm without act-order. */
 int nmv_marlin_gemm(void* c, const void* a, const int32_t* b_q_weight, const void* b_scales,

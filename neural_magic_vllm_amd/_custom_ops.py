@@ -288,3 +288,16 @@ def prefix_prefill_attention(out: torch.Tensor, query: torch.Tensor, key_cache: 
     from neural_magic_vllm_amd import _torch_bindings as tb
     tb.prefix_prefill_attention(out, query, key_cache, value_cache, block_tables, query_start_loc,
                                 seq_lens, context_lens, max_query_len, scale)
+
+
+# AWQ / asymmetric checkpoints on the Marlin kernel (not ops of nm-vllm 0.5.1; later vLLM: awq_marlin)
+def awq_marlin_repack(qweight: torch.Tensor, size_k: int, size_n: int) -> torch.Tensor:
+    from neural_magic_vllm_amd import _torch_bindings as tb
+    return tb.awq_marlin_repack(qweight, size_k, size_n)
+
+
+def marlin_zp_gemm(a: torch.Tensor, b_q_weight: torch.Tensor, b_scales: torch.Tensor,
+                   b_zeros: torch.Tensor, workspace: torch.Tensor, size_m: int, size_n: int,
+                   size_k: int) -> torch.Tensor:
+    from neural_magic_vllm_amd import _torch_bindings as tb
+    return tb.marlin_zp_gemm(a, b_q_weight, b_scales, b_zeros, workspace, size_m, size_n, size_k)

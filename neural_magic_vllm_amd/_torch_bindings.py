@@ -239,6 +239,40 @@ def gptq_marlin_gemm(a, b_q_weight, b_scales, g_idx, perm, workspace, num_bits, 
     return c
 
 
+def marlin_zp_gemm(a, b_q_weight, b_scales, b_zeros, workspace, size_m, size_n, size_k) -> torch.Tensor:
+    """Marlin-format GEMM with zero points (csrc/w4a16_gemm.hip; not an op of nm-vllm 0.5.1):
+    b_zeros holds z in A's dtype, [groups, N] in marlin_permute_scales order; 4-bit, group 128."""
+    _req(a.shape[0] == size_m and a.shape[1] == size_k and a.is_contiguous(), "marlin_zp_gemm: bad a")
+    _req(b_q_weight.dtype == torch.int32 and b_q_weight.is_contiguous()
+         and b_q_weight.shape == (size_k // 16, size_n * 2), "marlin_zp_gemm: b_q_weight must be int32 [K/16, 2N]")
+    _req(b_scales.dtype == a.dtype and b_zeros.dtype == a.dtype and b_scales.is_contiguous()
+         and b_zeros.is_contiguous() and b_scales.shape == b_zeros.shape and b_scales.shape[1] == size_n,
+         "marlin_zp_gemm: scales / zeros must be [groups, N] in A's dtype")
+    _req(workspace.dtype == torch.int32 and workspace.numel() >= size_n // 64 * 16, "marlin_zp_gemm: workspace")
+    c = torch.empty((size_m, size_n), dtype=a.dtype, device=a.device)
+    if size_m == 0:
+        return c
+    L = _lib.load()
+    nbytes = L.nmv_gptq_marlin_gemm_scratch_bytes(size_m, size_n, size_k, 0)
+    scratch = torch.empty((max(nbytes, 16), ), dtype=torch.uint8, device=a.device)
+    with device_guard(a):
+        check(L.nmv_marlin_zp_gemm(ptr(c), ptr(a), ptr(b_q_weight), ptr(b_scales), ptr(b_zeros),
+                                   ptr(workspace), workspace.numel(), ptr(scratch), scratch.numel(),
+                                   size_m, size_n, size_k, b_scales.shape[0], dtype_code(a.dtype),
+                                   stream_of(a)))
+    return c
+
+
+def awq_marlin_repack(qweight, size_k, size_n) -> torch.Tensor:
+    """AWQ int32 [K, N/8] -> Marlin int32 [K/16, 2N]"""
+    _req(qweight.dtype == torch.int32 and qweight.is_contiguous() and qweight.shape == (size_k, size_n // 8),
+         "awq_marlin_repack: qweight must be int32 [K, N/8]")
+    out = torch.empty((size_k // 16, size_n * 2), dtype=torch.int32, device=qweight.device)
+    with device_guard(qweight):
+        check(_lib.load().nmv_awq_marlin_repack(ptr(out), ptr(qweight), size_k, size_n, stream_of(qweight)))
+    return out
+
+
 def marlin_gemm(a, b_q_weight, b_scales, workspace, size_m, size_n, size_k) -> torch.Tensor:
     """csrc/quantization/marlin/dense/marlin_cuda_kernel.cu:1045-1136 (legacy Marlin, 4-bit)"""
     _req(a.shape[0] == size_m and a.shape[1] == size_k, "Shape mismatch: a vs size_m / size_k")

@@ -91,6 +91,7 @@ struct GemmParams {
   const uint16_t* a;      // [M, K]
   const uint4* b;         // Marlin int32 [K/16, N*2] viewed as uint4 [K/16, N/2]
   const uint16_t* s;      // [num_groups, N] (marlin_permute_scales layout)
+  const uint16_t* zp;     // zero points z in the model dtype, layout of s; null = symmetric (8)
   const int* perm;        // [K] or null: A columns are gathered through it (act-order)
   uint16_t* c;            // [M, N] (used when splits == 1)
   float* slab;            // [splits, M, N] fp32 (used when splits > 1)
@@ -551,8 +552,12 @@ __global__ __launch_bounds__(GT) void w4a16_gemm_kernel(const GemmParams p) {
 // through the same bank-masked DPP rotate, and a byte becomes a model-dtype number with one
 // v_perm_b32 per pair (fp16: 0x6400 | b = 1024 + b) or v_cvt_f32_ubyte + pack (bf16: b itself);
 // the zero point (128, resp. 1024 + 128) leaves through the sum-of-activations correction.
-template <typename T, int MT, int WN, int WK, int GS, bool PS = false, int BITS = 4>
+// ZP: per-(group, column) zero points (asymmetric AWQ / GPTQ checkpoints repacked to the Marlin
+// layout): p.zp holds z in the model dtype in the layout of the scales; they travel through LDS
+// with the scales (threads 32..63 stage them) and replace the constant 8 in the correction term.
+template <typename T, int MT, int WN, int WK, int GS, bool PS = false, int BITS = 4, bool ZP = false>
 __global__ __launch_bounds__(GT, 2) void w4a16_gemm_tall_kernel(const GemmParams p) {
+  static_assert(!ZP || (BITS == 4 && GS == 128), "zero points: 4-bit, group 128");
   static_assert(WN * WK == 4, "4 waves per workgroup");
   static_assert(BITS == 4 || (BITS == 8 && !PS), "4-bit, or 8-bit without the prescale variant");
   constexpr int WV = BITS / 4;                 // 16-byte loads per lane and k-step
@@ -567,12 +572,13 @@ __global__ __launch_bounds__(GT, 2) void w4a16_gemm_tall_kernel(const GemmParams
   constexpr int PPR = 4 * KSS;                 // 16-byte activation pieces per row and stage
   constexpr int A_U4 = KSS * 4 * MP;           // uint4 per (stage, k-group): [k-step][g][row]
   constexpr int SC_U4 = 4 * 8;                 // one scale group: [k-group * WN + wn] x 128 B
-  constexpr int MAIN_U4 = 2 * WK * A_U4 + 2 * SC_U4;
+  constexpr int MAIN_U4 = 2 * WK * A_U4 + (ZP ? 4 : 2) * SC_U4;
   constexpr int RED_U4 = (WK > 1) ? (WK - 1) * WN * MT * 256 : 0;
   constexpr int LDS_U4 = MAIN_U4 > RED_U4 ? (MAIN_U4 > GT ? MAIN_U4 : GT) : (RED_U4 > GT ? RED_U4 : GT);
   __shared__ __attribute__((aligned(16))) uint4 lds[LDS_U4];
   uint4* a_s = lds;
   uint4* sc_s = lds + 2 * WK * A_U4;
+  uint4* zp_s = sc_s + 2 * SC_U4;              // [2][SC_U4] zero points (ZP only)
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -645,7 +651,9 @@ __global__ __launch_bounds__(GT, 2) void w4a16_gemm_tall_kernel(const GemmParams
   // scale rows: threads 0..31 = (k-group*WN + wn') x 8 pieces of 16 B (64 columns x 2 B)
   const int s_combo = (threadIdx.x >> 3) & 3, s_piece = threadIdx.x & 7;
   const int s_chunk = min(blockIdx.x * WN + (s_combo % WN), n_chunks - 1);
-  const uint16_t* s_src = p.s + (int64_t)s_chunk * 64 + s_piece * 8;
+  // threads 0..31 fetch scales, threads 32..63 the zero points (same geometry)
+  const bool s_is_zp = ZP && threadIdx.x >= 32;
+  const uint16_t* s_src = (s_is_zp ? p.zp : p.s) + (int64_t)s_chunk * 64 + s_piece * 8;
   const int s_k0 = k_wg0 + (s_combo / WN) * k_per_wave;
   auto load_sc = [&](int st) -> uint4 {
     if constexpr (GS == 0) return make_uint4(0, 0, 0, 0);
@@ -655,6 +663,9 @@ __global__ __launch_bounds__(GT, 2) void w4a16_gemm_tall_kernel(const GemmParams
   auto store_sc = [&](int gbuf, uint4 v) {
     if constexpr (GS != 0) {
       if (threadIdx.x < 32) sc_s[gbuf * SC_U4 + threadIdx.x] = v;
+      if constexpr (ZP) {
+        if (threadIdx.x >= 32 && threadIdx.x < 64) zp_s[gbuf * SC_U4 + threadIdx.x - 32] = v;
+      }
     }
   };
 
@@ -685,16 +696,20 @@ __global__ __launch_bounds__(GT, 2) void w4a16_gemm_tall_kernel(const GemmParams
     for (int t = 0; t < GT_; ++t) zs[t] = -ZPC * accs[t][0];
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
-      uint4 d4 = make_uint4(0, 0, 0, 0);
+      uint4 d4 = make_uint4(0, 0, 0, 0), z4 = make_uint4(0, 0, 0, 0);
       if constexpr (GS != 0) d4 = sc_s[gbuf * SC_U4 + (wk * WN + wn) * 8 + (g & 1) * 4 + reg];
+      if constexpr (ZP) z4 = zp_s[gbuf * SC_U4 + (wk * WN + wn) * 8 + (g & 1) * 4 + reg];
       const uint32_t d[4] = {d4.x, d4.y, d4.z, d4.w};
+      const uint32_t zd[4] = {z4.x, z4.y, z4.z, z4.w};
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         float scv = 1.f;
         if constexpr (GS != 0) scv = T::to_float((uint16_t)(d[j] >> sc_shift));
+        float nzc = 0.f;   // -(16 + z) of this column
+        if constexpr (ZP) nzc = -(16.0f + T::to_float((uint16_t)(zd[j] >> sc_shift)));
 #pragma unroll
         for (int t = 0; t < GT_; ++t) {
-          const float dlt = accg[j][t][reg] + zs[t];
+          const float dlt = ZP ? fmaf(nzc, accs[t][0], accg[j][t][reg]) : accg[j][t][reg] + zs[t];
           if constexpr (GS != 0) accm[j][t][reg] = fmaf(scv, dlt, accm[j][t][reg]);
           else accm[j][t][reg] += dlt;
         }
@@ -737,10 +752,14 @@ __global__ __launch_bounds__(GT, 2) void w4a16_gemm_tall_kernel(const GemmParams
         if (first) {  // static: the group's scales of columns 16 j + r: element (r&7)*8 + 2 j + (r>>3)
           const uint4 d4 = sc_s[gbuf * SC_U4 + (wk * WN + wn) * 8 + (r & 7)];
           const uint32_t d[4] = {d4.x, d4.y, d4.z, d4.w};
+          uint4 z4 = make_uint4(0, 0, 0, 0);
+          if constexpr (ZP) z4 = zp_s[gbuf * SC_U4 + (wk * WN + wn) * 8 + (r & 7)];
+          const uint32_t zd[4] = {z4.x, z4.y, z4.z, z4.w};
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             ps_s[j] = T::to_float((uint16_t)(d[j] >> ((r >> 3) * 16)));
-            ps_z[j] = -W4_ZP * ps_s[j];
+            const float zc = ZP ? 16.0f + T::to_float((uint16_t)(zd[j] >> ((r >> 3) * 16))) : W4_ZP;
+            ps_z[j] = -zc * ps_s[j];
           }
         }
       }
@@ -955,6 +974,31 @@ __global__ void marlin_repack_kernel(const uint32_t* __restrict__ qw, const int*
 }
 
 // ---------------------------------------------------------------------------------------------
+// AWQ checkpoint layout (int32 [K, N/8]: 8 columns of one k per word, nibble of column c =
+// {0,4,1,5,2,6,3,7}[c], dequantize.cuh:31-62) -> Marlin tensor, the same target as above.
+__global__ void awq_marlin_repack_kernel(const uint32_t* __restrict__ qw, uint32_t* __restrict__ out,
+                                         int K, int N) {
+  const int64_t row_words = (int64_t)N * 2;
+  const int64_t total = (int64_t)(K / 16) * row_words;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int kt = idx / row_words;
+  const int col = idx % row_words;
+  const int chunk = col / 128, rr = col % 128;
+  const int i = rr >> 2, j = rr & 3;
+  const int q = i & 3, n_in = i >> 2;
+  uint32_t res = 0;
+#pragma unroll
+  for (int pz = 0; pz < 8; ++pz) {
+    const int k = kt * 16 + 2 * q + ((pz & 1) ? 8 : 0) + (pz >> 2);
+    const int n = chunk * 64 + j * 16 + ((pz >> 1) & 1) * 8 + n_in;
+    const int c = n & 7;
+    const uint32_t w = qw[(int64_t)k * (N / 8) + (n >> 3)];
+    res |= ((w >> (4 * (((c & 1) << 2) | (c >> 1)))) & 0xfu) << (4 * pz);
+  }
+  out[idx] = res;
+}
+
 struct GemmPlan {
   int mt, wn, wm, wk;  // kernel shape
   int splits, k_per_wg, m_blocks, n_blocks;
@@ -1053,6 +1097,21 @@ static int launch_gemm_gs(const GemmPlan& pl, const GemmParams& p, hipStream_t s
 #undef NMV_W8_TALL_CASE
       return -1;
     }
+    if constexpr (GS == 128) {
+      if (pl.tall && p.zp != nullptr) {
+#define NMV_ZP_TALL_CASE(mt_, wn_, wk_, ps_)                                                                \
+  if (pl.mt == mt_ && pl.wn == wn_ && pl.wk == wk_) {                                                       \
+    hipLaunchKernelGGL((w4a16_gemm_tall_kernel<T, mt_, wn_, wk_, 128, ps_, 4, true>), grid, block, 0, s, p); \
+    return 0;                                                                                               \
+  }
+        NMV_ZP_TALL_CASE(1, 4, 1, false) NMV_ZP_TALL_CASE(1, 2, 2, false) NMV_ZP_TALL_CASE(1, 1, 4, false)
+        NMV_ZP_TALL_CASE(2, 4, 1, false) NMV_ZP_TALL_CASE(2, 2, 2, false) NMV_ZP_TALL_CASE(2, 1, 4, false)
+        NMV_ZP_TALL_CASE(4, 4, 1, false) NMV_ZP_TALL_CASE(4, 2, 2, false) NMV_ZP_TALL_CASE(4, 1, 4, false)
+        NMV_ZP_TALL_CASE(8, 4, 1, true)
+#undef NMV_ZP_TALL_CASE
+        return -1;
+      }
+    }
     if (pl.tall) {
 #define NMV_W4_TALL_CASE(mt_, wn_, wk_)                                                        \
   if (pl.mt == mt_ && pl.wn == wn_ && pl.wk == wk_) {                                          \
@@ -1144,13 +1203,11 @@ extern "C" int64_t nmv_gptq_marlin_gemm_scratch_bytes(int size_m, int size_n, in
   return max_splits > 1 ? (int64_t)max_splits * size_m * size_n * 4 : 0;
 }
 
-extern "C" int nmv_gptq_marlin_gemm(void* c, const void* a, const int32_t* b_q_weight,
-                                    const void* b_scales, const int32_t* g_idx,
-                                    const int32_t* perm, int32_t* workspace,
-                                    int64_t workspace_len, void* scratch, int64_t scratch_bytes,
-                                    int num_bits, int size_m, int size_n, int size_k,
-                                    int num_groups, int is_k_full, nmv_dtype_t dtype,
-                                    void* stream) {
+static int marlin_gemm_impl(void* c, const void* a, const int32_t* b_q_weight, const void* b_scales,
+                            const void* b_zeros, const int32_t* g_idx, const int32_t* perm,
+                            int32_t* workspace, int64_t workspace_len, void* scratch,
+                            int64_t scratch_bytes, int num_bits, int size_m, int size_n, int size_k,
+                            int num_groups, int is_k_full, nmv_dtype_t dtype, void* stream) {
   // `workspace` (the reference's lock array, zero on entry and exit) holds the split-K tickets
   NMV_CHECK(dtype == NMV_F16 || dtype == NMV_BF16,
             "gpt_marlin_gemm only supports bfloat16 and float16");
@@ -1203,6 +1260,9 @@ extern "C" int nmv_gptq_marlin_gemm(void* c, const void* a, const int32_t* b_q_w
   p.b = (const uint4*)b_q_weight;
   p.s = (const uint16_t*)b_scales;
   p.perm = has_act_order ? perm : nullptr;
+  p.zp = (const uint16_t*)b_zeros;
+  NMV_CHECK(b_zeros == nullptr || (pl.tall && num_bits == 4 && group_size == 128),
+            "marlin_zp_gemm: zero points need 4-bit codes, group 128, K %% 256 == 0, no act-order");
   p.c = (uint16_t*)c;
   p.slab = (float*)scratch;
   p.tickets = workspace;
@@ -1221,6 +1281,40 @@ extern "C" int nmv_gptq_marlin_gemm(void* c, const void* a, const int32_t* b_q_w
 
 /* legacy Marlin checkpoints (csrc/quantization/marlin/dense/marlin_cuda_kernel.cu:1045-1136):
  * 4-bit, group -1 / 128, no act-order -- the same tile and scale layout as gptq_marlin */
+extern "C" int nmv_gptq_marlin_gemm(void* c, const void* a, const int32_t* b_q_weight,
+                                    const void* b_scales, const int32_t* g_idx,
+                                    const int32_t* perm, int32_t* workspace,
+                                    int64_t workspace_len, void* scratch, int64_t scratch_bytes,
+                                    int num_bits, int size_m, int size_n, int size_k,
+                                    int num_groups, int is_k_full, nmv_dtype_t dtype,
+                                    void* stream) {
+  return marlin_gemm_impl(c, a, b_q_weight, b_scales, nullptr, g_idx, perm, workspace, workspace_len,
+                          scratch, scratch_bytes, num_bits, size_m, size_n, size_k, num_groups,
+                          is_k_full, dtype, stream);
+}
+
+extern "C" int nmv_marlin_zp_gemm(void* c, const void* a, const int32_t* b_q_weight,
+                                  const void* b_scales, const void* b_zeros, int32_t* workspace,
+                                  int64_t workspace_len, void* scratch, int64_t scratch_bytes,
+                                  int size_m, int size_n, int size_k, int num_groups,
+                                  nmv_dtype_t dtype, void* stream) {
+  NMV_CHECK(b_zeros != nullptr, "marlin_zp_gemm: b_zeros is required");
+  return marlin_gemm_impl(c, a, b_q_weight, b_scales, b_zeros, nullptr, nullptr, workspace,
+                          workspace_len, scratch, scratch_bytes, 4, size_m, size_n, size_k,
+                          num_groups, 1, dtype, stream);
+}
+
+extern "C" int nmv_awq_marlin_repack(int32_t* out, const int32_t* qweight, int size_k, int size_n,
+                                     void* stream) {
+  NMV_CHECK(size_k % 16 == 0 && size_n % 64 == 0, "awq_marlin_repack: K %% 16 and N %% 64 required");
+  const int64_t total = (int64_t)(size_k / 16) * size_n * 2;
+  if (total == 0) return NMV_OK;
+  hipLaunchKernelGGL(awq_marlin_repack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, (const uint32_t*)qweight, (uint32_t*)out, size_k, size_n);
+  NMV_LAUNCH_CHECK();
+  return NMV_OK;
+}
+
 extern "C" int nmv_marlin_gemm(void* c, const void* a, const int32_t* b_q_weight,
                                const void* b_scales, int32_t* workspace, int64_t workspace_len,
                                void* scratch, int64_t scratch_bytes, int size_m, int size_n,
@@ -1229,7 +1323,7 @@ extern "C" int nmv_marlin_gemm(void* c, const void* a, const int32_t* b_q_weight
   NMV_CHECK(num_groups >= 1 && size_k % num_groups == 0, "marlin_gemm: bad number of scale groups");
   const int gs = num_groups > 1 ? size_k / num_groups : -1;
   NMV_CHECK(gs == -1 || gs == 128, "Unexpected groupsize = %d", gs);
-  return nmv_gptq_marlin_gemm(c, a, b_q_weight, b_scales, nullptr, nullptr, workspace,
-                              workspace_len, scratch, scratch_bytes, 4, size_m, size_n, size_k,
-                              num_groups, 1, dtype, stream);
+  return marlin_gemm_impl(c, a, b_q_weight, b_scales, nullptr, nullptr, nullptr, workspace,
+                          workspace_len, scratch, scratch_bytes, 4, size_m, size_n, size_k,
+                          num_groups, 1, dtype, stream);
 }

@@ -94,8 +94,11 @@ def test_gptq_method(gpu_device, desc_act):
 
 
 @pytest.mark.parametrize("m", [5, 300])
-def test_awq_method(gpu_device, m):
-    k, parts, dt = 512, [256, 128], torch.float16
+@pytest.mark.parametrize("k", [512, 384])
+def test_awq_method(gpu_device, m, k):
+    """k = 512: repacked to Marlin at load (zero-point Marlin kernel); k = 384 (not a multiple of
+    256): stays on ops.awq_gemm / dequantize + matmul like the reference"""
+    parts, dt = [256, 128], torch.float16
     layer = make_layer("awq", dict(w_bit=4, q_group_size=128, zero_point=True), k, parts, dt, gpu_device)
     g = torch.Generator().manual_seed(2)
     ws = []
@@ -108,7 +111,8 @@ def test_awq_method(gpu_device, m):
         ws.append(ref_math.awq_reference_weight(q, z, s, 128, dt))
     finish(layer)
     x = torch.randn((m, k), generator=g).to(dt)
-    out, _ = layer(x.to(gpu_device))  # m = 300 takes the dequantize + matmul branch
+    assert (getattr(layer, "awq_marlin_kn", None) is not None) == (k % 256 == 0)
+    out, _ = layer(x.to(gpu_device))  # unrepacked, m = 300 takes the dequantize + matmul branch
     assert ref_math.compute_max_diff(out.cpu(), x.float() @ torch.cat(ws, 1).float()) < 5e-3
 
 

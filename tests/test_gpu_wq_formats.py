@@ -152,3 +152,36 @@ def test_fp8_marlin_gemm(gpu_device, m, k, n, dtype):
     out = ops.fp8_marlin_gemm(a.to(d), mq, scales, ws, 8, m, n, k)
     assert rel_err(out.cpu(), a.float() @ w_ref.float()) < 0.04
     assert rel_err(out.cpu(), (a.float() @ w_ref.float()).to(dtype)) < 5e-3
+
+
+@pytest.mark.parametrize("k,n", [(256, 64), (1024, 448), (2048, 128)])
+def test_awq_marlin_repack_is_the_marlin_layout(gpu_device, k, n):
+    """AWQ words -> Marlin tensor: bit-equal to marlin_weights() of the unpacked codes"""
+    from neural_magic_vllm_amd import _custom_ops as ops
+    g = torch.Generator().manual_seed(2)
+    q = torch.randint(0, 16, (k, n), generator=g, dtype=torch.int32)
+    qweight = ref_math.pack_cols(q, 4, ref_math.AWQ_NIBBLE_OF_COLUMN).to(gpu_device)
+    out = ops.awq_marlin_repack(qweight, k, n).cpu()
+    assert torch.equal(out, ref_math.marlin_weights(q, k, n, 4))
+
+
+@pytest.mark.parametrize("m", [1, 16, 40, 70, 300])
+@pytest.mark.parametrize("k,n", [(1024, 448), (2048, 64)])
+@pytest.mark.parametrize("dtype", [torch.half, torch.bfloat16])
+def test_marlin_zp_gemm_matches_awq(gpu_device, m, k, n, dtype):
+    """asymmetric (zero-point) weights on the Marlin kernel: same answer as the AWQ definition
+    w = (q - z) * s, for every tile height the plan picks (16 / 32 / 64 / 128 rows)"""
+    from neural_magic_vllm_amd import _custom_ops as ops
+    g = torch.Generator().manual_seed(5)
+    w = torch.randn((k, n), generator=g).to(dtype)
+    a = torch.randn((m, k), generator=g).to(dtype)
+    q, z, s = ref_math.quantize_asym(w, 4, 128)
+    w_ref = ref_math.awq_reference_weight(q, z, s, 128, dtype)
+    d = gpu_device
+    mq = ref_math.marlin_weights(q, k, n, 4).to(d)
+    ms = ref_math.marlin_permute_scales(s, k, n, 128).to(d)
+    mz = ref_math.marlin_permute_scales(z.to(dtype), k, n, 128).to(d)
+    ws = torch.zeros(n // 64 * 16, dtype=torch.int32, device=d)
+    out = ops.marlin_zp_gemm(a.to(d), mq, ms, mz, ws, m, n, k)
+    assert int(ws.abs().sum()) == 0
+    assert rel_err(out.cpu(), (a.float() @ w_ref.float()).to(dtype)) < 5e-3

@@ -57,6 +57,8 @@ if __name__ == "__main__":
         gz = ri((k // gs, n // 8))
         aq = [ri((k, n // 8)) for _ in range(ncopy)]
         m8 = [ri((k // 16, n * 4)) for _ in range(max(2, ncopy // 2))]
+        m4 = [ri((k // 16, n * 2)) for _ in range(ncopy)]
+        zp = torch.randint(0, 16, (k // gs, n), device=dev, generator=gen).half()
         wsp = torch.zeros(n // 64 * 16, dtype=torch.int32, device=dev)
         e = torch.empty(0, dtype=torch.int32, device=dev)
         for m in [int(x) for x in args.ms.split(",")]:
@@ -64,6 +66,8 @@ if __name__ == "__main__":
             t_gptq = timed(lambda i: ops.gptq_gemm(a, gq[i % ncopy], gz, sc, e, True, 4))
             t_awq = timed(lambda i: ops.awq_gemm(a, aq[i % ncopy], sc, gz, 8))
             t_m8 = timed(lambda i: ops.gptq_marlin_gemm(a, m8[i % len(m8)], sc, e, e, wsp, 8, m, n, k, True))
+            t_zp = timed(lambda i: ops.marlin_zp_gemm(a, m4[i % ncopy], sc, zp, wsp, m, n, k))
             b4, b8 = k * n // 2, k * n
             print(f"{name:8s} M={m:3d}  gptq4 {t_gptq:8.1f} us {b4 / t_gptq / 1e3:6.0f} GB/s   awq4 {t_awq:8.1f} us "
-                  f"{b4 / t_awq / 1e3:6.0f} GB/s   marlin8 {t_m8:8.1f} us {b8 / t_m8 / 1e3:6.0f} GB/s", flush=True)
+                  f"{b4 / t_awq / 1e3:6.0f} GB/s   marlin8 {t_m8:8.1f} us {b8 / t_m8 / 1e3:6.0f} GB/s   "
+                  f"marlin4+zp {t_zp:8.1f} us {b4 / t_zp / 1e3:6.0f} GB/s", flush=True)
