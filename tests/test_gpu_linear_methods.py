@@ -88,6 +88,8 @@ def test_gptq_method(gpu_device, desc_act):
         layer.scales.weight_loader(layer.scales, s, i)
         ws.append(ref_math.gptq_reference_weight(q, z, s, g_idx, dt))
     finish(layer)
+    # without act-order the layer was repacked to Marlin + zero points at load; with it, exllama path
+    assert (getattr(layer, "gptq_marlin_kn", None) is not None) == (not desc_act)
     x = torch.randn((m, k), generator=g).to(dt)
     out, _ = layer(x.to(gpu_device))
     assert ref_math.compute_max_diff(out.cpu(), x.float() @ torch.cat(ws, 1).float()) < 5e-3
