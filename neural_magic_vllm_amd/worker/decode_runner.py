@@ -257,23 +257,36 @@ class DecodeRunner:
     def capture(self, warmup: int = 2) -> bool:
         """capture one decode step into a hipGraph; returns False (and stays eager) on failure"""
         saved = [t.clone() for t in (self.input_ids, self.positions, self.seq_lens, self.slot_mapping)]
+        prev_stream = torch.cuda.current_stream(self.device)
         try:
             s = torch.cuda.Stream(device=self.device)
-            s.wait_stream(torch.cuda.current_stream(self.device))
+            s.wait_stream(prev_stream)
             with torch.cuda.stream(s):
                 for _ in range(warmup):  # first touch: marlin repack, workspace moves, allocator
                     self._step_body()
-            torch.cuda.current_stream(self.device).wait_stream(s)
+            prev_stream.wait_stream(s)
             torch.cuda.synchronize(self.device)
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            # thread_local: helper threads of the process group (watchdog, event polling) may call
+            # into the runtime while this thread captures
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                 out = self._step_body()
             self.graph, self._graph_out = graph, out
             ok = True
         except Exception as e:  # pragma: no cover - depends on the runtime
-            print(f"[decode_runner] hipGraph capture failed, staying eager: {e!r}")
+            print(f"[decode_runner] hipGraph capture failed, staying eager: {str(e).splitlines()[0]}")
             self.graph = None
             ok = False
+            # torch.cuda.graph.__exit__ raises from capture_end() before it restores the stream, so
+            # the poisoned capture stream would stay current: go back to the caller's stream, then
+            # drain the error code the invalidated capture left behind for the next checked HIP call
+            torch.cuda.set_stream(prev_stream)
+            for _ in range(8):
+                try:
+                    torch.cuda.synchronize(self.device)
+                    break
+                except Exception:
+                    pass
         for dst, src in zip((self.input_ids, self.positions, self.seq_lens, self.slot_mapping), saved):
             dst.copy_(src)
         torch.cuda.synchronize(self.device)

@@ -1,0 +1,87 @@
+"""GPU, tensor parallel 2 (two processes sharing the one GPU of the test box, gloo for the
+collectives): the whole TP path that `bench.py --gpus N` runs over RCCL -- column/row-parallel
+quantised linears with sharded Marlin weights and scales, head-sharded paged attention and KV cache,
+vocab-parallel embedding / lm_head + gather -- must reproduce the single-process model."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+QUANT = dict(method="gptq_marlin", bits=4, group_size=128)
+BATCH, PROMPT, STEPS = 2, 24, 4
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _run(runner, try_capture=False):
+    """prefill + greedy decode; returns the token ids per step"""
+    runner.setup_batch(BATCH, PROMPT, STEPS + 4)
+    first = runner.prefill(PROMPT, seed=7)
+    toks = [first.cpu()]
+    runner.input_ids.copy_(first)
+    if try_capture:
+        # gloo collectives cannot be captured into a hipGraph: capture() must fail cleanly, restore
+        # the step inputs and leave the runner usable (the eager fallback bench.py relies on)
+        assert runner.capture() is False
+        runner.input_ids.copy_(first)
+    for _ in range(STEPS):
+        nxt = runner.decode_step()
+        toks.append(nxt.cpu())
+    return torch.stack(toks)
+
+
+def _worker(rank, world, port, q):
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                          WORLD_SIZE=str(world), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        import torch.distributed as dist
+        from neural_magic_vllm_amd import distributed as nd
+        from neural_magic_vllm_amd.worker import decode_runner as dr
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        nd.initialize_model_parallel(world, backend="gloo", local_rank=0)
+        dev = torch.device("cuda:0")
+        runner = dr.DecodeRunner(dr.TINY, dev, torch.bfloat16, QUANT, dr.CacheConfig(16, "auto"))
+        assert runner.tp_size == world
+        toks = _run(runner, try_capture=True)
+        if rank == 0:
+            q.put(("ok", toks.tolist()))
+        nd.destroy_model_parallel()
+        dist.destroy_process_group()
+        if rank != 0:
+            q.put(("ok", None))
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put(("err", f"rank {rank}: {e!r}\n{traceback.format_exc()}"))
+
+
+def test_tp2_matches_single_process(gpu_device):
+    from neural_magic_vllm_amd.worker import decode_runner as dr
+    ref_runner = dr.DecodeRunner(dr.TINY, gpu_device, torch.bfloat16, QUANT, dr.CacheConfig(16, "auto"))
+    ref = _run(ref_runner).tolist()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    errs = [m for s, m in res if s == "err"]
+    assert not errs, errs
+    got = [m for s, m in res if m is not None][0]
+    # greedy tokens: TP changes the fp32 summation order of the row-parallel GEMMs, so allow a rare
+    # near-tie flip but require the prefill token and at least all but one decode token to agree
+    flat_ref = [t for step in ref for t in step]
+    flat_got = [t for step in got for t in step]
+    assert flat_got[:BATCH] == flat_ref[:BATCH]
+    assert sum(a != b for a, b in zip(flat_got, flat_ref)) <= 1, (got, ref)
