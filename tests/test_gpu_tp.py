@@ -63,14 +63,16 @@ def _worker(rank, world, port, q):
         q.put(("err", f"rank {rank}: {e!r}\n{traceback.format_exc()}"))
 
 
-def test_tp2_matches_single_process(gpu_device):
+@pytest.mark.parametrize("world", [2, 4])
+def test_tp_matches_single_process(gpu_device, world):
+    """world = 4 > the tiny model's 2 KV heads: also covers KV-head replication (llama.py:109-117)"""
     from neural_magic_vllm_amd.worker import decode_runner as dr
     ref_runner = dr.DecodeRunner(dr.TINY, gpu_device, torch.bfloat16, QUANT, dr.CacheConfig(16, "auto"))
     ref = _run(ref_runner).tolist()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=240) for _ in procs]
