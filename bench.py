@@ -188,14 +188,22 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", 1))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    # rehearsal knobs (tests/test_gpu_tp.py): all ranks on one GPU with gloo collectives, to exercise
+    # this script's N > 1 path on a 1-GPU box; the measured configuration is one rank per GPU + RCCL
+    backend = os.environ.get("NMV_BENCH_DIST_BACKEND", "nccl")
+    if os.environ.get("NMV_BENCH_SINGLE_DEVICE"):
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
     import torch.distributed as dist
     from neural_magic_vllm_amd import distributed as nd
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", device_id=dev)
-        nd.initialize_model_parallel(world, backend="nccl", local_rank=local_rank)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
+        nd.initialize_model_parallel(world, backend=backend, local_rank=local_rank)
     from neural_magic_vllm_amd.worker import decode_runner as dr
     arch = {"llama3-8b": dr.LLAMA3_8B, "llama3-70b": dr.LLAMA3_70B, "tiny": dr.TINY}[args.model]
     quant = {"w4a16": dict(method="gptq_marlin", bits=4, group_size=128),

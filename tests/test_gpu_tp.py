@@ -87,3 +87,24 @@ def test_tp_matches_single_process(gpu_device, world):
     flat_got = [t for step in got for t in step]
     assert flat_got[:BATCH] == flat_ref[:BATCH]
     assert sum(a != b for a, b in zip(flat_got, flat_ref)) <= 1, (got, ref)
+
+
+def test_bench_py_multi_rank_rehearsal(gpu_device):
+    """bench.py's N > 1 path end to end (driver contract: torch.distributed.run, one JSON line from
+    rank 0) rehearsed with two ranks on this box's one GPU and gloo collectives, tiny model"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NMV_BENCH_DIST_BACKEND="gloo", NMV_BENCH_SINGLE_DEVICE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(root, "bench.py"),
+           "--gpus", "2", "--steps", "4", "--warmup", "2", "--model", "tiny", "--batch", "4", "--context", "40",
+           "--no-graph"]  # gloo collectives cannot be captured; the failed-capture fallback is tested above
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 4 and out["value"] > 0 and out["scaling"] == "strong"
+    assert out["config"]["parallelism"] == "tp2" and out["config"]["hip_graph"] is False  # gloo: eager
