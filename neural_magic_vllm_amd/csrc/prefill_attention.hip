@@ -58,8 +58,14 @@ __global__ __launch_bounds__(256) void prefill_attention_kernel(const FaParams p
   static_assert(D % 32 == 0 && D <= 256, "head size");
   constexpr int DC = D / 32;          // 32-wide head-dim chunks (MFMA k-steps of Q.K^T)
   constexpr int DT = D / 16;          // 16-wide head-dim tiles of the output
-  constexpr int VS = D + 8;           // LDS row stride of the V tile (elements): odd multiple of 16 B
-  __shared__ __attribute__((aligned(16))) uint16_t v_s[FA_KT * VS];
+  constexpr int VS = D + 8;           // LDS row stride of a K / V tile (elements): odd multiple of 16 B
+                                      // -> conflict-free ds_read_b128 rows and transposed reads
+  constexpr int TILE = FA_KT * VS;    // elements of one tile image
+  constexpr int PIECES = FA_KT * D / 8;             // 16-byte pieces of a tile
+  constexpr int PPT = (PIECES + 255) / 256;         // pieces per thread
+  static_assert(PIECES % 256 == 0, "whole pieces per thread");
+  // K and V tiles, double buffered: tile kt+1 is fetched into registers while tile kt is consumed
+  __shared__ __attribute__((aligned(16))) uint16_t kv_s[2 * 2 * TILE];
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -92,30 +98,47 @@ __global__ __launch_bounds__(256) void prefill_attention_kernel(const FaParams p
   const int n_kt = last_q / FA_KT + 1;
   const float sc = p.scale;
 
+  // tile loader: thread t owns pieces t, t+256, ... of the K and of the V tile (row = piece / (D/8))
+  uint4 kreg[PPT], vreg[PPT];
+  auto fetch = [&](int kt) {
+    const int k0 = kt * FA_KT;
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+      const int id = threadIdx.x + i * 256;
+      const int row = id / (D / 8), c8 = id % (D / 8);
+      const int64_t off = (int64_t)min(k0 + row, L - 1) * p.kv_stride + c8 * 8;   // rows past L: clamped,
+      kreg[i] = ld16(kbase + off);                                                // masked through P = 0
+      vreg[i] = ld16(vbase + off);
+    }
+  };
+  auto park = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+      const int id = threadIdx.x + i * 256;
+      const int row = id / (D / 8), c8 = id % (D / 8);
+      *reinterpret_cast<uint4*>(&kv_s[(buf * 2 + 0) * TILE + row * VS + c8 * 8]) = kreg[i];
+      *reinterpret_cast<uint4*>(&kv_s[(buf * 2 + 1) * TILE + row * VS + c8 * 8]) = vreg[i];
+    }
+  };
+  fetch(0);
+  park(0);
+  __syncthreads();
+
   for (int kt = 0; kt < n_kt; ++kt) {
     const int k0 = kt * FA_KT;
-    // ---- V tile -> LDS (all 256 threads; rows past the prompt are clamped, masked via P = 0) ----
-    __syncthreads();  // previous tile's readers are done
-    {
-      constexpr int PIECES = FA_KT * D / 8;          // 16-byte pieces
-#pragma unroll
-      for (int i = 0; i < (PIECES + 255) / 256; ++i) {
-        const int id = threadIdx.x + i * 256;
-        if (id < PIECES) {
-          const int row = id / (D / 8), c8 = id % (D / 8);
-          const uint4 x = ld16(vbase + (int64_t)min(k0 + row, L - 1) * p.kv_stride + c8 * 8);
-          *reinterpret_cast<uint4*>(&v_s[row * VS + c8 * 8]) = x;
-        }
-      }
-    }
-    // ---- S^T = K . Q^T for the 4 key tiles ----
+    const int buf = kt & 1;
+    const uint16_t* k_s = &kv_s[(buf * 2 + 0) * TILE];
+    const uint16_t* v_s = &kv_s[(buf * 2 + 1) * TILE];
+    if (kt + 1 < n_kt) fetch(kt + 1);   // uniform; lands in registers while this tile is consumed
+    // ---- S^T = K . Q^T for the 4 key tiles: K rows from LDS (shared by the 4 waves) ----
     f32x4_t s[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       s[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-      const uint16_t* kp = kbase + (int64_t)min(k0 + t * 16 + r, L - 1) * p.kv_stride + g * 8;
+      const uint16_t* kp = k_s + (t * 16 + r) * VS + g * 8;
 #pragma unroll
-      for (int c = 0; c < DC; ++c) s[t] = FaMfma<T>::run(ld16(kp + c * 32), qf[c], s[t]);
+      for (int c = 0; c < DC; ++c)
+        s[t] = FaMfma<T>::run(*reinterpret_cast<const uint4*>(kp + c * 32), qf[c], s[t]);
     }
     // ---- scale, causal / length mask, online softmax (row = this lane's query) ----
     const bool diag = k0 + FA_KT - 1 > qt0;   // uniform: only tiles that reach past the first query
@@ -152,7 +175,6 @@ __global__ __launch_bounds__(256) void prefill_attention_kernel(const FaParams p
     m_run = m_new;
 #pragma unroll
     for (int t = 0; t < DT; ++t) o[t] *= alpha;
-    __syncthreads();  // V tile is in LDS
     // ---- O^T += V^T . P^T : two 32-key steps, DT output tiles ----
 #pragma unroll
     for (int st = 0; st < 2; ++st) {
@@ -169,6 +191,8 @@ __global__ __launch_bounds__(256) void prefill_attention_kernel(const FaParams p
         o[t] = FaMfma<T>::run(make_uint4(lo2.x, lo2.y, hi2.x, hi2.y), pb, o[t]);
       }
     }
+    if (kt + 1 < n_kt) park(buf ^ 1);   // the other buffer's readers finished before the last barrier
+    __syncthreads();
   }
   // ---- normalise and store: lane (q = r, g) holds d = 16 t + 4 g + i of its row ----
   l_run += __shfl_xor(l_run, 16, 64);
