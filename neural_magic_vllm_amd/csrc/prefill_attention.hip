@@ -53,8 +53,11 @@ struct FaParams {
   float scale;
 };
 
-template <typename T, int D>
+// QU = 16-query sub-tiles per wave: 1 (64 queries per workgroup; short prompts, more workgroups) or
+// 2 (128 queries: every K / V operand read from LDS feeds two MFMAs).
+template <typename T, int D, int QU>
 __global__ __launch_bounds__(256) void prefill_attention_kernel(const FaParams p) {
+  constexpr int QT = FA_QT * QU;      // queries per workgroup
   static_assert(D % 32 == 0 && D <= 256, "head size");
   constexpr int DC = D / 32;          // 32-wide head-dim chunks (MFMA k-steps of Q.K^T)
   constexpr int DT = D / 16;          // 16-wide head-dim tiles of the output
@@ -74,27 +77,34 @@ __global__ __launch_bounds__(256) void prefill_attention_kernel(const FaParams p
   const int kv_head = head / (p.num_heads / p.num_kv_heads);
   const int tok0 = p.cu_seqlens[seq];
   const int L = p.cu_seqlens[seq + 1] - tok0;
-  const int qt0 = blockIdx.x * FA_QT;
+  const int qt0 = blockIdx.x * QT;
   if (qt0 >= L) return;  // uniform
   const int tr_off = (4 * g + (r >> 2)) * VS + 4 * (r & 3);  // this lane's address role in a tr read
-  const int q_row = qt0 + wave * 16 + r;           // this lane's query (prompt-relative)
-  const int q_row_c = min(q_row, L - 1);
+  int q_row[QU];                                   // this lane's queries (prompt-relative)
+#pragma unroll
+  for (int u = 0; u < QU; ++u) q_row[u] = qt0 + (wave * QU + u) * 16 + r;
 
-  // ---- Q fragment of the wave (B operand of S^T = K . Q^T): 8 head dims per lane and chunk ----
-  uint4 qf[DC];
-  {
-    const uint16_t* qp = p.q + (int64_t)(tok0 + q_row_c) * p.q_stride + (int64_t)head * D + g * 8;
+  // ---- Q fragments of the wave (B operand of S^T = K . Q^T): 8 head dims per lane and chunk ----
+  uint4 qf[QU][DC];
 #pragma unroll
-    for (int c = 0; c < DC; ++c) qf[c] = ld16(qp + c * 32);
+  for (int u = 0; u < QU; ++u) {
+    const uint16_t* qp = p.q + (int64_t)(tok0 + min(q_row[u], L - 1)) * p.q_stride + (int64_t)head * D + g * 8;
+#pragma unroll
+    for (int c = 0; c < DC; ++c) qf[u][c] = ld16(qp + c * 32);
   }
-  f32x4_t o[DT];
+  f32x4_t o[QU][DT];
+  float m_run[QU], l_run[QU];             // per lane = per query row (l: this lane's share)
 #pragma unroll
-  for (int t = 0; t < DT; ++t) o[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  float m_run = -INFINITY, l_run = 0.f;   // per lane = per query row (l: this lane's share)
+  for (int u = 0; u < QU; ++u) {
+    m_run[u] = -INFINITY;
+    l_run[u] = 0.f;
+#pragma unroll
+    for (int t = 0; t < DT; ++t) o[u][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  }
 
   const uint16_t* kbase = p.k + (int64_t)tok0 * p.kv_stride + (int64_t)kv_head * D;
   const uint16_t* vbase = p.v + (int64_t)tok0 * p.kv_stride + (int64_t)kv_head * D;
-  const int last_q = min(qt0 + FA_QT, L) - 1;      // causal: keys 0 .. last_q
+  const int last_q = min(qt0 + QT, L) - 1;         // causal: keys 0 .. last_q
   const int n_kt = last_q / FA_KT + 1;
   const float sc = p.scale;
 
@@ -131,54 +141,60 @@ __global__ __launch_bounds__(256) void prefill_attention_kernel(const FaParams p
     const uint16_t* v_s = &kv_s[(buf * 2 + 1) * TILE];
     if (kt + 1 < n_kt) fetch(kt + 1);   // uniform; lands in registers while this tile is consumed
     // ---- S^T = K . Q^T for the 4 key tiles: K rows from LDS (shared by the 4 waves) ----
-    f32x4_t s[4];
+    f32x4_t s[QU][4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      s[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int u = 0; u < QU; ++u) s[u][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
       const uint16_t* kp = k_s + (t * 16 + r) * VS + g * 8;
 #pragma unroll
-      for (int c = 0; c < DC; ++c)
-        s[t] = FaMfma<T>::run(*reinterpret_cast<const uint4*>(kp + c * 32), qf[c], s[t]);
+      for (int c = 0; c < DC; ++c) {
+        const uint4 kf = *reinterpret_cast<const uint4*>(kp + c * 32);
+#pragma unroll
+        for (int u = 0; u < QU; ++u) s[u][t] = FaMfma<T>::run(kf, qf[u][c], s[u][t]);
+      }
     }
     // ---- scale, causal / length mask, online softmax (row = this lane's query) ----
     const bool diag = k0 + FA_KT - 1 > qt0;   // uniform: only tiles that reach past the first query
-    float mx = -INFINITY;
+    uint32_t pp[QU][8];                              // packed P: [t][pair]
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int u = 0; u < QU; ++u) {
+      float mx = -INFINITY;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int key = k0 + t * 16 + 4 * g + i;
-        float x = s[t][i] * sc;
-        if (diag && (key > q_row || key >= L)) x = -INFINITY;
-        s[t][i] = x;
-        mx = fmaxf(mx, x);
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int key = k0 + t * 16 + 4 * g + i;
+          float x = s[u][t][i] * sc;
+          if (diag && (key > q_row[u] || key >= L)) x = -INFINITY;
+          s[u][t][i] = x;
+          mx = fmaxf(mx, x);
+        }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run[u], mx);        // finite: key 0 is visible to every query
+      const float alpha = __expf(m_run[u] - m_new);
+      float psum = 0.f;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        float e[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          e[i] = __expf(s[u][t][i] - m_new);
+          e[i] = T::to_float(T::from_float(e[i]));  // P in the model dtype, and the sum of the same
+          psum += e[i];
+        }
+        pp[u][2 * t] = T::pack2(e[0], e[1]);
+        pp[u][2 * t + 1] = T::pack2(e[2], e[3]);
       }
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);           // finite: key 0 is visible to every query
-    const float alpha = __expf(m_run - m_new);
-    float psum = 0.f;
-    uint32_t pp[8];                                  // packed P: [t][pair]
+      l_run[u] = l_run[u] * alpha + psum;
+      m_run[u] = m_new;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      float e[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        e[i] = __expf(s[t][i] - m_new);
-        e[i] = T::to_float(T::from_float(e[i]));    // P in the model dtype, and the sum of the same
-        psum += e[i];
-      }
-      pp[2 * t] = T::pack2(e[0], e[1]);
-      pp[2 * t + 1] = T::pack2(e[2], e[3]);
+      for (int t = 0; t < DT; ++t) o[u][t] *= alpha;
     }
-    l_run = l_run * alpha + psum;
-    m_run = m_new;
-#pragma unroll
-    for (int t = 0; t < DT; ++t) o[t] *= alpha;
     // ---- O^T += V^T . P^T : two 32-key steps, DT output tiles ----
 #pragma unroll
     for (int st = 0; st < 2; ++st) {
-      const uint4 pb = make_uint4(pp[4 * st], pp[4 * st + 1], pp[4 * st + 2], pp[4 * st + 3]);
 #pragma unroll
       for (int t = 0; t < DT; ++t) {
         // A operand: V^T row d = 16 t + r, keys 32 st + {4g..4g+3, 16+4g..16+4g+3}: two hardware
@@ -188,24 +204,31 @@ __global__ __launch_bounds__(256) void prefill_attention_kernel(const FaParams p
         const v4s_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_t*)vp);
         const v4s_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_t*)(vp + 16 * VS));
         const uint2 lo2 = __builtin_bit_cast(uint2, lo), hi2 = __builtin_bit_cast(uint2, hi);
-        o[t] = FaMfma<T>::run(make_uint4(lo2.x, lo2.y, hi2.x, hi2.y), pb, o[t]);
+        const uint4 vf = make_uint4(lo2.x, lo2.y, hi2.x, hi2.y);
+#pragma unroll
+        for (int u = 0; u < QU; ++u)
+          o[u][t] = FaMfma<T>::run(vf, make_uint4(pp[u][4 * st], pp[u][4 * st + 1], pp[u][4 * st + 2], pp[u][4 * st + 3]), o[u][t]);
       }
     }
     if (kt + 1 < n_kt) park(buf ^ 1);   // the other buffer's readers finished before the last barrier
     __syncthreads();
   }
-  // ---- normalise and store: lane (q = r, g) holds d = 16 t + 4 g + i of its row ----
-  l_run += __shfl_xor(l_run, 16, 64);
-  l_run += __shfl_xor(l_run, 32, 64);
-  if (q_row >= L) return;
-  const float inv = 1.f / l_run;
-  uint16_t* op = p.out + (int64_t)(tok0 + q_row) * p.o_stride + (int64_t)head * D + 4 * g;
+  // ---- normalise and store: lane (q = r, g) holds d = 16 t + 4 g + i of its rows ----
 #pragma unroll
-  for (int t = 0; t < DT; ++t) {
-    uint2 pk;
-    pk.x = T::pack2(o[t][0] * inv, o[t][1] * inv);
-    pk.y = T::pack2(o[t][2] * inv, o[t][3] * inv);
-    *reinterpret_cast<uint2*>(op + 16 * t) = pk;
+  for (int u = 0; u < QU; ++u) {
+    float l = l_run[u];
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    if (q_row[u] >= L) continue;
+    const float inv = 1.f / l;
+    uint16_t* op = p.out + (int64_t)(tok0 + q_row[u]) * p.o_stride + (int64_t)head * D + 4 * g;
+#pragma unroll
+    for (int t = 0; t < DT; ++t) {
+      uint2 pk;
+      pk.x = T::pack2(o[u][t][0] * inv, o[u][t][1] * inv);
+      pk.y = T::pack2(o[u][t][2] * inv, o[u][t][3] * inv);
+      *reinterpret_cast<uint2*>(op + 16 * t) = pk;
+    }
   }
 }
 
@@ -367,15 +390,18 @@ extern "C" int nmv_prefill_attention(void* out, const void* q, const void* k, co
   if (num_seqs <= 0 || max_seq_len <= 0) return NMV_OK;
   FaParams p{(const uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v, (uint16_t*)out, cu_seqlens,
              q_stride, kv_stride, o_stride, num_heads, num_kv_heads, scale};
-  dim3 grid((max_seq_len + FA_QT - 1) / FA_QT, num_heads, num_seqs), block(256);
   hipStream_t s = (hipStream_t)stream;
+  // QU = 2 (128-query workgroups, each K / V operand feeding two MFMAs) was measured slower at every
+  // size (L = 8192: 2.09 ms vs 1.44 ms: twice the registers, more masked work on the diagonal)
+  const int qu = 1;
+  dim3 grid((max_seq_len + FA_QT * qu - 1) / (FA_QT * qu), num_heads, num_seqs), block(256);
+#define NMV_FA_LAUNCH(T_, D_) hipLaunchKernelGGL((prefill_attention_kernel<T_, D_, 1>), grid, block, 0, s, p);
   if (dtype == NMV_BF16) {
-    if (head_size == 64) hipLaunchKernelGGL((prefill_attention_kernel<BF16, 64>), grid, block, 0, s, p);
-    else hipLaunchKernelGGL((prefill_attention_kernel<BF16, 128>), grid, block, 0, s, p);
+    if (head_size == 64) NMV_FA_LAUNCH(BF16, 64) else NMV_FA_LAUNCH(BF16, 128)
   } else {
-    if (head_size == 64) hipLaunchKernelGGL((prefill_attention_kernel<F16, 64>), grid, block, 0, s, p);
-    else hipLaunchKernelGGL((prefill_attention_kernel<F16, 128>), grid, block, 0, s, p);
+    if (head_size == 64) NMV_FA_LAUNCH(F16, 64) else NMV_FA_LAUNCH(F16, 128)
   }
+#undef NMV_FA_LAUNCH
   NMV_LAUNCH_CHECK();
   return NMV_OK;
 }

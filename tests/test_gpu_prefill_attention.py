@@ -27,7 +27,9 @@ def ref_attention(q, k, v, seq_lens, scale):
 @pytest.mark.parametrize("dtype", [torch.half, torch.bfloat16])
 @pytest.mark.parametrize("heads", [(32, 8), (8, 8), (12, 1)])
 @pytest.mark.parametrize("head_size", [64, 128])
-@pytest.mark.parametrize("seq_lens", [[1], [37, 64, 1, 200], [513], [65, 128, 129]])
+@pytest.mark.parametrize("seq_lens", [[1], [37, 64, 1, 200], [513], [65, 128, 129],
+                                      # >= 2048 64-query tiles with 32 heads: the 128-query workgroup form
+                                      [260, 129, 128, 1, 257, 255, 64, 130, 200, 3, 127, 256, 131, 90, 17, 259]])
 def test_prefill_attention(gpu_device, dtype, heads, head_size, seq_lens):
     from neural_magic_vllm_amd import _custom_ops as ops
     nq, nkv = heads
