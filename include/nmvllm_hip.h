@@ -276,11 +276,17 @@ int nmv_scaled_fp8_quant(void* out, const void* input, float* scale, int64_t num
 
 /* cutlass_scaled_mm (scaled_mm_entry.cu:48-100): out[M,N] = a_scales * (b_scales * (a . b)) + bias.
  * a [M,K] row-major (lda), b column-major = [N,K] row-major (ldb = b.stride(1)), out row-major
- * (ldc); scales fp32 with numel 1 (per tensor) or M / N; bias in out_dtype or NULL. */
+ * (ldc); scales fp32 with numel 1 (per tensor) or M / N; bias in out_dtype or NULL.
+ * scratch: optional device buffer of nmv_scaled_mm_scratch_bytes(M, N, K) bytes for the split-K
+ * slabs used at M > 32 on long-K shapes; NULL / too small => the kernel runs unsplit (same result
+ * for int8, fp32 summation order differs for fp8).  The reference allocates its CUTLASS workspace
+ * inside the op the same way. */
+int64_t nmv_scaled_mm_scratch_bytes(int M, int N, int K);
 int nmv_scaled_mm(void* out, const void* a, const void* b, const float* a_scales,
                   const float* b_scales, const void* bias, int M, int N, int K, int64_t lda,
                   int64_t ldb, int64_t ldc, int a_scales_numel, int b_scales_numel,
-                  nmv_q8_dtype_t in_dtype, nmv_dtype_t out_dtype, void* stream);
+                  nmv_q8_dtype_t in_dtype, nmv_dtype_t out_dtype, void* scratch,
+                  int64_t scratch_bytes, void* stream);
 
 /* cutlass_scaled_mm_supports_fp8 (scaled_mm_entry.cu:32-46) */
 int nmv_cutlass_scaled_mm_supports_fp8(int64_t cuda_device_capability);

@@ -74,7 +74,8 @@ SIGNATURES = {
     "nmv_awq_dequantize": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "nmv_scaled_int8_quant": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "nmv_scaled_fp8_quant": (_I, [_P, _P, _P, _L, _I, _I, _P]),
-    "nmv_scaled_mm": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _L, _L, _L, _I, _I, _I, _I, _P]),
+    "nmv_scaled_mm": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _L, _L, _L, _I, _I, _I, _I, _P, _L, _P]),
+    "nmv_scaled_mm_scratch_bytes": (_L, [_I, _I, _I]),
     "nmv_cutlass_scaled_mm_supports_fp8": (_I, [_L]),
     "nmv_get_device_attribute": (_L, [_L, _L]),
     "nmv_get_max_shared_memory_per_block_device_attribute": (_L, [_L]),

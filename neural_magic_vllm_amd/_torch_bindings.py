@@ -507,10 +507,13 @@ def cutlass_scaled_mm(out, a, b, a_scales, b_scales, bias) -> None:
     m, k = a.shape
     n = b.shape[1]
     with device_guard(a):
-        check(_lib.load().nmv_scaled_mm(ptr(out), ptr(a), ptr(b), ptr(a_scales), ptr(b_scales),
-                                        ptr(bias), m, n, k, a.stride(0), b.stride(1),
-                                        out.stride(0), a_scales.numel(), b_scales.numel(), q,
-                                        dtype_code(out.dtype), stream_of(a)))
+        lib = _lib.load()
+        sb = lib.nmv_scaled_mm_scratch_bytes(m, n, k)
+        scratch = torch.empty(sb, dtype=torch.uint8, device=a.device) if sb else None
+        check(lib.nmv_scaled_mm(ptr(out), ptr(a), ptr(b), ptr(a_scales), ptr(b_scales),
+                                ptr(bias), m, n, k, a.stride(0), b.stride(1),
+                                out.stride(0), a_scales.numel(), b_scales.numel(), q,
+                                dtype_code(out.dtype), ptr(scratch), sb, stream_of(a)))
 
 
 # ----------------------------------------------------------------------------- cache ops

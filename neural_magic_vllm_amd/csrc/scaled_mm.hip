@@ -15,6 +15,8 @@
 // of a workgroup split K and reduce through LDS; no cross-workgroup reduction.
 // HBM-bound: algorithmic bytes K*N + M*K + 2*M*N + 4*(M+N).
 #include "common.h"
+#include <type_traits>
+#include <cstdlib>
 
 namespace nmv {
 
@@ -30,6 +32,9 @@ struct MMParams {
   int M, N, K;
   int64_t lda, ldb, ldc;
   int a_per_row, b_per_col;  // 1: per-token / per-channel scales, 0: per-tensor
+  // split-K over blockIdx.z (M > 32): raw int32 / fp32 partials in slab[splits][M][N]
+  int splits, k_per_split;
+  void* slab;
 };
 
 template <bool FP8> struct Acc;
@@ -67,10 +72,12 @@ __global__ __launch_bounds__(MM_THREADS) void scaled_mm_kernel(const MMParams p)
   const int r = lane & 15, g = lane >> 4;
   const int n0 = blockIdx.x * (16 * NT);
   const int m0 = blockIdx.y * (16 * MT);
-  // K split over the 4 waves in multiples of 64
-  const int ksteps = (p.K + 63) / 64;
+  // K split over blockIdx.z (k_per_split, a multiple of 64) and then over the 4 waves, in
+  // multiples of 64
+  const int split_s0 = blockIdx.z * (p.k_per_split / 64);
+  const int ksteps = min((p.K + 63) / 64, split_s0 + p.k_per_split / 64) - split_s0;
   const int per_wave = (ksteps + 3) / 4;
-  const int ks0 = wave * per_wave, ks1 = min(ks0 + per_wave, ksteps);
+  const int ks0 = split_s0 + wave * per_wave, ks1 = min(ks0 + per_wave, split_s0 + ksteps);
 
   const uint8_t* wp[NT];
 #pragma unroll
@@ -132,6 +139,28 @@ __global__ __launch_bounds__(MM_THREADS) void scaled_mm_kernel(const MMParams p)
   for (int j = 0; j < NT; ++j) {
     const int nb = n0 + j * 16 + 4 * g;
     if (nb >= p.N) continue;
+    if (p.splits > 1) {  // raw partial sums; scaled_mm_reduce_kernel finishes
+      elem_t* slab = reinterpret_cast<elem_t*>(p.slab) + (int64_t)blockIdx.z * p.M * p.N;
+#pragma unroll
+      for (int t = 0; t < MT; ++t) {
+        const int m = m0 + t * 16 + r;
+        if (m >= p.M) continue;
+        typename A::type v = acc[j][t];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int ww = 0; ww < 3; ++ww) v[i] += redt[ww][j][t][i][lane];
+        elem_t* dst = slab + (int64_t)m * p.N + nb;
+        if (nb + 3 < p.N && (p.N & 3) == 0) {
+          *reinterpret_cast<typename A::type*>(dst) = v;
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (nb + i < p.N) dst[i] = v[i];
+        }
+      }
+      continue;
+    }
     float bs[4], bv[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -167,25 +196,98 @@ __global__ __launch_bounds__(MM_THREADS) void scaled_mm_kernel(const MMParams p)
   }
 }
 
+
+// sums the split-K slabs in the accumulator's own type, then the same epilogue arithmetic
 template <typename T, bool FP8>
-static void launch_mm(const MMParams& p, hipStream_t s) {
+__global__ __launch_bounds__(256) void scaled_mm_reduce_kernel(const MMParams p) {
+  using elem_t = typename std::conditional<FP8, float, int>::type;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int n4 = (p.N + 3) / 4;
+  if (idx >= (int64_t)p.M * n4) return;
+  const int m = (int)(idx / n4), nb = (int)(idx % n4) * 4;
+  const elem_t* src = reinterpret_cast<const elem_t*>(p.slab) + (int64_t)m * p.N + nb;
+  const int64_t slab_stride = (int64_t)p.M * p.N;
+  const float as = p.a_scales[p.a_per_row ? m : 0];
+  uint16_t* dst = reinterpret_cast<uint16_t*>(p.out) + (int64_t)m * p.ldc + nb;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (nb + i >= p.N) break;
+    elem_t v = 0;
+    for (int s = 0; s < p.splits; ++s) v += src[s * slab_stride + i];
+    const float bs = p.b_scales[p.b_per_col ? nb + i : 0];
+    const float bv = p.bias ? T::to_float(reinterpret_cast<const uint16_t*>(p.bias)[nb + i]) : 0.f;
+    dst[i] = T::from_float(fmaf(as, bs * (float)v, bv));
+  }
+}
+
+struct MMPlan {
+  int mt, nt, un;  // tiles per wave, 64-byte k-steps in flight
+  int splits, k_per_split;
+};
+
+static int env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+
+// Tile and split-K choice, by shape (Llama-3-8B projections measured on MI355X).
+static MMPlan mm_plan(int M, int N, int K, int64_t scratch_bytes) {
+  MMPlan pl{1, 1, 4, 1, K};
+  const int n16 = (N + 15) / 16;
+  int splits = 1;
+  if (M <= 16) {
+    // one column tile per wave: pure weight streaming (4.9 TB/s on gate_up)
+  } else if (M <= 32) {
+    pl.mt = 2, pl.nt = n16 >= 1024 ? 2 : 1;
+  } else {
+    // Every activation fragment a wave loads is reused for NT column tiles, so the L2 traffic for
+    // activations is 4/NT x the weight bytes: take the widest NT that still leaves >= 192
+    // workgroups; a long K (down_proj) keeps NT = 4 and reaches that count with split-K slabs
+    // instead (the reduce launch costs ~3 us, which a short K does not repay).
+    const int m_blocks = (M + 63) / 64;
+    pl.mt = 4;
+    for (pl.nt = 4; pl.nt > 1; pl.nt >>= 1) {
+      const int base = ((n16 + pl.nt - 1) / pl.nt) * m_blocks;
+      if (base >= 192) break;
+      if (pl.nt == 4 && K >= 8192) {
+        while (splits < 4 && base * splits < 256) splits *= 2;
+        break;
+      }
+    }
+    const int nt = env_int("NMV_MM_NT", 0);
+    if (nt == 1 || nt == 2 || nt == 4) pl.nt = nt;
+    splits = max(1, env_int("NMV_MM_SPLITS", splits));
+    pl.un = pl.nt == 1 ? 4 : 2;
+  }
+  if ((int64_t)splits * M * N * 4 > scratch_bytes) splits = 1;
+  int kps = (K + splits - 1) / splits;
+  kps = (kps + 63) / 64 * 64;
+  pl.splits = (K + kps - 1) / kps;
+  pl.k_per_split = kps;
+  return pl;
+}
+
+template <typename T, bool FP8>
+static void launch_mm(MMParams p, const MMPlan& pl, hipStream_t s) {
+  p.splits = pl.splits;
+  p.k_per_split = pl.k_per_split;
 #define MM_CASE(MT_, NT_, UN_)                                                                       \
-  {                                                                                                  \
-    dim3 grid((p.N + 16 * NT_ - 1) / (16 * NT_), (p.M + 16 * MT_ - 1) / (16 * MT_));                 \
+  if (pl.mt == MT_ && pl.nt == NT_) {                                                                \
+    dim3 grid((p.N + 16 * NT_ - 1) / (16 * NT_), (p.M + 16 * MT_ - 1) / (16 * MT_), pl.splits);      \
     hipLaunchKernelGGL((scaled_mm_kernel<T, FP8, MT_, NT_, UN_>), grid, dim3(MM_THREADS), 0, s, p);  \
   }
-  // wide enough to keep >= ~256 workgroups: more columns per wave (activation reuse)
-  const int n16 = (p.N + 15) / 16;
-  // measured on the Llama-3-8B shapes: one column tile per wave is best at M <= 16 (weight
-  // streaming, 4.9 TB/s on gate_up), reuse pays from M = 32 on the wide projections
-  if (p.M <= 16) {
-    MM_CASE(1, 1, 4)
-  } else if (p.M <= 32) {
-    if (n16 >= 1024) MM_CASE(2, 2, 4) else MM_CASE(2, 1, 4)
-  } else {
-    if (n16 >= 1024) MM_CASE(4, 4, 2) else if (n16 >= 384) MM_CASE(4, 2, 2) else MM_CASE(4, 1, 4)
-  }
+  MM_CASE(1, 1, 4)
+  MM_CASE(2, 1, 4)
+  MM_CASE(2, 2, 4)
+  MM_CASE(4, 1, 4)
+  MM_CASE(4, 2, 2)
+  MM_CASE(4, 4, 2)
 #undef MM_CASE
+  if (pl.splits > 1) {
+    const int64_t items = (int64_t)p.M * ((p.N + 3) / 4);
+    hipLaunchKernelGGL((scaled_mm_reduce_kernel<T, FP8>), dim3((unsigned)((items + 255) / 256)),
+                       dim3(256), 0, s, p);
+  }
 }
 
 }  // namespace nmv
@@ -197,11 +299,18 @@ extern "C" int nmv_cutlass_scaled_mm_supports_fp8(int64_t cuda_device_capability
   return cuda_device_capability >= 89 ? 1 : 0;
 }
 
+// split-K slabs (M > 32): at most 4 x [M, N] x 4 bytes; without scratch (null) the kernels run
+// unsplit
+extern "C" int64_t nmv_scaled_mm_scratch_bytes(int M, int N, int K) {
+  const MMPlan pl = mm_plan(M, N, K, INT64_MAX);
+  return pl.splits > 1 ? (int64_t)pl.splits * M * N * 4 : 0;
+}
+
 extern "C" int nmv_scaled_mm(void* out, const void* a, const void* b, const float* a_scales,
                              const float* b_scales, const void* bias, int M, int N, int K,
                              int64_t lda, int64_t ldb, int64_t ldc, int a_scales_numel,
                              int b_scales_numel, nmv_q8_dtype_t in_dtype, nmv_dtype_t out_dtype,
-                             void* stream) {
+                             void* scratch, int64_t scratch_bytes, void* stream) {
   NMV_CHECK(out_dtype == NMV_F16 || out_dtype == NMV_BF16, "cutlass_scaled_mm: out must be fp16/bf16");
   NMV_CHECK(in_dtype == NMV_I8 || in_dtype == NMV_FP8_E4M3, "cutlass_scaled_mm: a/b must be int8 or fp8_e4m3");
   NMV_CHECK(a_scales_numel == 1 || a_scales_numel == M, "cutlass_scaled_mm: a_scales.numel() must be 1 or M");
@@ -212,12 +321,13 @@ extern "C" int nmv_scaled_mm(void* out, const void* a, const void* b, const floa
   if (M == 0 || N == 0) return NMV_OK;
   MMParams p{(const uint8_t*)a, (const uint8_t*)b, out, a_scales, b_scales, bias, M, N, K,
              lda, ldb, ldc, a_scales_numel == M && M > 1 ? 1 : (a_scales_numel == M ? 1 : 0),
-             b_scales_numel == N && N > 1 ? 1 : (b_scales_numel == N ? 1 : 0)};
+             b_scales_numel == N && N > 1 ? 1 : (b_scales_numel == N ? 1 : 0), 1, K, scratch};
   hipStream_t s = (hipStream_t)stream;
+  const MMPlan pl = mm_plan(M, N, K, scratch ? scratch_bytes : 0);
   if (in_dtype == NMV_I8) {
-    if (out_dtype == NMV_F16) launch_mm<F16, false>(p, s); else launch_mm<BF16, false>(p, s);
+    if (out_dtype == NMV_F16) launch_mm<F16, false>(p, pl, s); else launch_mm<BF16, false>(p, pl, s);
   } else {
-    if (out_dtype == NMV_F16) launch_mm<F16, true>(p, s); else launch_mm<BF16, true>(p, s);
+    if (out_dtype == NMV_F16) launch_mm<F16, true>(p, pl, s); else launch_mm<BF16, true>(p, pl, s);
   }
   NMV_LAUNCH_CHECK();
   return NMV_OK;

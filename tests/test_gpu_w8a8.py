@@ -153,3 +153,35 @@ def test_cutlass_scaled_mm_strided_output_and_checks(gpu_device):
         torch.ops._C.cutlass_scaled_mm(torch.empty((m, n), dtype=torch.bfloat16, device=d), a.to(d),
                                        bt.t().contiguous().to(d), sa.to(d), sb.to(d), None)
     assert ops.cutlass_scaled_mm_supports_fp8(95) and not ops.cutlass_scaled_mm_supports_fp8(80)
+
+
+@pytest.mark.parametrize("kind", ["int8", "fp8"])
+@pytest.mark.parametrize("m,n,k", [(64, 4096, 4096), (512, 6144, 4096), (130, 208, 14336), (48, 4096, 14336),
+                                   (300, 1008, 2064), (2048, 512, 1024), (64, 4096, 14336)])
+def test_cutlass_scaled_mm_split_k_and_tiles(gpu_device, monkeypatch, kind, m, n, k):
+    """M > 32: the per-wave column-tile count NT and the split-K slab count are chosen by shape.
+    int8 accumulates exactly in int32 whatever the split, so every variant is bit-identical; fp8
+    differs in fp32 summation order only.  All are checked against the oracle as well."""
+    from neural_magic_vllm_amd import _custom_ops as ops
+    g = torch.Generator().manual_seed(3)
+    conv = to_int8 if kind == "int8" else to_fp8
+    a = conv(torch.randn((m, k), generator=g) * (20 if kind == "int8" else 1))
+    bt = conv(torch.randn((n, k), generator=g) * (20 if kind == "int8" else 1))
+    sa = torch.rand((m, 1), generator=g) / 100
+    sb = torch.rand((1, n), generator=g) / 100
+    bias = torch.randn((n, ), generator=g).to(torch.bfloat16)
+    d = gpu_device
+    args = (a.to(d), bt.to(d).t(), sa.to(d), sb.to(d), torch.bfloat16, bias.to(d))
+    outs = [ops.cutlass_scaled_mm(*args).cpu()]
+    for nt, splits in ((1, 1), (2, 3), (4, 4), (4, 1)):
+        monkeypatch.setenv("NMV_MM_NT", str(nt))
+        monkeypatch.setenv("NMV_MM_SPLITS", str(splits))
+        outs.append(ops.cutlass_scaled_mm(*args).cpu())
+    ref = oracle.scaled_mm(a, bt.t(), sa, sb, torch.bfloat16, bias)
+    if kind == "int8":
+        for i, o in enumerate(outs[1:]):
+            assert torch.equal(outs[0].view(torch.int16), o.view(torch.int16)), i
+        assert torch.allclose(outs[0].float(), ref.float(), rtol=2**-7 * 1.01, atol=1e-3)
+    else:
+        for o in outs:
+            assert torch.allclose(o.float(), ref.float(), rtol=2**-7 * 1.01, atol=2e-2)
