@@ -149,6 +149,33 @@ int nmv_activation(void* out, const void* input, int num_tokens, int d, int act,
                    nmv_dtype_t dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Fused decode-step launches.  Not ops of nm-vllm 0.5.1 (which launches the parts separately; later
+ * vLLM grew similar fusions): each is bit-identical to the sequence of reference ops it names and
+ * exists because a launch on a [B, hidden] tensor is ~5 us of latency, not bandwidth.
+ * ------------------------------------------------------------------------------------------ */
+/* rotary_embedding (pos_encoding_kernels.cu:121-160) followed by reshape_and_cache
+ * (cache_kernels.cu:253-278): query / key rotated in place, then key / value of every token with
+ * slot_mapping[t] >= 0 written to the paged cache. */
+int nmv_rotary_embedding_and_cache(const int64_t* positions, void* query, void* key,
+                                   const void* value, int num_tokens, int num_heads,
+                                   int num_kv_heads, int head_size, int rot_dim, int64_t query_stride,
+                                   int64_t key_stride, int64_t value_stride,
+                                   const void* cos_sin_cache, int is_neox, void* key_cache,
+                                   void* value_cache, const int64_t* slot_mapping, int block_size,
+                                   nmv_dtype_t dtype, nmv_kv_dtype_t kv_dtype, float kv_scale,
+                                   void* stream);
+/* rms_norm (residual == NULL) or fused_add_rms_norm (residual updated in place, input untouched)
+ * followed by dynamic per-token scaled_int8_quant (int8_quant_kernels.cu:37-75): out_q int8
+ * [num_tokens, hidden], scales float [num_tokens].  hidden % 8 == 0, hidden <= 8192. */
+int nmv_rms_norm_dynamic_int8_quant(void* out_q, float* scales, const void* input, void* residual,
+                                    const void* weight, float epsilon, int num_tokens,
+                                    int hidden_size, nmv_dtype_t dtype, void* stream);
+/* silu_and_mul followed by dynamic per-token scaled_int8_quant: input [num_tokens, 2*d] ->
+ * out_q int8 [num_tokens, d], scales float [num_tokens].  d % 8 == 0, d <= 32768. */
+int nmv_silu_and_mul_dynamic_int8_quant(void* out_q, float* scales, const void* input,
+                                        int num_tokens, int d, nmv_dtype_t dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * W4A16 / W8A16 (GPTQ-Marlin format)  (csrc/ops.h:86-94, csrc/quantization/gptq_marlin/)
  * ---------------------------------------------------------------------------------------- */
 

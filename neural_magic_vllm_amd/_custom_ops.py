@@ -301,3 +301,26 @@ def marlin_zp_gemm(a: torch.Tensor, b_q_weight: torch.Tensor, b_scales: torch.Te
                    size_k: int) -> torch.Tensor:
     from neural_magic_vllm_amd import _torch_bindings as tb
     return tb.marlin_zp_gemm(a, b_q_weight, b_scales, b_zeros, workspace, size_m, size_n, size_k)
+
+
+# fused decode-step launches (not ops of nm-vllm 0.5.1; each is bit-identical to the sequence of
+# reference ops it replaces -- see include/nmvllm_hip.h)
+def rotary_embedding_and_cache(positions: torch.Tensor, query: torch.Tensor, key: torch.Tensor,
+                               value: torch.Tensor, head_size: int, cos_sin_cache: torch.Tensor,
+                               is_neox: bool, key_cache: torch.Tensor, value_cache: torch.Tensor,
+                               slot_mapping: torch.Tensor, kv_cache_dtype: str, kv_scale: float) -> None:
+    from neural_magic_vllm_amd import _torch_bindings as tb
+    tb.rotary_embedding_and_cache(positions, query, key, value, head_size, cos_sin_cache, is_neox,
+                                  key_cache, value_cache, slot_mapping, kv_cache_dtype, kv_scale)
+
+
+def rms_norm_dynamic_int8_quant(input: torch.Tensor, residual: Optional[torch.Tensor],
+                                weight: torch.Tensor,
+                                epsilon: float) -> Tuple[torch.Tensor, torch.Tensor]:
+    from neural_magic_vllm_amd import _torch_bindings as tb
+    return tb.rms_norm_dynamic_int8_quant(input, residual, weight, epsilon)
+
+
+def silu_and_mul_dynamic_int8_quant(input: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    from neural_magic_vllm_amd import _torch_bindings as tb
+    return tb.silu_and_mul_dynamic_int8_quant(input)

@@ -548,6 +548,56 @@ def reshape_and_cache_flash(key, value, key_cache, value_cache, slot_mapping,
             value.stride(0), key_cache.stride(0), dtype_code(key.dtype), stream_of(key)))
 
 
+# ----------------------------------------------------------------------------- fused decode-step launches
+def rotary_embedding_and_cache(positions, query, key, value, head_size, cos_sin_cache, is_neox,
+                               key_cache, value_cache, slot_mapping, kv_cache_dtype, kv_scale) -> None:
+    """rotary_embedding (pos_encoding_kernels.cu:121-160) + reshape_and_cache (cache_kernels.cu:253-278)
+    in one launch; query / key [T, heads*head_size] rotated in place, value [T, kv_heads*head_size]"""
+    nt, rot, nh, nkv, qs, ks = _rope_args(positions, query, key, head_size, cos_sin_cache)
+    _req(cos_sin_cache.dtype == query.dtype, "cos_sin_cache dtype must match query")
+    _req(query.dim() == 2 and key.dim() == 2 and value.dim() == 2 and value.shape == key.shape,
+         "rotary_embedding_and_cache: query / key / value must be [T, heads*head_size]")
+    _req(query.stride(-1) == 1 and key.stride(-1) == 1 and value.stride(-1) == 1,
+         "rotary_embedding_and_cache: heads must be contiguous")
+    _req(slot_mapping.dtype == torch.int64 and slot_mapping.numel() == nt, "slot_mapping must be int64 [T]")
+    _req(key_cache.is_contiguous() and value_cache.is_contiguous(), "caches must be contiguous")
+    _req(key_cache.shape[1] == nkv and value_cache.shape[1] == nkv, "cache kv-head count mismatch")
+    block_size = key_cache.shape[3]
+    with device_guard(query):
+        check(_lib.load().nmv_rotary_embedding_and_cache(
+            ptr(positions), ptr(query), ptr(key), ptr(value), nt, nh, nkv, head_size, rot, qs, ks,
+            value.stride(0), ptr(cos_sin_cache), int(is_neox), ptr(key_cache), ptr(value_cache),
+            ptr(slot_mapping), block_size, dtype_code(query.dtype), kv_dtype_code(kv_cache_dtype),
+            kv_scale, stream_of(query)))
+
+
+def rms_norm_dynamic_int8_quant(input, residual, weight, epsilon):
+    """(fused_add_)rms_norm -> dynamic per-token scaled_int8_quant; returns (int8 [T, H], scales [T, 1]);
+    residual (or None) is updated in place as fused_add_rms_norm does, input is left untouched"""
+    _req(input.is_contiguous() and (residual is None or residual.is_contiguous()),
+         "rms_norm_dynamic_int8_quant: tensors must be contiguous")
+    out = torch.empty(input.shape, dtype=torch.int8, device=input.device)
+    scales = torch.empty((_rows(input), 1), dtype=torch.float32, device=input.device)
+    with device_guard(input):
+        check(_lib.load().nmv_rms_norm_dynamic_int8_quant(
+            ptr(out), ptr(scales), ptr(input), ptr(residual), ptr(weight), epsilon, _rows(input),
+            input.shape[-1], dtype_code(input.dtype), stream_of(input)))
+    return out, scales
+
+
+def silu_and_mul_dynamic_int8_quant(input):
+    """silu_and_mul -> dynamic per-token scaled_int8_quant; input [T, 2d] -> (int8 [T, d], scales [T, 1])"""
+    _req(input.is_contiguous(), "silu_and_mul_dynamic_int8_quant: input must be contiguous")
+    d = input.shape[-1] // 2
+    out = torch.empty(input.shape[:-1] + (d, ), dtype=torch.int8, device=input.device)
+    scales = torch.empty((_rows(input), 1), dtype=torch.float32, device=input.device)
+    with device_guard(input):
+        check(_lib.load().nmv_silu_and_mul_dynamic_int8_quant(
+            ptr(out), ptr(scales), ptr(input), _rows(input), d, dtype_code(input.dtype),
+            stream_of(input)))
+    return out, scales
+
+
 def copy_blocks(key_caches: List[torch.Tensor], value_caches: List[torch.Tensor],
                 block_mapping: torch.Tensor) -> None:
     """csrc/cache_kernels.cu:101-148 (the pointer tables are built on the host and copied)"""

@@ -123,11 +123,32 @@ class ROCmHipAttentionImpl(AttentionImpl):
             raise ValueError(f"Head size {head_size} is not supported by PagedAttention. "
                              f"Supported head sizes are: {supported}.")
 
+    def rope_and_cache(self, positions: torch.Tensor, query: torch.Tensor, key: torch.Tensor,
+                       value: torch.Tensor, rotary_emb, kv_cache: Optional[torch.Tensor],
+                       attn_metadata: ROCmHipAttentionMetadata, kv_scale: float = 1.0) -> bool:
+        """rotary_embedding + reshape_and_cache in one launch (ops.rotary_embedding_and_cache): the
+        two are back-to-back ~5 us launches on the decode path.  Returns False (nothing done) when
+        the fused form does not apply; otherwise query / key are rotated in place and the caller
+        passes cache_written=True to forward()."""
+        if kv_cache is None or query.dim() != 2 or query.dtype not in (torch.float16, torch.bfloat16):
+            return False
+        cos_sin = rotary_emb.cos_sin_cache
+        if cos_sin.device != query.device or cos_sin.dtype != query.dtype:
+            cos_sin = rotary_emb.cos_sin_cache = cos_sin.to(query.device, dtype=query.dtype)
+        key_cache, value_cache = PagedAttention.split_kv_cache(kv_cache, self.num_kv_heads,
+                                                               self.head_size)
+        ops.rotary_embedding_and_cache(positions, query, key, value, self.head_size, cos_sin,
+                                       rotary_emb.is_neox_style, key_cache, value_cache,
+                                       attn_metadata.slot_mapping.flatten(), self.kv_cache_dtype,
+                                       kv_scale)
+        return True
+
     def forward(self, query: torch.Tensor, key: torch.Tensor, value: torch.Tensor,
                 kv_cache: Optional[torch.Tensor], attn_metadata: ROCmHipAttentionMetadata,
-                kv_scale: float = 1.0) -> torch.Tensor:
+                kv_scale: float = 1.0, cache_written: bool = False) -> torch.Tensor:
         """query [num_tokens, num_heads*head_size], key/value [num_tokens, num_kv_heads*head_size],
-        kv_cache [2, num_blocks, block_size*num_kv_heads*head_size] -> [num_tokens, hidden]"""
+        kv_cache [2, num_blocks, block_size*num_kv_heads*head_size] -> [num_tokens, hidden].
+        cache_written: rope_and_cache() below has already stored key / value in the cache."""
         num_tokens, hidden_size = query.shape
         query = query.view(-1, self.num_heads, self.head_size)
         key = key.view(-1, self.num_kv_heads, self.head_size)
@@ -139,9 +160,10 @@ class ROCmHipAttentionImpl(AttentionImpl):
         if kv_cache is not None:
             key_cache, value_cache = PagedAttention.split_kv_cache(kv_cache, self.num_kv_heads,
                                                                    self.head_size)
-            PagedAttention.write_to_paged_cache(key, value, key_cache, value_cache,
-                                                attn_metadata.slot_mapping, self.kv_cache_dtype,
-                                                kv_scale)
+            if not cache_written:
+                PagedAttention.write_to_paged_cache(key, value, key_cache, value_cache,
+                                                    attn_metadata.slot_mapping, self.kv_cache_dtype,
+                                                    kv_scale)
 
         num_prefill_tokens = attn_metadata.num_prefill_tokens
         num_decode_tokens = attn_metadata.num_decode_tokens

@@ -43,8 +43,22 @@ class Attention(nn.Module):
                              sliding_window, kv_cache_dtype, blocksparse_params)
 
     def forward(self, query: torch.Tensor, key: torch.Tensor, value: torch.Tensor,
-                kv_cache: Optional[torch.Tensor], attn_metadata: AttentionMetadata) -> torch.Tensor:
+                kv_cache: Optional[torch.Tensor], attn_metadata: AttentionMetadata,
+                cache_written: bool = False) -> torch.Tensor:
+        if cache_written:
+            return self.impl.forward(query, key, value, kv_cache, attn_metadata, self._kv_scale,
+                                     cache_written=True)
         return self.impl.forward(query, key, value, kv_cache, attn_metadata, self._kv_scale)
+
+    def rope_and_cache(self, positions: torch.Tensor, query: torch.Tensor, key: torch.Tensor,
+                       value: torch.Tensor, rotary_emb, kv_cache: Optional[torch.Tensor],
+                       attn_metadata: AttentionMetadata) -> bool:
+        """one-launch rotary embedding + KV-cache write where the backend has it (not part of the
+        reference's Attention layer; see ROCmHipAttentionImpl.rope_and_cache)"""
+        fused = getattr(self.impl, "rope_and_cache", None)
+        if fused is None:
+            return False
+        return fused(positions, query, key, value, rotary_emb, kv_cache, attn_metadata, self._kv_scale)
 
     def extra_repr(self) -> str:
         return (f"head_size={self.impl.head_size}, num_heads={self.impl.num_heads}, "

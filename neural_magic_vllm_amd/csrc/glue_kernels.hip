@@ -14,9 +14,18 @@
 
 namespace nmv {
 
+// The rounded bits pass through an empty asm so that the compiler has to materialise them: hipcc
+// was seen to drop the float -> _Float16 -> float round trip altogether when the rounded value
+// never reached memory (the fused norm + int8-quant kernel, fp16 only: a few quantised values per
+// 100k moved by one step).
+__device__ __forceinline__ uint32_t pin(uint32_t bits) {
+  asm volatile("" : "+v"(bits));
+  return bits;
+}
+
 template <typename T>
 __device__ __forceinline__ float rnd(float f) {  // round-trip through the model dtype
-  return T::to_float(T::from_float(f));
+  return T::to_float((uint16_t)pin(T::from_float(f)));
 }
 
 __device__ __forceinline__ float block_sum_256(float v, float* red /*[4]*/) {
@@ -29,6 +38,26 @@ __device__ __forceinline__ float block_sum_256(float v, float* red /*[4]*/) {
   const int nw = (blockDim.x + 63) >> 6;
   for (int i = 0; i < nw; ++i) t += red[i];
   return t;
+}
+
+__device__ __forceinline__ float block_max_pos(float v, float* red /*[16]*/) {  // v >= 0
+  v = wave_max(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  float t = 0.f;
+  const int nw = (blockDim.x + 63) >> 6;
+  for (int i = 0; i < nw; ++i) t = fmaxf(t, red[i]);
+  return t;
+}
+
+// dynamic per-token int8 (int8_quant_kernels.cu:37-75): x * (127 / absmax), round to nearest even,
+// saturate -- the arithmetic of int8_quant_kernel<T, true> in quant_kernels.hip
+__device__ __forceinline__ uint32_t q8(float x, float mul) {
+  float d = __builtin_nearbyintf(x * mul);
+  d = fminf(fmaxf(d, -128.f), 127.f);
+  return (uint32_t)(uint8_t)(int8_t)d;
 }
 
 // ---------------------------------------------------------------- RMSNorm
@@ -107,6 +136,93 @@ __global__ __launch_bounds__(256) void rms_norm_kernel(uint16_t* out,       // [
   }
 }
 
+// Register-resident form for 16-byte-aligned rows of up to 256 * 8 * NV elements (the decode
+// step: [B, 4096]): the row is read once, the weight vectors are requested together with it, and
+// only the block reduction sits between the loads and the stores -- the generic kernel above pays a
+// second dependent read of the row, ~1 us of the ~4.6 us such a launch takes.  Per-lane summation
+// order is the generic kernel's, so the results are bit-identical.
+// QUANT: the normalised row (rounded to the model dtype exactly as the stand-alone op does) is not
+// stored but quantised to int8 with a dynamic per-token scale, i.e. rms_norm -> scaled_int8_quant
+// (dynamic) in one launch for the W8A8 linears.
+template <typename T, bool FUSED_ADD, int NV, bool QUANT>
+__global__ __launch_bounds__(256) void rms_norm_reg_kernel(void* out_v, uint16_t* input,
+                                                           uint16_t* residual,
+                                                           const uint16_t* __restrict__ weight,
+                                                           float* __restrict__ q_scale,
+                                                           float epsilon, int hidden) {
+  __shared__ float red[16];
+  const int64_t row = (int64_t)blockIdx.x * hidden;
+  const int nv = hidden / 8;
+  uint32_t xs[NV][4];
+  uint4 w[NV];
+  float var = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int v = threadIdx.x + i * 256;
+    const bool ok = v < nv;
+    const int vc = ok ? v : nv - 1;
+    w[i] = ld16(weight + vc * 8);
+    const uint4 x = ld16(input + row + vc * 8);
+    xs[i][0] = x.x, xs[i][1] = x.y, xs[i][2] = x.z, xs[i][3] = x.w;
+    if constexpr (FUSED_ADD) {
+      const uint4 r = ld16(residual + row + vc * 8);
+      const uint32_t rs[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        // z = x + residual rounded to the model dtype (layernorm_kernels.cu:271-274)
+        const float lo = rnd<T>(lo_f<T>(xs[i][j]) + lo_f<T>(rs[j]));
+        const float hi = rnd<T>(hi_f<T>(xs[i][j]) + hi_f<T>(rs[j]));
+        xs[i][j] = T::pack2(lo, hi);
+        if (ok) var += lo * lo + hi * hi;
+      }
+      if (ok) st16(residual + row + v * 8, make_uint4(xs[i][0], xs[i][1], xs[i][2], xs[i][3]));
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float lo = lo_f<T>(xs[i][j]), hi = hi_f<T>(xs[i][j]);
+        if (ok) var += lo * lo + hi * hi;
+      }
+    }
+  }
+  var = block_sum_256(var, red);
+  const float s = rsqrtf(var / hidden + epsilon);
+  float amax = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int v = threadIdx.x + i * 256;
+    const uint32_t ws[4] = {w[i].x, w[i].y, w[i].z, w[i].w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      // ((scalar_t)(x * s_variance)) * weight  (layernorm_kernels.cu:41-42)
+      const float lo = rnd<T>(lo_f<T>(xs[i][j]) * s) * lo_f<T>(ws[j]);
+      const float hi = rnd<T>(hi_f<T>(xs[i][j]) * s) * hi_f<T>(ws[j]);
+      xs[i][j] = T::pack2(lo, hi);
+      if constexpr (QUANT) xs[i][j] = pin(xs[i][j]);
+      if constexpr (QUANT)
+        if (v < nv) amax = fmaxf(amax, fmaxf(fabsf(lo_f<T>(xs[i][j])), fabsf(hi_f<T>(xs[i][j]))));
+    }
+    if constexpr (!QUANT)
+      if (v < nv)
+        st16(reinterpret_cast<uint16_t*>(out_v) + row + v * 8,
+             make_uint4(xs[i][0], xs[i][1], xs[i][2], xs[i][3]));
+  }
+  if constexpr (QUANT) {
+    amax = block_max_pos(amax, red);
+    if (threadIdx.x == 0) q_scale[blockIdx.x] = amax / 127.0f;
+    const float mul = 127.0f / amax;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int v = threadIdx.x + i * 256;
+      uint2 o;
+      o.x = q8(lo_f<T>(xs[i][0]), mul) | (q8(hi_f<T>(xs[i][0]), mul) << 8) |
+            (q8(lo_f<T>(xs[i][1]), mul) << 16) | (q8(hi_f<T>(xs[i][1]), mul) << 24);
+      o.y = q8(lo_f<T>(xs[i][2]), mul) | (q8(hi_f<T>(xs[i][2]), mul) << 8) |
+            (q8(lo_f<T>(xs[i][3]), mul) << 16) | (q8(hi_f<T>(xs[i][3]), mul) << 24);
+      if (v < nv) *reinterpret_cast<uint2*>(reinterpret_cast<int8_t*>(out_v) + row + v * 8) = o;
+    }
+  }
+}
+
 // ---------------------------------------------------------------- rotary embedding
 // One workgroup per token.  Every intermediate is rounded to the model dtype exactly as the
 // reference's scalar_t arithmetic does (pos_encoding_kernels.cu:10-37: x*cos - y*sin with
@@ -160,6 +276,98 @@ __global__ void rotary_embedding_kernel(const int64_t* __restrict__ positions,
     const int head_idx = i / embed_dim;
     const int rot_offset = i % embed_dim;
     rope_one<T, IS_NEOX>(key + token_idx * key_stride + (int64_t)head_idx * head_size, cos_ptr,
+                         sin_ptr, rot_offset, embed_dim);
+  }
+}
+
+// rotary_embedding + reshape_and_cache in one launch (the decode step calls them back to back on
+// [B, heads*head_size] tensors of a few hundred KB: each launch is ~5 us of latency, not bandwidth).
+// Same arithmetic and the same in-place update of query / key as the two separate ops.  The lane
+// that rotates a key pair also stores the two rotated elements (the rounded bits it writes back to
+// `key`) at their place in the paged cache, so there is no barrier and no second read: one
+// load -> rotate -> store chain per lane, as in rotary_embedding alone.
+template <typename T, bool FP8>
+__device__ __forceinline__ void cache_store_k(void* key_cache, int64_t head_base /*(block*heads+head)*/,
+                                              int head_size, int block_size, int64_t block_offset,
+                                              int d, uint16_t bits, float kv_scale) {
+  constexpr int X = FP8 ? 16 : 8;
+  const int64_t tgt = ((head_base * (head_size / X) + d / X) * block_size + block_offset) * X + d % X;
+  if constexpr (FP8)
+    reinterpret_cast<uint8_t*>(key_cache)[tgt] = f32_to_fp8(T::to_float(bits) / kv_scale);
+  else
+    reinterpret_cast<uint16_t*>(key_cache)[tgt] = bits;
+}
+
+template <typename T, bool IS_NEOX, bool FP8>
+__global__ void rope_and_cache_kernel(const int64_t* __restrict__ positions, uint16_t* query,
+                                      uint16_t* key, const uint16_t* value,
+                                      const uint16_t* __restrict__ cos_sin_cache, int rot_dim,
+                                      int64_t query_stride, int64_t key_stride,
+                                      int64_t value_stride, int num_heads, int num_kv_heads,
+                                      int head_size, void* key_cache, void* value_cache,
+                                      const int64_t* __restrict__ slot_mapping, int block_size,
+                                      float kv_scale) {
+  const int token_idx = blockIdx.x;
+  const int64_t pos = positions[token_idx];
+  const int64_t slot_idx = slot_mapping[token_idx];
+  const bool cached = slot_idx >= 0;  // padding tokens are rotated but not cached (cache_kernels.cu:166-169)
+  const int64_t block_idx = cached ? slot_idx / block_size : 0;
+  const int64_t block_offset = cached ? slot_idx % block_size : 0;
+  const uint16_t* cache_ptr = cos_sin_cache + pos * rot_dim;
+  const int embed_dim = rot_dim / 2;
+  const uint16_t* cos_ptr = cache_ptr;
+  const uint16_t* sin_ptr = cache_ptr + embed_dim;
+  // ---- K: rotate, write back, store in the cache ----
+  const int nk = num_kv_heads * embed_dim;
+  for (int i = threadIdx.x; i < nk; i += blockDim.x) {
+    const int head_idx = i / embed_dim;
+    const int rot_offset = i % embed_dim;
+    uint16_t* arr = key + token_idx * key_stride + (int64_t)head_idx * head_size;
+    const int x_index = IS_NEOX ? rot_offset : 2 * rot_offset;
+    const int y_index = IS_NEOX ? embed_dim + rot_offset : 2 * rot_offset + 1;
+    const float c = T::to_float(cos_ptr[rot_offset]);
+    const float s = T::to_float(sin_ptr[rot_offset]);
+    const float x = T::to_float(arr[x_index]);
+    const float y = T::to_float(arr[y_index]);
+    const uint16_t xo = T::from_float(rnd<T>(x * c) - rnd<T>(y * s));
+    const uint16_t yo = T::from_float(rnd<T>(y * c) + rnd<T>(x * s));
+    arr[x_index] = xo;
+    arr[y_index] = yo;
+    if (cached) {
+      const int64_t hb = block_idx * num_kv_heads + head_idx;
+      cache_store_k<T, FP8>(key_cache, hb, head_size, block_size, block_offset, x_index, xo, kv_scale);
+      cache_store_k<T, FP8>(key_cache, hb, head_size, block_size, block_offset, y_index, yo, kv_scale);
+    }
+  }
+  if (cached) {
+    // K dims beyond rot_dim pass through unrotated
+    const int pass = head_size - rot_dim;
+    for (int i = threadIdx.x; i < num_kv_heads * pass; i += blockDim.x) {
+      const int head_idx = i / pass, d = rot_dim + i % pass;
+      cache_store_k<T, FP8>(key_cache, block_idx * num_kv_heads + head_idx, head_size, block_size,
+                            block_offset, d, key[token_idx * key_stride + (int64_t)head_idx * head_size + d],
+                            kv_scale);
+    }
+    // ---- V: element scatter, as write_token_to_cache (cache_write.h) ----
+    const int n = num_kv_heads * head_size;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+      const int head_idx = i / head_size;
+      const int head_off = i % head_size;
+      const int64_t tgt =
+          ((block_idx * num_kv_heads + head_idx) * head_size + head_off) * block_size + block_offset;
+      const uint16_t v = value[token_idx * value_stride + i];
+      if constexpr (!FP8)
+        reinterpret_cast<uint16_t*>(value_cache)[tgt] = v;
+      else
+        reinterpret_cast<uint8_t*>(value_cache)[tgt] = f32_to_fp8(T::to_float(v) / kv_scale);
+    }
+  }
+  // ---- Q ----
+  const int nq = num_heads * embed_dim;
+  for (int i = threadIdx.x; i < nq; i += blockDim.x) {
+    const int head_idx = i / embed_dim;
+    const int rot_offset = i % embed_dim;
+    rope_one<T, IS_NEOX>(query + token_idx * query_stride + (int64_t)head_idx * head_size, cos_ptr,
                          sin_ptr, rot_offset, embed_dim);
   }
 }
@@ -222,6 +430,49 @@ __device__ __forceinline__ float unary_act(float x) {
   }
 }
 
+// silu_and_mul -> scaled_int8_quant (dynamic per token) in one launch: the products, rounded to
+// the model dtype as act_and_mul_kernel stores them, stay in registers (NV 16-byte vectors per
+// lane, 1024 lanes) while the row maximum is reduced.
+template <typename T, int ACT, int NV>
+__global__ __launch_bounds__(1024) void act_and_mul_quant_kernel(int8_t* __restrict__ out,
+                                                                 float* __restrict__ q_scale,
+                                                                 const uint16_t* __restrict__ input,
+                                                                 int d) {
+  __shared__ float red[16];
+  const int64_t token_idx = blockIdx.x;
+  const uint16_t* xr = input + token_idx * 2 * d;
+  const uint16_t* yr = xr + d;
+  const int nv = d / 8;
+  uint32_t r[NV][4];
+  float amax = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int v = threadIdx.x + i * 1024;
+    const int vc = v < nv ? v : nv - 1;
+    const uint4 x = ld16(xr + vc * 8), y = ld16(yr + vc * 8);
+    const uint32_t xs[4] = {x.x, x.y, x.z, x.w}, ys[4] = {y.x, y.y, y.z, y.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      r[i][j] = pin(T::pack2(gate_act<T, ACT>(lo_f<T>(xs[j])) * lo_f<T>(ys[j]),
+                             gate_act<T, ACT>(hi_f<T>(xs[j])) * hi_f<T>(ys[j])));
+      if (v < nv) amax = fmaxf(amax, fmaxf(fabsf(lo_f<T>(r[i][j])), fabsf(hi_f<T>(r[i][j]))));
+    }
+  }
+  amax = block_max_pos(amax, red);
+  if (threadIdx.x == 0) q_scale[token_idx] = amax / 127.0f;
+  const float mul = 127.0f / amax;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int v = threadIdx.x + i * 1024;
+    uint2 o;
+    o.x = q8(lo_f<T>(r[i][0]), mul) | (q8(hi_f<T>(r[i][0]), mul) << 8) |
+          (q8(lo_f<T>(r[i][1]), mul) << 16) | (q8(hi_f<T>(r[i][1]), mul) << 24);
+    o.y = q8(lo_f<T>(r[i][2]), mul) | (q8(hi_f<T>(r[i][2]), mul) << 8) |
+          (q8(lo_f<T>(r[i][3]), mul) << 16) | (q8(hi_f<T>(r[i][3]), mul) << 24);
+    if (v < nv) *reinterpret_cast<uint2*>(out + token_idx * d + v * 8) = o;
+  }
+}
+
 template <typename T, int ACT>
 __global__ void activation_kernel(uint16_t* __restrict__ out, const uint16_t* __restrict__ input,
                                   int d) {
@@ -237,19 +488,46 @@ using namespace nmv;
 #define NMV_HALF_ONLY(name)                                                              \
   NMV_CHECK(dtype == NMV_F16 || dtype == NMV_BF16, name ": unsupported dtype %d", (int)dtype)
 
+// kind: 0 rms_norm, 1 fused_add_rms_norm; q_out/q_scale non-null: int8 output with per-token scales
+template <typename T>
+static void rms_launch(void* out, uint16_t* input, uint16_t* residual, const uint16_t* weight,
+                       float* q_scale, float epsilon, int num_tokens, int hidden, bool quant,
+                       hipStream_t s) {
+  dim3 grid(num_tokens), block(256);
+  const bool fused = residual != nullptr;
+  const bool aligned = hidden % 8 == 0 &&
+                       (((uintptr_t)input | (uintptr_t)out | (uintptr_t)residual | (uintptr_t)weight) & 15) == 0;
+  const int nv = aligned ? (hidden / 8 + 255) / 256 : 0;
+#define RMS_REG(NV_)                                                                               \
+  {                                                                                                \
+    if (fused) {                                                                                   \
+      if (quant) hipLaunchKernelGGL((rms_norm_reg_kernel<T, true, NV_, true>), grid, block, 0, s, out, input, residual, weight, q_scale, epsilon, hidden); \
+      else hipLaunchKernelGGL((rms_norm_reg_kernel<T, true, NV_, false>), grid, block, 0, s, out, input, residual, weight, q_scale, epsilon, hidden); \
+    } else {                                                                                       \
+      if (quant) hipLaunchKernelGGL((rms_norm_reg_kernel<T, false, NV_, true>), grid, block, 0, s, out, input, residual, weight, q_scale, epsilon, hidden); \
+      else hipLaunchKernelGGL((rms_norm_reg_kernel<T, false, NV_, false>), grid, block, 0, s, out, input, residual, weight, q_scale, epsilon, hidden); \
+    }                                                                                              \
+  }
+  if (nv == 1) RMS_REG(1)
+  else if (nv == 2) RMS_REG(2)
+  else if (nv >= 3 && nv <= 4) RMS_REG(4)
+  else if (fused)
+    hipLaunchKernelGGL((rms_norm_kernel<T, true>), grid, block, 0, s, (uint16_t*)out, input, residual, weight, epsilon, hidden);
+  else
+    hipLaunchKernelGGL((rms_norm_kernel<T, false>), grid, block, 0, s, (uint16_t*)out, input, residual, weight, epsilon, hidden);
+#undef RMS_REG
+}
+
 extern "C" int nmv_rms_norm(void* out, const void* input, const void* weight, float epsilon,
                             int num_tokens, int hidden_size, nmv_dtype_t dtype, void* stream) {
   NMV_HALF_ONLY("rms_norm");
   if (num_tokens == 0) return NMV_OK;
-  dim3 grid(num_tokens), block(256);
   if (dtype == NMV_F16)
-    hipLaunchKernelGGL((rms_norm_kernel<F16, false>), grid, block, 0, (hipStream_t)stream,
-                       (uint16_t*)out, (uint16_t*)input, (uint16_t*)nullptr,
-                       (const uint16_t*)weight, epsilon, hidden_size);
+    rms_launch<F16>(out, (uint16_t*)input, nullptr, (const uint16_t*)weight, nullptr, epsilon,
+                    num_tokens, hidden_size, false, (hipStream_t)stream);
   else
-    hipLaunchKernelGGL((rms_norm_kernel<BF16, false>), grid, block, 0, (hipStream_t)stream,
-                       (uint16_t*)out, (uint16_t*)input, (uint16_t*)nullptr,
-                       (const uint16_t*)weight, epsilon, hidden_size);
+    rms_launch<BF16>(out, (uint16_t*)input, nullptr, (const uint16_t*)weight, nullptr, epsilon,
+                     num_tokens, hidden_size, false, (hipStream_t)stream);
   NMV_LAUNCH_CHECK();
   return NMV_OK;
 }
@@ -258,16 +536,56 @@ extern "C" int nmv_fused_add_rms_norm(void* input, void* residual, const void* w
                                       float epsilon, int num_tokens, int hidden_size,
                                       nmv_dtype_t dtype, void* stream) {
   NMV_HALF_ONLY("fused_add_rms_norm");
+  NMV_CHECK(residual != nullptr, "fused_add_rms_norm: null residual");
   if (num_tokens == 0) return NMV_OK;
-  dim3 grid(num_tokens), block(256);
   if (dtype == NMV_F16)
-    hipLaunchKernelGGL((rms_norm_kernel<F16, true>), grid, block, 0, (hipStream_t)stream,
-                       (uint16_t*)input, (uint16_t*)input, (uint16_t*)residual,
-                       (const uint16_t*)weight, epsilon, hidden_size);
+    rms_launch<F16>(input, (uint16_t*)input, (uint16_t*)residual, (const uint16_t*)weight, nullptr,
+                    epsilon, num_tokens, hidden_size, false, (hipStream_t)stream);
   else
-    hipLaunchKernelGGL((rms_norm_kernel<BF16, true>), grid, block, 0, (hipStream_t)stream,
-                       (uint16_t*)input, (uint16_t*)input, (uint16_t*)residual,
-                       (const uint16_t*)weight, epsilon, hidden_size);
+    rms_launch<BF16>(input, (uint16_t*)input, (uint16_t*)residual, (const uint16_t*)weight, nullptr,
+                     epsilon, num_tokens, hidden_size, false, (hipStream_t)stream);
+  NMV_LAUNCH_CHECK();
+  return NMV_OK;
+}
+
+extern "C" int nmv_rms_norm_dynamic_int8_quant(void* out_q, float* scales, const void* input,
+                                               void* residual, const void* weight, float epsilon,
+                                               int num_tokens, int hidden_size, nmv_dtype_t dtype,
+                                               void* stream) {
+  NMV_HALF_ONLY("rms_norm_dynamic_int8_quant");
+  NMV_CHECK(hidden_size % 8 == 0 && hidden_size <= 8192 &&
+                (((uintptr_t)input | (uintptr_t)out_q | (uintptr_t)residual | (uintptr_t)weight) & 15) == 0,
+            "rms_norm_dynamic_int8_quant: hidden_size must be a multiple of 8, <= 8192, 16-byte aligned rows");
+  if (num_tokens == 0) return NMV_OK;
+  if (dtype == NMV_F16)
+    rms_launch<F16>(out_q, (uint16_t*)input, (uint16_t*)residual, (const uint16_t*)weight, scales,
+                    epsilon, num_tokens, hidden_size, true, (hipStream_t)stream);
+  else
+    rms_launch<BF16>(out_q, (uint16_t*)input, (uint16_t*)residual, (const uint16_t*)weight, scales,
+                     epsilon, num_tokens, hidden_size, true, (hipStream_t)stream);
+  NMV_LAUNCH_CHECK();
+  return NMV_OK;
+}
+
+extern "C" int nmv_silu_and_mul_dynamic_int8_quant(void* out_q, float* scales, const void* input,
+                                                   int num_tokens, int d, nmv_dtype_t dtype,
+                                                   void* stream) {
+  NMV_HALF_ONLY("silu_and_mul_dynamic_int8_quant");
+  NMV_CHECK(d % 8 == 0 && d <= 32768 && (((uintptr_t)input | (uintptr_t)out_q) & 15) == 0,
+            "silu_and_mul_dynamic_int8_quant: d must be a multiple of 8, <= 32768, 16-byte aligned rows");
+  if (num_tokens == 0 || d == 0) return NMV_OK;
+  dim3 grid(num_tokens), block(1024);
+  hipStream_t s = (hipStream_t)stream;
+  const int nv = (d / 8 + 1023) / 1024;
+#define LAUNCH_AQ(T, NV_)                                                                   \
+  hipLaunchKernelGGL((act_and_mul_quant_kernel<T, 0, NV_>), grid, block, 0, s, (int8_t*)out_q, \
+                     scales, (const uint16_t*)input, d)
+  if (dtype == NMV_F16) {
+    if (nv == 1) LAUNCH_AQ(F16, 1); else if (nv == 2) LAUNCH_AQ(F16, 2); else LAUNCH_AQ(F16, 4);
+  } else {
+    if (nv == 1) LAUNCH_AQ(BF16, 1); else if (nv == 2) LAUNCH_AQ(BF16, 2); else LAUNCH_AQ(BF16, 4);
+  }
+#undef LAUNCH_AQ
   NMV_LAUNCH_CHECK();
   return NMV_OK;
 }
@@ -316,6 +634,46 @@ extern "C" int nmv_batched_rotary_embedding(const int64_t* positions, void* quer
   return rope_launch(positions, query, key, num_tokens, num_heads, num_kv_heads, head_size,
                      rot_dim, query_stride, key_stride, cos_sin_cache, is_neox,
                      cos_sin_cache_offsets, dtype, stream);
+}
+
+extern "C" int nmv_rotary_embedding_and_cache(const int64_t* positions, void* query, void* key,
+                                              const void* value, int num_tokens, int num_heads,
+                                              int num_kv_heads, int head_size, int rot_dim,
+                                              int64_t query_stride, int64_t key_stride,
+                                              int64_t value_stride, const void* cos_sin_cache,
+                                              int is_neox, void* key_cache, void* value_cache,
+                                              const int64_t* slot_mapping, int block_size,
+                                              nmv_dtype_t dtype, nmv_kv_dtype_t kv_dtype,
+                                              float kv_scale, void* stream) {
+  NMV_HALF_ONLY("rotary_embedding_and_cache");
+  NMV_CHECK(rot_dim > 0 && rot_dim % 2 == 0 && rot_dim <= head_size,
+            "rotary_embedding_and_cache: bad rot_dim %d for head_size %d", rot_dim, head_size);
+  NMV_CHECK(kv_dtype == NMV_KV_AUTO || kv_dtype == NMV_KV_FP8_E4M3,
+            "rotary_embedding_and_cache: unsupported kv cache dtype %d", (int)kv_dtype);
+  const int x = kv_dtype == NMV_KV_AUTO ? 8 : 16;
+  NMV_CHECK(head_size % x == 0, "rotary_embedding_and_cache: head_size %d not a multiple of x=%d",
+            head_size, x);
+  NMV_CHECK(block_size > 0 && num_kv_heads > 0 && num_heads > 0, "rotary_embedding_and_cache: bad shape");
+  if (num_tokens == 0) return NMV_OK;
+  dim3 grid(num_tokens), block(std::min(std::max(num_heads * rot_dim / 2, 64), 512));
+  hipStream_t s = (hipStream_t)stream;
+#define LAUNCH_RC(T, NEOX, FP8)                                                                  \
+  hipLaunchKernelGGL((rope_and_cache_kernel<T, NEOX, FP8>), grid, block, 0, s, positions,        \
+                     (uint16_t*)query, (uint16_t*)key, (const uint16_t*)value,                   \
+                     (const uint16_t*)cos_sin_cache, rot_dim, query_stride, key_stride,          \
+                     value_stride, num_heads, num_kv_heads, head_size, key_cache, value_cache,   \
+                     slot_mapping, block_size, kv_scale)
+#define LAUNCH_RC_T(T)                                                       \
+  if (kv_dtype == NMV_KV_AUTO) {                                             \
+    if (is_neox) LAUNCH_RC(T, true, false); else LAUNCH_RC(T, false, false); \
+  } else {                                                                   \
+    if (is_neox) LAUNCH_RC(T, true, true); else LAUNCH_RC(T, false, true);   \
+  }
+  if (dtype == NMV_F16) LAUNCH_RC_T(F16) else LAUNCH_RC_T(BF16)
+#undef LAUNCH_RC_T
+#undef LAUNCH_RC
+  NMV_LAUNCH_CHECK();
+  return NMV_OK;
 }
 
 extern "C" int nmv_act_and_mul(void* out, const void* input, int num_tokens, int d, int act,

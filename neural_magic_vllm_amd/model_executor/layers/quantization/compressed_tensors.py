@@ -7,7 +7,7 @@ Two schemes on the hot path:
   * WNA16: weight_packed int32 [N, K/pack] + weight_scale [N, K/g] -> transposed to the GPTQ
     layout on first use, ops.gptq_marlin_repack, then ops.gptq_marlin_gemm.
 The 2:4-sparse w4a16 scheme of the reference is out of scope (no sparse MFMA path in north_star)."""
-from typing import Any, Callable, Dict, List, Optional
+from typing import Any, Callable, Dict, List, NamedTuple, Optional
 
 import torch
 from torch.nn.parameter import Parameter
@@ -17,6 +17,20 @@ from ...utils import set_weight_attrs
 from .base_config import LinearMethodBase, QuantizationConfig
 from .gptq_marlin import (GPTQ_MARLIN_MAX_PARALLEL, GPTQ_MARLIN_MIN_THREAD_N, GPTQMarlinState,
                           marlin_permute_scales)
+
+
+class Int8Activations(NamedTuple):
+    """Activations already quantised per token by a fused producer (ops.rms_norm_dynamic_int8_quant,
+    ops.silu_and_mul_dynamic_int8_quant): what ops.scaled_int8_quant(x, None) would have returned."""
+    q: torch.Tensor      # int8 [T, K]
+    scale: torch.Tensor  # float32 [T, 1]
+    dtype: torch.dtype   # the model dtype the GEMM writes
+
+
+def accepts_int8_activations(linear) -> bool:
+    """True for a W8A8 linear with dynamic per-token activation quantisation"""
+    scheme = getattr(linear, "scheme", None)
+    return isinstance(scheme, CompressedTensorsW8A8) and not scheme.is_static_input_scheme
 
 
 class CompressedTensorsW8A8:
@@ -60,12 +74,17 @@ class CompressedTensorsW8A8:
             layer.weight_scale = Parameter(ws, requires_grad=False)
         layer.weight = Parameter(layer.weight.t(), requires_grad=False)  # column-major B
 
-    def apply_weights(self, layer, x: torch.Tensor):
-        x2 = x.reshape(-1, x.shape[-1])
-        x_q, x_scale = ops.scaled_int8_quant(x2, layer.input_scale)
+    def apply_weights(self, layer, x):
+        if isinstance(x, Int8Activations):
+            assert not self.is_static_input_scheme
+            x_q, x_scale, out_dtype, lead = x.q.reshape(-1, x.q.shape[-1]), x.scale, x.dtype, x.q.shape[:-1]
+        else:
+            x2 = x.reshape(-1, x.shape[-1])
+            x_q, x_scale = ops.scaled_int8_quant(x2, layer.input_scale)
+            out_dtype, lead = x.dtype, x.shape[:-1]
         out = ops.cutlass_scaled_mm(x_q, layer.weight, scale_a=x_scale, scale_b=layer.weight_scale,
-                                    out_dtype=x.dtype)
-        return out.reshape(x.shape[:-1] + (out.shape[-1], ))
+                                    out_dtype=out_dtype)
+        return out.reshape(lead + (out.shape[-1], ))
 
 
 class CompressedTensorsWNA16:

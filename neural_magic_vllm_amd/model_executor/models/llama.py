@@ -7,11 +7,13 @@ surface, rope in place on the q/k slices, attention through the Attention layer,
 carried through fused_add_rms_norm.  Checkpoint name mapping, LoRA, pipeline parallelism and
 rope scaling are outside the hot-path scope.
 """
+import os
 from typing import Any, Iterable, List, Optional, Tuple
 
 import torch
 from torch import nn
 
+from ... import _custom_ops as ops
 from ...attention import Attention, AttentionMetadata
 from ...distributed import get_tensor_model_parallel_world_size
 from ..layers.activation import SiluAndMul
@@ -19,8 +21,16 @@ from ..layers.layernorm import RMSNorm
 from ..layers.linear import MergedColumnParallelLinear, QKVParallelLinear, RowParallelLinear
 from ..layers.logits_processor import LogitsProcessor
 from ..layers.quantization.base_config import QuantizationConfig
+from ..layers.quantization.compressed_tensors import Int8Activations, accepts_int8_activations
 from ..layers.rotary_embedding import get_rope
 from ..layers.vocab_parallel_embedding import ParallelLMHead, VocabParallelEmbedding
+
+
+def fused_glue_default() -> bool:
+    """Fused decode-step launches (rotary + cache write; norm / activation + int8 quantisation) are
+    on unless NMV_FUSED_GLUE=0; every one is bit-identical to the op sequence it replaces.  Modules
+    keep the choice in `.fused_glue` so that tests can compare both forms on one set of weights."""
+    return os.environ.get("NMV_FUSED_GLUE", "1") != "0"
 
 
 class LlamaMLP(nn.Module):
@@ -36,10 +46,15 @@ class LlamaMLP(nn.Module):
         if hidden_act != "silu":
             raise ValueError(f"Unsupported activation: {hidden_act}. Only silu is supported for now.")
         self.act_fn = SiluAndMul()
+        self.fused_glue = fused_glue_default()
 
     def forward(self, x):
         gate_up, _ = self.gate_up_proj(x)
-        x = self.act_fn(gate_up)
+        if self.fused_glue and gate_up.is_cuda and accepts_int8_activations(self.down_proj):
+            # silu_and_mul + dynamic per-token int8 quantisation of down_proj's input: one launch
+            x = Int8Activations(*ops.silu_and_mul_dynamic_int8_quant(gate_up), gate_up.dtype)
+        else:
+            x = self.act_fn(gate_up)
         x, _ = self.down_proj(x)
         return x
 
@@ -81,13 +96,18 @@ class LlamaAttention(nn.Module):
         self.attn = Attention(self.num_heads, self.head_dim, self.scaling,
                               num_kv_heads=self.num_kv_heads, cache_config=cache_config,
                               quant_config=quant_config)
+        self.fused_glue = fused_glue_default()
 
     def forward(self, positions: torch.Tensor, hidden_states: torch.Tensor,
                 kv_cache: Optional[torch.Tensor], attn_metadata: AttentionMetadata) -> torch.Tensor:
         qkv, _ = self.qkv_proj(hidden_states)
         q, k, v = qkv.split([self.q_size, self.kv_size, self.kv_size], dim=-1)
-        q, k = self.rotary_emb(positions, q, k)
-        attn_output = self.attn(q, k, v, kv_cache, attn_metadata)
+        if self.fused_glue and q.is_cuda and self.attn.rope_and_cache(positions, q, k, v, self.rotary_emb,
+                                                                      kv_cache, attn_metadata):
+            attn_output = self.attn(q, k, v, kv_cache, attn_metadata, cache_written=True)
+        else:
+            q, k = self.rotary_emb(positions, q, k)
+            attn_output = self.attn(q, k, v, kv_cache, attn_metadata)
         output, _ = self.o_proj(attn_output)
         return output
 
@@ -114,18 +134,36 @@ class LlamaDecoderLayer(nn.Module):
                             bias=getattr(config, "mlp_bias", False))
         self.input_layernorm = RMSNorm(config.hidden_size, eps=config.rms_norm_eps)
         self.post_attention_layernorm = RMSNorm(config.hidden_size, eps=config.rms_norm_eps)
+        self.fused_glue = fused_glue_default()
 
     def forward(self, positions: torch.Tensor, hidden_states: torch.Tensor,
                 kv_cache: Optional[torch.Tensor], attn_metadata: AttentionMetadata,
                 residual: Optional[torch.Tensor]) -> Tuple[torch.Tensor, torch.Tensor]:
-        if residual is None:
+        fuse_q = self.fused_glue and hidden_states.is_cuda
+        if fuse_q and accepts_int8_activations(self.self_attn.qkv_proj):
+            # (fused_add_)rms_norm + dynamic per-token int8 quantisation of qkv_proj's input
+            ln = self.input_layernorm
+            if residual is None:
+                residual = hidden_states
+                q, sc = ops.rms_norm_dynamic_int8_quant(hidden_states, None, ln.weight.data, ln.variance_epsilon)
+            else:
+                q, sc = ops.rms_norm_dynamic_int8_quant(hidden_states, residual, ln.weight.data,
+                                                        ln.variance_epsilon)
+            hidden_states = Int8Activations(q, sc, residual.dtype)
+        elif residual is None:
             residual = hidden_states
             hidden_states = self.input_layernorm(hidden_states)
         else:
             hidden_states, residual = self.input_layernorm(hidden_states, residual)
         hidden_states = self.self_attn(positions=positions, hidden_states=hidden_states,
                                        kv_cache=kv_cache, attn_metadata=attn_metadata)
-        hidden_states, residual = self.post_attention_layernorm(hidden_states, residual)
+        if fuse_q and accepts_int8_activations(self.mlp.gate_up_proj):
+            ln = self.post_attention_layernorm
+            q, sc = ops.rms_norm_dynamic_int8_quant(hidden_states, residual, ln.weight.data,
+                                                    ln.variance_epsilon)
+            hidden_states = Int8Activations(q, sc, residual.dtype)
+        else:
+            hidden_states, residual = self.post_attention_layernorm(hidden_states, residual)
         hidden_states = self.mlp(hidden_states)
         return hidden_states, residual
 

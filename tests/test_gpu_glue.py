@@ -159,3 +159,94 @@ def test_glue_golden(gpu_device):
         ops.rotary_embedding(pos, q, k, 128, D("rope_cache"), neox)
         assert torch.allclose(q.cpu().float(), T("rope_q_" + tag).float(), atol=2e-2, rtol=1.6e-2)
         assert torch.allclose(k.cpu().float(), T("rope_k_" + tag).float(), atol=2e-2, rtol=1.6e-2)
+
+
+# ----------------------------------------------------------------------------- fused launches
+# Each fused op must be bit-identical to the sequence of reference ops it replaces (which are
+# themselves pinned against the oracle above and in test_gpu_cache.py / test_gpu_w8a8.py).
+@pytest.mark.parametrize("is_neox", [True, False])
+@pytest.mark.parametrize("dtype", [torch.half, torch.bfloat16])
+@pytest.mark.parametrize("kv_cache_dtype", ["auto", "fp8"])
+@pytest.mark.parametrize("heads,kv_heads,head_size,rot_dim", [(32, 8, 128, 128), (8, 8, 64, 64), (4, 1, 128, 64),
+                                                             (16, 2, 256, 128)])
+def test_rotary_embedding_and_cache_matches_separate_ops(gpu_device, is_neox, dtype, kv_cache_dtype, heads,
+                                                         kv_heads, head_size, rot_dim):
+    from neural_magic_vllm_amd import _custom_ops as ops
+    d = gpu_device
+    g = torch.Generator().manual_seed(0)
+    num_tokens, block_size, num_blocks, max_pos = 19, 16, 11, 4096
+    qkv = torch.randn((num_tokens, (heads + 2 * kv_heads) * head_size), generator=g).to(dtype).to(d)
+    cos_sin = torch.randn((max_pos, rot_dim), generator=g).to(dtype).to(d)
+    positions = torch.randint(0, max_pos, (num_tokens, ), generator=g).to(d)
+    slots = torch.randperm(num_blocks * block_size, generator=g)[:num_tokens].to(d)
+    slots[3] = -1  # padding token: rotated, not cached
+    cdt = torch.uint8 if kv_cache_dtype == "fp8" else dtype
+    x = 16 // torch.tensor([], dtype=cdt).element_size()
+    kv_scale = 0.5 if kv_cache_dtype == "fp8" else 1.0
+
+    def caches():
+        gen = torch.Generator().manual_seed(1)
+        kc = torch.randint(0, 100, (num_blocks, kv_heads, head_size // x, block_size, x), generator=gen)
+        vc = torch.randint(0, 100, (num_blocks, kv_heads, head_size, block_size), generator=gen)
+        return kc.to(cdt).to(d), vc.to(cdt).to(d)
+
+    def split(t):
+        return t.split([heads * head_size, kv_heads * head_size, kv_heads * head_size], dim=-1)
+
+    # the separate ops on strided slices of qkv, as the model calls them
+    ref_qkv = qkv.clone()
+    q, k, v = split(ref_qkv)
+    ref_kc, ref_vc = caches()
+    ops.rotary_embedding(positions, q, k, head_size, cos_sin, is_neox)
+    ops.reshape_and_cache(k.view(num_tokens, kv_heads, head_size), v.view(num_tokens, kv_heads, head_size),
+                          ref_kc, ref_vc, slots, kv_cache_dtype, kv_scale)
+    got_qkv = qkv.clone()
+    q, k, v = split(got_qkv)
+    kc, vc = caches()
+    ops.rotary_embedding_and_cache(positions, q, k, v, head_size, cos_sin, is_neox, kc, vc, slots,
+                                   kv_cache_dtype, kv_scale)
+    assert torch.equal(got_qkv.view(torch.int16), ref_qkv.view(torch.int16))
+    assert torch.equal(kc.view(torch.uint8), ref_kc.view(torch.uint8))
+    assert torch.equal(vc.view(torch.uint8), ref_vc.view(torch.uint8))
+    assert not torch.equal(got_qkv.view(torch.int16), qkv.view(torch.int16))
+
+
+@pytest.mark.parametrize("num_tokens", [1, 7, 83])
+@pytest.mark.parametrize("hidden", [768, 4096, 5120, 8192])
+@pytest.mark.parametrize("dtype", [torch.half, torch.bfloat16])
+@pytest.mark.parametrize("add_residual", [False, True])
+def test_rms_norm_dynamic_int8_quant_matches_separate_ops(gpu_device, num_tokens, hidden, dtype, add_residual):
+    from neural_magic_vllm_amd import _custom_ops as ops
+    g = torch.Generator().manual_seed(0)
+    d = gpu_device
+    x = torch.randn((num_tokens, hidden), generator=g).to(dtype).to(d)
+    res = torch.randn((num_tokens, hidden), generator=g).to(dtype).to(d)
+    w = (1 + 0.1 * torch.randn((hidden, ), generator=g)).to(dtype).to(d)
+    if add_residual:
+        normed, ref_res = x.clone(), res.clone()
+        ops.fused_add_rms_norm(normed, ref_res, w, 1e-5)
+    else:
+        normed = torch.empty_like(x)
+        ops.rms_norm(normed, x, w, 1e-5)
+    ref_q, ref_s = ops.scaled_int8_quant(normed)
+    x_in, got_res = x.clone(), res.clone()
+    q, s = ops.rms_norm_dynamic_int8_quant(x_in, got_res if add_residual else None, w, 1e-5)
+    assert q.dtype == torch.int8 and s.shape == (num_tokens, 1)
+    assert torch.equal(q, ref_q) and torch.equal(s, ref_s)
+    assert torch.equal(x_in, x)  # the input is left untouched
+    if add_residual:
+        assert torch.equal(got_res, ref_res)
+
+
+@pytest.mark.parametrize("num_tokens", [1, 64])
+@pytest.mark.parametrize("d_", [512, 14336, 11008, 28672])
+@pytest.mark.parametrize("dtype", [torch.half, torch.bfloat16])
+def test_silu_and_mul_dynamic_int8_quant_matches_separate_ops(gpu_device, num_tokens, d_, dtype):
+    from neural_magic_vllm_amd import _custom_ops as ops
+    g = torch.Generator().manual_seed(0)
+    x = (torch.randn((num_tokens, 2 * d_), generator=g) * 2).to(dtype).to(gpu_device)
+    act = torch.empty((num_tokens, d_), dtype=dtype, device=gpu_device)
+    ops.silu_and_mul(act, x)
+    ref_q, ref_s = ops.scaled_int8_quant(act)
+    q, s = ops.silu_and_mul_dynamic_int8_quant(x)
+    assert torch.equal(q, ref_q) and torch.equal(s, ref_s)
