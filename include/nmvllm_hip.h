@@ -153,6 +153,15 @@ int nmv_activation(void* out, const void* input, int num_tokens, int d, int act,
  * vLLM grew similar fusions): each is bit-identical to the sequence of reference ops it names and
  * exists because a launch on a [B, hidden] tensor is ~5 us of latency, not bandwidth.
  * ------------------------------------------------------------------------------------------ */
+/* gate_up GEMM with silu_and_mul folded into the epilogue: b_q_weight / b_scales are the Marlin
+ * tensors (gptq_marlin_repack / marlin_permute_scales) of a 4-bit symmetric weight, group 128 or
+ * channelwise, no act-order, whose OUTPUT COLUMNS were interleaved before the repack so that
+ * 64-column chunk c = [gate 32c..32c+31 | up 32c..32c+31]; c: [size_m, size_n / 2].  K % 256 == 0,
+ * N % 128 == 0.  Bit-identical to gptq_marlin_gemm on the original weight + silu_and_mul. */
+int nmv_gptq_marlin_gemm_silu_mul(void* c, const void* a, const int32_t* b_q_weight,
+                                  const void* b_scales, int32_t* workspace, int64_t workspace_len,
+                                  int size_m, int size_n, int size_k, int num_groups,
+                                  nmv_dtype_t dtype, void* stream);
 /* rotary_embedding (pos_encoding_kernels.cu:121-160) followed by reshape_and_cache
  * (cache_kernels.cu:253-278): query / key rotated in place, then key / value of every token with
  * slot_mapping[t] >= 0 written to the paged cache. */

@@ -324,3 +324,9 @@ def rms_norm_dynamic_int8_quant(input: torch.Tensor, residual: Optional[torch.Te
 def silu_and_mul_dynamic_int8_quant(input: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     from neural_magic_vllm_amd import _torch_bindings as tb
     return tb.silu_and_mul_dynamic_int8_quant(input)
+
+
+def gptq_marlin_gemm_silu_mul(a: torch.Tensor, b_q_weight: torch.Tensor, b_scales: torch.Tensor,
+                              workspace: torch.Tensor, size_m: int, size_n: int, size_k: int) -> torch.Tensor:
+    from neural_magic_vllm_amd import _torch_bindings as tb
+    return tb.gptq_marlin_gemm_silu_mul(a, b_q_weight, b_scales, workspace, size_m, size_n, size_k)

@@ -571,6 +571,26 @@ def rotary_embedding_and_cache(positions, query, key, value, head_size, cos_sin_
             kv_scale, stream_of(query)))
 
 
+def gptq_marlin_gemm_silu_mul(a, b_q_weight, b_scales, workspace, size_m, size_n, size_k) -> torch.Tensor:
+    """gate_up GEMM + silu_and_mul in one launch on column-interleaved Marlin weights
+    (include/nmvllm_hip.h: nmv_gptq_marlin_gemm_silu_mul); returns [size_m, size_n // 2]"""
+    _req(a.dim() == 2 and a.shape == (size_m, size_k) and a.is_contiguous(), "gemm_silu_mul: bad a")
+    _req(a.dtype in (torch.float16, torch.bfloat16), "gemm_silu_mul: fp16 / bf16 only")
+    _req(b_q_weight.dtype == torch.int32 and b_q_weight.is_contiguous()
+         and b_q_weight.shape == (size_k // 16, size_n * 2), "gemm_silu_mul: b_q_weight must be int32 [K/16, 2N]")
+    _req(b_scales.dtype == a.dtype and b_scales.is_contiguous() and b_scales.shape[1] == size_n,
+         "gemm_silu_mul: scales must be [groups, N] in A's dtype")
+    _req(workspace.dtype == torch.int32 and workspace.numel() >= size_n // 64 * 16, "gemm_silu_mul: workspace")
+    c = torch.empty((size_m, size_n // 2), dtype=a.dtype, device=a.device)
+    if size_m == 0:
+        return c
+    with device_guard(a):
+        check(_lib.load().nmv_gptq_marlin_gemm_silu_mul(
+            ptr(c), ptr(a), ptr(b_q_weight), ptr(b_scales), ptr(workspace), workspace.numel(), size_m,
+            size_n, size_k, b_scales.shape[0], dtype_code(a.dtype), stream_of(a)))
+    return c
+
+
 def rms_norm_dynamic_int8_quant(input, residual, weight, epsilon):
     """(fused_add_)rms_norm -> dynamic per-token scaled_int8_quant; returns (int8 [T, H], scales [T, 1]);
     residual (or None) is updated in place as fused_add_rms_norm does, input is left untouched"""

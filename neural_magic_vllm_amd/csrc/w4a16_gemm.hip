@@ -87,6 +87,15 @@ template <> struct W4<F16> {
 };
 constexpr float W4_ZP = 24.0f;  // (16 + q) - 24 = q - 8
 
+// float -> model dtype -> float; the bits pass through an empty asm so that the rounding is
+// materialised even when the value never reaches memory (see glue_kernels.hip: pin())
+template <typename T>
+__device__ __forceinline__ float round_trip(float f) {
+  uint32_t b = T::from_float(f);
+  asm volatile("" : "+v"(b));
+  return T::to_float((uint16_t)b);
+}
+
 struct GemmParams {
   const uint16_t* a;      // [M, K]
   const uint4* b;         // Marlin int32 [K/16, N*2] viewed as uint4 [K/16, N/2]
@@ -101,6 +110,8 @@ struct GemmParams {
   int group_size;         // 32/64/128, or 0 = channelwise (one scale row)
   int k_per_wg;           // k range of one workgroup (multiple of WK*STAGE_K)
   int splits;
+  int epi;                // 1: silu(gate) * up epilogue on column-interleaved gate_up weights (tall
+                          //    kernel, splits == 1): c is [M, N/2]
 };
 
 
@@ -885,6 +896,32 @@ __global__ __launch_bounds__(GT, 2) void w4a16_gemm_tall_kernel(const GemmParams
   // ---- epilogue ----
   if (p.splits == 1) {
     if (!writer) return;
+    if (p.epi) {
+      // gate_up with silu_and_mul folded in: the weight columns were interleaved at load time so
+      // that a chunk holds gate[32 c .. 32 c + 31] in tiles 0, 1 and up[32 c .. 32 c + 31] in tiles
+      // 2, 3 -- the lane that holds a gate element holds its up element.  Same roundings as the two
+      // ops it replaces: both GEMM outputs rounded to the model dtype, silu in fp32 rounded to the
+      // model dtype (activation_kernels.cu:14-26), product rounded.
+#pragma unroll
+      for (int t = 0; t < MT; ++t) {
+        const int m = m0 + t * 16 + r;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          float o[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float gb = round_trip<T>(accm[j][t][i]), ub = round_trip<T>(accm[j + 2][t][i]);
+            o[i] = round_trip<T>(gb / (1.0f + expf(-gb))) * ub;
+          }
+          uint2 pk;
+          pk.x = T::pack2(o[0], o[1]);
+          pk.y = T::pack2(o[2], o[3]);
+          *reinterpret_cast<uint2*>(p.c + (int64_t)m * (p.N >> 1) + chunk * 32 + j * 16 + 4 * g) = pk;
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
       const int m = m0 + t * 16 + r;
@@ -1014,7 +1051,7 @@ static int env_int(const char* name, int dflt) {
 // few microseconds at HBM speed, so the plan aims at >= ~2 workgroups per CU while keeping the
 // fp32 partial traffic (splits * M * N * 4 B) well below the weight bytes (K * N / 2).
 static GemmPlan make_plan(int M, int N, int K, int64_t tickets_len, bool allow_tall = false,
-                          int bits = 4) {
+                          int bits = 4, bool unsplit = false) {
   GemmPlan pl;
   const int n_chunks = N / 64;
   pl.tall = 0;
@@ -1048,7 +1085,7 @@ static GemmPlan make_plan(int M, int N, int K, int64_t tickets_len, bool allow_t
     splits = std::min(splits, env_int("NMV_W4_TALL_MAX_SPLITS", 8));
     splits = env_int("NMV_W4_SPLITS", splits);
     splits = std::max(1, std::min(splits, k_units));
-    if ((int64_t)base_wgs > tickets_len) splits = 1;
+    if ((int64_t)base_wgs > tickets_len || unsplit) splits = 1;
     pl.k_per_wg = ((k_units + splits - 1) / splits) * unit;
     pl.splits = (K + pl.k_per_wg - 1) / pl.k_per_wg;
     return pl;
@@ -1207,7 +1244,8 @@ static int marlin_gemm_impl(void* c, const void* a, const int32_t* b_q_weight, c
                             const void* b_zeros, const int32_t* g_idx, const int32_t* perm,
                             int32_t* workspace, int64_t workspace_len, void* scratch,
                             int64_t scratch_bytes, int num_bits, int size_m, int size_n, int size_k,
-                            int num_groups, int is_k_full, nmv_dtype_t dtype, void* stream) {
+                            int num_groups, int is_k_full, nmv_dtype_t dtype, void* stream,
+                            int epi = 0) {
   // `workspace` (the reference's lock array, zero on entry and exit) holds the split-K tickets
   NMV_CHECK(dtype == NMV_F16 || dtype == NMV_BF16,
             "gpt_marlin_gemm only supports bfloat16 and float16");
@@ -1249,7 +1287,10 @@ static int marlin_gemm_impl(void* c, const void* a, const int32_t* b_q_weight, c
   // groups of 32 / 64 and act-order stay on the 16-row kernel
   const bool allow_tall = !has_act_order && (group_size == 0 || group_size == 128);
   const GemmPlan pl = make_plan(size_m, size_n, size_k, workspace ? workspace_len : 0, allow_tall,
-                                num_bits);
+                                num_bits, epi != 0);
+  NMV_CHECK(!epi || (pl.tall && pl.splits == 1 && num_bits == 4 && b_zeros == nullptr && size_n % 128 == 0),
+            "gptq_marlin_gemm_silu_mul: needs 4-bit symmetric codes, group 128 or channelwise, no "
+            "act-order, K %% 256 == 0, N %% 128 == 0");
   const int64_t need = pl.splits > 1 ? (int64_t)pl.splits * size_m * size_n * 4 : 0;
   NMV_CHECK(need < (int64_t)1 << 31, "gptq_marlin_gemm: split-K slab too large");
   NMV_CHECK(scratch_bytes >= need && (need == 0 || scratch != nullptr),
@@ -1271,12 +1312,27 @@ static int marlin_gemm_impl(void* c, const void* a, const int32_t* b_q_weight, c
   p.group_size = group_size;
   p.k_per_wg = pl.k_per_wg;
   p.splits = pl.splits;
+  p.epi = epi;
   hipStream_t s = (hipStream_t)stream;
   const int rc = dtype == NMV_F16 ? launch_gemm<F16>(pl, p, s) : launch_gemm<BF16>(pl, p, s);
   NMV_CHECK(rc == 0, "gptq_marlin_gemm: no kernel for plan mt=%d wn=%d wm=%d wk=%d", pl.mt, pl.wn,
             pl.wm, pl.wk);
   NMV_LAUNCH_CHECK();
   return NMV_OK;
+}
+
+/* gate_up projection with silu_and_mul folded into the epilogue (not an op of nm-vllm 0.5.1).
+ * b_q_weight / b_scales: the Marlin tensors of a weight whose OUTPUT COLUMNS were interleaved before
+ * the repack -- 64-column chunk c = [gate 32c..32c+31 | up 32c..32c+31] -- c: [size_m, size_n / 2].
+ * Bit-identical to gptq_marlin_gemm on the original weight followed by silu_and_mul. */
+extern "C" int nmv_gptq_marlin_gemm_silu_mul(void* c, const void* a, const int32_t* b_q_weight,
+                                             const void* b_scales, int32_t* workspace,
+                                             int64_t workspace_len, int size_m, int size_n,
+                                             int size_k, int num_groups, nmv_dtype_t dtype,
+                                             void* stream) {
+  return marlin_gemm_impl(c, a, b_q_weight, b_scales, nullptr, nullptr, nullptr, workspace,
+                          workspace_len, nullptr, 0, 4, size_m, size_n, size_k, num_groups, 1, dtype,
+                          stream, 1);
 }
 
 /* legacy Marlin checkpoints (csrc/quantization/marlin/dense/marlin_cuda_kernel.cu:1045-1136):

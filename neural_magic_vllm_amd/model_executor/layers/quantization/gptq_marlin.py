@@ -253,8 +253,46 @@ class GPTQMarlinLinearMethod(LinearMethodBase):
                                               cfg.group_size, cfg.weight_bits)
         replace_tensor("scales", marlin_scales)
 
+    # ---- gate_up with silu_and_mul folded into the GEMM epilogue (ops.gptq_marlin_gemm_silu_mul;
+    # not part of the reference's LinearMethod) ----
+    def can_fuse_silu_mul(self, layer: torch.nn.Module) -> bool:
+        """a merged [gate | up] projection whose columns can be interleaved per 64-column chunk before
+        the (first-touch) Marlin repack, and which is wide enough that the GEMM wants no split-K"""
+        cfg = self.quant_config
+        n, k = layer.output_size_per_partition, layer.input_size_per_partition
+        if getattr(layer, "gate_up_interleaved", False):
+            return True
+        return (layer.marlin_state == GPTQMarlinState.REPACK and cfg.weight_bits == 4 and not cfg.desc_act
+                and cfg.group_size in (-1, 128) and k % 256 == 0 and n % 128 == 0 and n // 64 >= 256
+                and getattr(layer, "bias", None) is None and layer.is_k_full)
+
+    @staticmethod
+    def _interleave_gate_up(t: torch.Tensor) -> torch.Tensor:
+        """columns [gate 0..I-1 | up 0..I-1] -> per 64-column chunk c: [gate 32c..32c+31 | up 32c..32c+31]"""
+        lead, n = t.shape[:-1], t.shape[-1]
+        return t.reshape(*lead, 2, n // 64, 32).transpose(-3, -2).reshape(*lead, n).contiguous()
+
+    def apply_silu_mul(self, layer: torch.nn.Module, x: torch.Tensor) -> torch.Tensor:
+        """silu(x @ W_gate) * (x @ W_up) -> [.., N/2], bit-identical to apply() + SiluAndMul"""
+        reshaped_x = x.reshape(-1, x.shape[-1])
+        part_size_n = layer.output_size_per_partition
+        part_size_k = layer.input_size_per_partition
+        if layer.marlin_state == GPTQMarlinState.REPACK:
+            assert self.can_fuse_silu_mul(layer)
+            layer.marlin_state = GPTQMarlinState.READY
+            layer.qweight.data = self._interleave_gate_up(layer.qweight.data)
+            layer.scales.data = self._interleave_gate_up(layer.scales.data)
+            layer.gate_up_interleaved = True
+            self._repack(layer)
+        assert getattr(layer, "gate_up_interleaved", False), "layer was repacked without the interleave"
+        out = ops.gptq_marlin_gemm_silu_mul(reshaped_x, layer.qweight, layer.scales, layer.workspace,
+                                            reshaped_x.shape[0], part_size_n, part_size_k)
+        return out.reshape(x.shape[:-1] + (part_size_n // 2, ))
+
     def apply(self, layer: torch.nn.Module, x: torch.Tensor,
               bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+        assert not getattr(layer, "gate_up_interleaved", False), \
+            "this layer's columns are interleaved for apply_silu_mul()"
         reshaped_x = x.reshape(-1, x.shape[-1])
         size_m = reshaped_x.shape[0]
         part_size_n = layer.output_size_per_partition

@@ -49,6 +49,12 @@ class LlamaMLP(nn.Module):
         self.fused_glue = fused_glue_default()
 
     def forward(self, x):
+        qm = self.gate_up_proj.quant_method
+        if self.fused_glue and not isinstance(x, Int8Activations) and x.is_cuda \
+                and hasattr(qm, "apply_silu_mul") and qm.can_fuse_silu_mul(self.gate_up_proj):
+            # W4A16: silu_and_mul folded into the gate_up GEMM's epilogue (column-interleaved weights)
+            x, _ = self.down_proj(qm.apply_silu_mul(self.gate_up_proj, x))
+            return x
         gate_up, _ = self.gate_up_proj(x)
         if self.fused_glue and gate_up.is_cuda and accepts_int8_activations(self.down_proj):
             # silu_and_mul + dynamic per-token int8 quantisation of down_proj's input: one launch

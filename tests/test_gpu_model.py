@@ -152,22 +152,28 @@ def test_tiny_llama_chunked_prefill_matches_single_shot(gpu_device):
 
 @pytest.mark.parametrize("quant", [dict(method="gptq_marlin", bits=4, group_size=128),
                                    dict(method="w8a8", bits=8, group_size=-1)], ids=["w4a16", "w8a8"])
-def test_fused_glue_is_bit_identical(gpu_device, quant):
-    """the one-launch forms (rotary + cache write; for W8A8 also norm / silu_and_mul + dynamic int8
-    quantisation) against the reference's op-by-op sequence on the same weights: same tokens, same
-    hidden states, same KV cache, bit for bit"""
-    arch, weights, runner = build(quant, gpu_device)
-    mods = [m for m in runner.model.modules() if hasattr(m, "fused_glue")]
-    assert mods and all(m.fused_glue for m in mods)
+@pytest.mark.parametrize("wide_mlp", [False, True], ids=["tiny", "wide_mlp"])
+def test_fused_glue_is_bit_identical(gpu_device, monkeypatch, quant, wide_mlp):
+    """the one-launch forms (rotary + cache write; W8A8: norm / silu_and_mul + dynamic int8
+    quantisation; W4A16 with a wide MLP: silu_and_mul in the gate_up GEMM's epilogue) against the
+    reference's op-by-op sequence on the same weights: same tokens, same KV cache, bit for bit"""
+    import dataclasses
+    from neural_magic_vllm_amd.worker import decode_runner as dr
+    arch = dataclasses.replace(dr.TINY, intermediate_size=8192, num_hidden_layers=1) if wide_mlp else None
     outs = {}
     for fused in (True, False):
-        for m in mods:
-            m.fused_glue = fused
+        monkeypatch.setenv("NMV_FUSED_GLUE", "1" if fused else "0")
+        _, _, runner = build(quant, gpu_device, arch)
+        mods = [m for m in runner.model.modules() if hasattr(m, "fused_glue")]
+        assert mods and all(m.fused_glue == fused for m in mods)
         runner.setup_batch(5, 40, 8)
         runner.fill_context()
         toks = [runner.decode_step().clone() for _ in range(4)]
         torch.cuda.synchronize()
         outs[fused] = (torch.stack(toks).cpu(), [kv.clone() for kv in runner.kv_caches])
+        if fused and wide_mlp and quant["method"] == "gptq_marlin":
+            assert all(getattr(l.mlp.gate_up_proj, "gate_up_interleaved", False)
+                       for l in runner.model.model.layers)
     assert torch.equal(outs[True][0], outs[False][0])
     for a, b in zip(outs[True][1], outs[False][1]):
         assert torch.equal(a.view(torch.int16), b.view(torch.int16))

@@ -235,3 +235,43 @@ def test_marlin_gemm_arg_checks(gpu_device):
         ops.gptq_marlin_gemm(pr["a"].to(d), pr["marlin_q_w"].to(d), pr["marlin_s"].to(d), e, e, ws, 3, 4, 64, 128, True)
     with pytest.raises(RuntimeError, match="workspace"):
         ops.gptq_marlin_gemm(pr["a"].to(d), pr["marlin_q_w"].to(d), pr["marlin_s"].to(d), e, e, ws[:8], 4, 4, 64, 128, True)
+
+
+@pytest.mark.parametrize("m", [1, 16, 33, 64, 130, 512, 1100])
+@pytest.mark.parametrize("group_size", [128, -1])
+@pytest.mark.parametrize("dtype", [torch.half, torch.bfloat16])
+def test_gemm_silu_mul_epilogue_matches_separate_ops(gpu_device, monkeypatch, m, group_size, dtype):
+    """gate_up GEMM with silu_and_mul folded into the epilogue, on column-interleaved weights, against
+    gptq_marlin_gemm on the original weight followed by silu_and_mul: bit for bit, on every row tile
+    (16 / 32 / 64 / 128 rows per wave).  The fused form never splits K, so the comparison pins the
+    plain GEMM to one slab as well (otherwise the fp32 summation order differs)."""
+    monkeypatch.setenv("NMV_W4_SPLITS", "1")
+    from neural_magic_vllm_amd import _custom_ops as ops
+    d = gpu_device
+    k, inter = 512, 8192
+    n = 2 * inter
+    g = torch.Generator().manual_seed(5)
+    a = (torch.randn((m, k), generator=g) * 0.5).to(dtype)
+    w = (torch.randn((k, n), generator=g) * 0.1).to(dtype)
+    _, q_w, s, _, _ = ref_math.quantize_weights(w, 4, group_size, False, g)
+    s = s.to(dtype)
+    e = torch.empty(0, dtype=torch.int32, device=d)
+
+    def marlin(q, sc):
+        mq = ops.gptq_marlin_repack(ref_math.gptq_pack(q, 4, k, n).to(d), e, k, n, 4)
+        ms = ref_math.marlin_permute_scales(sc, k, n, group_size).to(d)
+        return mq, ms
+
+    def interleave(t):
+        return t.reshape(t.shape[0], 2, n // 64, 32).transpose(1, 2).reshape(t.shape[0], n).contiguous()
+
+    ws = torch.zeros(n // 64 * 16, dtype=torch.int32, device=d)
+    mq, ms = marlin(q_w, s)
+    full = ops.gptq_marlin_gemm(a.to(d), mq, ms, e, e, ws, 4, m, n, k, True)
+    ref = torch.empty((m, inter), dtype=dtype, device=d)
+    ops.silu_and_mul(ref, full)
+    mq_i, ms_i = marlin(interleave(q_w), interleave(s))
+    got = ops.gptq_marlin_gemm_silu_mul(a.to(d), mq_i, ms_i, ws, m, n, k)
+    assert got.shape == (m, inter)
+    assert torch.equal(got.view(torch.int16), ref.view(torch.int16))
+    assert int(ws.abs().sum()) == 0
