@@ -162,6 +162,18 @@ int nmv_gptq_marlin_gemm_silu_mul(void* c, const void* a, const int32_t* b_q_wei
                                   const void* b_scales, int32_t* workspace, int64_t workspace_len,
                                   int size_m, int size_n, int size_k, int num_groups,
                                   nmv_dtype_t dtype, void* stream);
+/* greedy sampling (torch.argmax of the reference's Sampler greedy branch; ties -> lowest index) of
+ * logits [num_seqs, vocab_size] (row stride in elements) into next_tokens int64[num_seqs], and --
+ * when positions != NULL -- the on-device advance of a decode batch: input_ids = token,
+ * positions += 1, seq_lens += 1, slot_mapping = block_tables[pos / bs] * bs + pos % bs
+ * (worker/model_runner.py:572-580), so that a captured step can be replayed back to back.
+ * scratch: nmv_greedy_sample_scratch_bytes(num_seqs) bytes. */
+int64_t nmv_greedy_sample_scratch_bytes(int num_seqs);
+int nmv_greedy_sample_advance(int64_t* next_tokens, const void* logits, int64_t row_stride,
+                              int num_seqs, int vocab_size, nmv_dtype_t dtype, void* scratch,
+                              int64_t scratch_bytes, int64_t* input_ids, int64_t* positions,
+                              int* seq_lens, int64_t* slot_mapping, const int* block_tables,
+                              int max_blocks_per_seq, int block_size, void* stream);
 /* rotary_embedding (pos_encoding_kernels.cu:121-160) followed by reshape_and_cache
  * (cache_kernels.cu:253-278): query / key rotated in place, then key / value of every token with
  * slot_mapping[t] >= 0 written to the paged cache. */

@@ -330,3 +330,12 @@ def gptq_marlin_gemm_silu_mul(a: torch.Tensor, b_q_weight: torch.Tensor, b_scale
                               workspace: torch.Tensor, size_m: int, size_n: int, size_k: int) -> torch.Tensor:
     from neural_magic_vllm_amd import _torch_bindings as tb
     return tb.gptq_marlin_gemm_silu_mul(a, b_q_weight, b_scales, workspace, size_m, size_n, size_k)
+
+
+def greedy_sample_advance(logits: torch.Tensor, input_ids: Optional[torch.Tensor] = None,
+                          positions: Optional[torch.Tensor] = None, seq_lens: Optional[torch.Tensor] = None,
+                          slot_mapping: Optional[torch.Tensor] = None,
+                          block_tables: Optional[torch.Tensor] = None, block_size: int = 0) -> torch.Tensor:
+    from neural_magic_vllm_amd import _torch_bindings as tb
+    return tb.greedy_sample_advance(logits, input_ids, positions, seq_lens, slot_mapping, block_tables,
+                                    block_size)

@@ -57,6 +57,8 @@ SIGNATURES = {
     "nmv_rotary_embedding_and_cache": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _L, _L, _L, _P, _I, _P, _P,
                                             _P, _I, _I, _I, _F, _P]),
     "nmv_gptq_marlin_gemm_silu_mul": (_I, [_P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _P]),
+    "nmv_greedy_sample_scratch_bytes": (_L, [_I]),
+    "nmv_greedy_sample_advance": (_I, [_P, _P, _L, _I, _I, _I, _P, _L, _P, _P, _P, _P, _P, _I, _I, _P]),
     "nmv_rms_norm_dynamic_int8_quant": (_I, [_P, _P, _P, _P, _P, _F, _I, _I, _I, _P]),
     "nmv_silu_and_mul_dynamic_int8_quant": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "nmv_activation": (_I, [_P, _P, _I, _I, _I, _I, _P]),

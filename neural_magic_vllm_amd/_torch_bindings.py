@@ -591,6 +591,32 @@ def gptq_marlin_gemm_silu_mul(a, b_q_weight, b_scales, workspace, size_m, size_n
     return c
 
 
+def greedy_sample_advance(logits, input_ids=None, positions=None, seq_lens=None, slot_mapping=None,
+                          block_tables=None, block_size=0) -> torch.Tensor:
+    """argmax over logits [B, V] (ties -> lowest index) -> int64 [B]; with the state tensors also
+    the on-device advance of a decode batch (include/nmvllm_hip.h: nmv_greedy_sample_advance)"""
+    _req(logits.dim() == 2 and logits.stride(1) == 1, "greedy_sample: logits must be [B, V] with contiguous rows")
+    _req(logits.dtype in (torch.float16, torch.bfloat16), "greedy_sample: fp16 / bf16 logits")
+    b, v = logits.shape
+    out = torch.empty((b, ), dtype=torch.int64, device=logits.device)
+    lib = _lib.load()
+    sb = lib.nmv_greedy_sample_scratch_bytes(b)
+    scratch = torch.empty(max(sb, 1), dtype=torch.uint8, device=logits.device)
+    if positions is not None:
+        _req(input_ids.dtype == torch.int64 and positions.dtype == torch.int64
+             and slot_mapping.dtype == torch.int64 and seq_lens.dtype == torch.int32
+             and block_tables.dtype == torch.int32, "greedy_sample: state tensor dtypes")
+        _req(all(t.is_contiguous() and t.numel() == b for t in (input_ids, positions, seq_lens, slot_mapping))
+             and block_tables.dim() == 2 and block_tables.is_contiguous() and block_tables.shape[0] == b,
+             "greedy_sample: state tensors must be contiguous [B]")
+    with device_guard(logits):
+        check(lib.nmv_greedy_sample_advance(
+            ptr(out), ptr(logits), logits.stride(0), b, v, dtype_code(logits.dtype), ptr(scratch), sb,
+            ptr(input_ids), ptr(positions), ptr(seq_lens), ptr(slot_mapping), ptr(block_tables),
+            block_tables.shape[1] if block_tables is not None else 0, block_size, stream_of(logits)))
+    return out
+
+
 def rms_norm_dynamic_int8_quant(input, residual, weight, epsilon):
     """(fused_add_)rms_norm -> dynamic per-token scaled_int8_quant; returns (int8 [T, H], scales [T, 1]);
     residual (or None) is updated in place as fused_add_rms_norm does, input is left untouched"""

@@ -15,12 +15,14 @@ What it reproduces (and nothing more):
 There is no scheduler, block manager, tokenizer or checkpoint loader: those sit above the
 drop-in boundary and stay the reference's own.
 """
+import os
 import time
 from dataclasses import dataclass
 from typing import List, Optional
 
 import torch
 
+from .. import _custom_ops as ops
 from ..attention.backends.rocm_hip_attn import ROCmHipAttentionMetadata
 from ..distributed import (get_tensor_model_parallel_rank, get_tensor_model_parallel_world_size,
                            tensor_model_parallel_all_gather)
@@ -138,6 +140,7 @@ class DecodeRunner:
         self.dtype = dtype
         self.cache_config = cache_config or CacheConfig()
         self.tp_size = get_tensor_model_parallel_world_size()
+        self.fused_step_tail = os.environ.get("NMV_FUSED_GLUE", "1") != "0"
         self.tp_rank = get_tensor_model_parallel_rank()
         quant_config = None
         if quant is not None and quant.get("method") == "w8a8":
@@ -238,6 +241,15 @@ class DecodeRunner:
 
     def _step_body(self) -> torch.Tensor:
         hidden = self.model(self.input_ids, self.positions, self.kv_caches, self._decode_metadata())
+        if self.fused_step_tail:
+            # argmax + state advance in two launches (csrc/sampling.hip) instead of torch.argmax and
+            # five element-wise kernels
+            logits = torch.matmul(hidden, self.model.lm_head.weight.t())
+            if self.tp_size > 1:
+                logits = tensor_model_parallel_all_gather(logits)
+            return ops.greedy_sample_advance(logits[:, :self.arch.vocab_size], self.input_ids, self.positions,
+                                             self.seq_lens, self.slot_mapping, self.block_tables,
+                                             self.cache_config.block_size)
         next_tokens = self._sample(hidden)
         # advance the batch state on device so that a captured step can be replayed back to back
         self.input_ids.copy_(next_tokens)

@@ -250,3 +250,44 @@ def test_silu_and_mul_dynamic_int8_quant_matches_separate_ops(gpu_device, num_to
     ref_q, ref_s = ops.scaled_int8_quant(act)
     q, s = ops.silu_and_mul_dynamic_int8_quant(x)
     assert torch.equal(q, ref_q) and torch.equal(s, ref_s)
+
+
+@pytest.mark.parametrize("b,v,stride", [(1, 128256, 128256), (64, 128256, 128256), (5, 2048, 2048),
+                                       (3, 1000, 1024), (7, 31, 40)])
+@pytest.mark.parametrize("dtype", [torch.half, torch.bfloat16])
+def test_greedy_sample_matches_argmax_with_ties(gpu_device, b, v, stride, dtype):
+    from neural_magic_vllm_amd import _custom_ops as ops
+    g = torch.Generator().manual_seed(0)
+    full = torch.randn((b, stride), generator=g).to(dtype)
+    full[:, v:] = 100.0                 # padding columns beyond the vocabulary must be ignored
+    logits = full.to(gpu_device)[:, :v]
+    got = ops.greedy_sample_advance(logits).cpu()
+    # bf16 / fp16 logits have many exact ties: the lowest index wins
+    ref = torch.stack([(row == row.max()).nonzero()[0, 0] for row in full[:, :v].float()])
+    assert got.dtype == torch.int64 and torch.equal(got, ref)
+    flat = torch.zeros((b, stride), dtype=dtype)
+    flat[:, min(17, v - 1)] = 1.0
+    flat[:, v - 1] = 1.0
+    assert torch.equal(ops.greedy_sample_advance(flat.to(gpu_device)[:, :v]).cpu(),
+                       torch.full((b, ), min(17, v - 1), dtype=torch.int64))
+
+
+def test_greedy_sample_advances_the_decode_state(gpu_device):
+    """input_ids / positions / seq_lens / slot_mapping after the fused tail == the reference's host
+    bookkeeping (model_runner.py:572-580)"""
+    from neural_magic_vllm_amd import _custom_ops as ops
+    d = gpu_device
+    g = torch.Generator().manual_seed(1)
+    b, v, bs, nblk = 6, 512, 16, 9
+    logits = torch.randn((b, v), generator=g).to(torch.bfloat16).to(d)
+    bt = torch.randperm(b * nblk, generator=g).view(b, nblk).to(torch.int32).to(d)
+    positions = torch.tensor([0, 14, 15, 16, 31, 100], dtype=torch.int64, device=d)
+    seq_lens = (positions + 1).to(torch.int32)
+    input_ids = torch.zeros(b, dtype=torch.int64, device=d)
+    slots = torch.zeros(b, dtype=torch.int64, device=d)
+    pos0 = positions.clone()
+    tok = ops.greedy_sample_advance(logits, input_ids, positions, seq_lens, slots, bt, bs)
+    assert torch.equal(tok, logits.float().argmax(-1)) and torch.equal(input_ids, tok)
+    assert torch.equal(positions, pos0 + 1) and torch.equal(seq_lens.long(), pos0 + 2)
+    exp = torch.tensor([int(bt[i, int(positions[i]) // bs]) * bs + int(positions[i]) % bs for i in range(b)])
+    assert torch.equal(slots.cpu(), exp)
