@@ -162,6 +162,32 @@ int nmv_gptq_marlin_gemm_silu_mul(void* c, const void* a, const int32_t* b_q_wei
                                   const void* b_scales, int32_t* workspace, int64_t workspace_len,
                                   int size_m, int size_n, int size_k, int num_groups,
                                   nmv_dtype_t dtype, void* stream);
+/* Deferred split-K reduction: nmv_gptq_marlin_gemm_partial stores the fp32
+ * partial tiles slab[splits, size_m, size_n] (splits = nmv_gptq_marlin_gemm_partial_splits(m, n, k),
+ * 0 = shape not supported) and skips the ticket / last-arriver pass; the consumer sums the slabs in
+ * split order and rounds to the model dtype, bit-identical to nmv_gptq_marlin_gemm's own output.
+ * 4-bit symmetric codes, group 128 or channelwise, no act-order, K % 256 == 0. */
+int nmv_gptq_marlin_gemm_partial_splits(int size_m, int size_n, int size_k);
+int nmv_gptq_marlin_gemm_partial(float* slab, int64_t slab_bytes, const void* a,
+                                 const int32_t* b_q_weight, const void* b_scales, int size_m,
+                                 int size_n, int size_k, int num_groups, nmv_dtype_t dtype,
+                                 void* stream);
+/* fused_add_rms_norm whose input is the slab sum: residual += round(sum_s slab[s]) (in place),
+ * out = rms_norm(residual) * weight.  hidden % 8 == 0, hidden <= 8192. */
+int nmv_fused_add_rms_norm_partial(void* out, const float* slab, int splits, void* residual,
+                                   const void* weight, float epsilon, int num_tokens,
+                                   int hidden_size, nmv_dtype_t dtype, void* stream);
+/* rotary_embedding_and_cache whose qkv row is the slab sum of nmv_gptq_marlin_gemm_partial
+ * (slab [splits, num_tokens, (heads + 2 kv_heads) * head_size] fp32): qkv_out receives the rounded
+ * row with q / k rotated (neox style, rot_dim == head_size; cos_sin_cache [max_pos, head_size]); k / v
+ * go to the paged cache unless key_cache == NULL. */
+int nmv_rotary_embedding_and_cache_partial(const int64_t* positions, const float* slab, int splits,
+                                           void* qkv_out, int num_tokens, int num_heads,
+                                           int num_kv_heads, int head_size, const void* cos_sin_cache,
+                                           void* key_cache, void* value_cache,
+                                           const int64_t* slot_mapping, int block_size,
+                                           nmv_dtype_t dtype, nmv_kv_dtype_t kv_dtype, float kv_scale,
+                                           void* stream);
 /* greedy sampling (torch.argmax of the reference's Sampler greedy branch; ties -> lowest index) of
  * logits [num_seqs, vocab_size] (row stride in elements) into next_tokens int64[num_seqs], and --
  * when positions != NULL -- the on-device advance of a decode batch: input_ids = token,

@@ -339,3 +339,32 @@ def greedy_sample_advance(logits: torch.Tensor, input_ids: Optional[torch.Tensor
     from neural_magic_vllm_amd import _torch_bindings as tb
     return tb.greedy_sample_advance(logits, input_ids, positions, seq_lens, slot_mapping, block_tables,
                                     block_size)
+
+
+# deferred split-K: the GEMM leaves fp32 slabs, the following fused_add_rms_norm sums them
+def gptq_marlin_gemm_partial_splits(size_m: int, size_n: int, size_k: int) -> int:
+    from neural_magic_vllm_amd import _torch_bindings as tb
+    return tb.gptq_marlin_gemm_partial_splits(size_m, size_n, size_k)
+
+
+def gptq_marlin_gemm_partial(a: torch.Tensor, b_q_weight: torch.Tensor, b_scales: torch.Tensor,
+                             size_m: int, size_n: int, size_k: int) -> torch.Tensor:
+    from neural_magic_vllm_amd import _torch_bindings as tb
+    return tb.gptq_marlin_gemm_partial(a, b_q_weight, b_scales, size_m, size_n, size_k)
+
+
+def fused_add_rms_norm_partial(slab: torch.Tensor, residual: torch.Tensor, weight: torch.Tensor,
+                               epsilon: float) -> torch.Tensor:
+    from neural_magic_vllm_amd import _torch_bindings as tb
+    return tb.fused_add_rms_norm_partial(slab, residual, weight, epsilon)
+
+
+def rotary_embedding_and_cache_partial(positions: torch.Tensor, slab: torch.Tensor, num_heads: int,
+                                       num_kv_heads: int, head_size: int, cos_sin_cache: torch.Tensor,
+                                       key_cache: Optional[torch.Tensor], value_cache: Optional[torch.Tensor],
+                                       slot_mapping: Optional[torch.Tensor], kv_cache_dtype: str,
+                                       kv_scale: float, dtype: torch.dtype) -> torch.Tensor:
+    from neural_magic_vllm_amd import _torch_bindings as tb
+    return tb.rotary_embedding_and_cache_partial(positions, slab, num_heads, num_kv_heads, head_size,
+                                                 cos_sin_cache, key_cache, value_cache, slot_mapping,
+                                                 kv_cache_dtype, kv_scale, dtype)

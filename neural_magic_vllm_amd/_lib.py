@@ -57,6 +57,11 @@ SIGNATURES = {
     "nmv_rotary_embedding_and_cache": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _L, _L, _L, _P, _I, _P, _P,
                                             _P, _I, _I, _I, _F, _P]),
     "nmv_gptq_marlin_gemm_silu_mul": (_I, [_P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _P]),
+    "nmv_gptq_marlin_gemm_partial_splits": (_I, [_I, _I, _I]),
+    "nmv_gptq_marlin_gemm_partial": (_I, [_P, _L, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "nmv_fused_add_rms_norm_partial": (_I, [_P, _P, _I, _P, _P, _F, _I, _I, _I, _P]),
+    "nmv_rotary_embedding_and_cache_partial": (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _I, _I,
+                                                    _F, _P]),
     "nmv_greedy_sample_scratch_bytes": (_L, [_I]),
     "nmv_greedy_sample_advance": (_I, [_P, _P, _L, _I, _I, _I, _P, _L, _P, _P, _P, _P, _P, _I, _I, _P]),
     "nmv_rms_norm_dynamic_int8_quant": (_I, [_P, _P, _P, _P, _P, _F, _I, _I, _I, _P]),

@@ -617,6 +617,68 @@ def greedy_sample_advance(logits, input_ids=None, positions=None, seq_lens=None,
     return out
 
 
+def gptq_marlin_gemm_partial_splits(size_m, size_n, size_k) -> int:
+    return int(_lib.load().nmv_gptq_marlin_gemm_partial_splits(size_m, size_n, size_k))
+
+
+def gptq_marlin_gemm_partial(a, b_q_weight, b_scales, size_m, size_n, size_k) -> torch.Tensor:
+    """deferred split-K: fp32 slabs [splits, M, N] for nmv_fused_add_rms_norm_partial to sum
+    (include/nmvllm_hip.h: nmv_gptq_marlin_gemm_partial)"""
+    _req(a.dim() == 2 and a.shape == (size_m, size_k) and a.is_contiguous(), "gemm_partial: bad a")
+    _req(b_q_weight.dtype == torch.int32 and b_q_weight.is_contiguous()
+         and b_q_weight.shape == (size_k // 16, size_n * 2), "gemm_partial: b_q_weight must be int32 [K/16, 2N]")
+    _req(b_scales.dtype == a.dtype and b_scales.is_contiguous() and b_scales.shape[1] == size_n,
+         "gemm_partial: scales must be [groups, N] in A's dtype")
+    lib = _lib.load()
+    splits = lib.nmv_gptq_marlin_gemm_partial_splits(size_m, size_n, size_k)
+    _req(splits >= 1, "gemm_partial: shape not supported")
+    slab = torch.empty((splits, size_m, size_n), dtype=torch.float32, device=a.device)
+    with device_guard(a):
+        check(lib.nmv_gptq_marlin_gemm_partial(ptr(slab), slab.numel() * 4, ptr(a), ptr(b_q_weight),
+                                               ptr(b_scales), size_m, size_n, size_k, b_scales.shape[0],
+                                               dtype_code(a.dtype), stream_of(a)))
+    return slab
+
+
+def fused_add_rms_norm_partial(slab, residual, weight, epsilon) -> torch.Tensor:
+    """residual += round(sum of the slabs); returns rms_norm(residual) * weight"""
+    _req(slab.dim() == 3 and slab.dtype == torch.float32 and slab.is_contiguous(), "norm_partial: slab [S, T, H] fp32")
+    _req(residual.is_contiguous() and residual.shape[-1] == slab.shape[2]
+         and residual.numel() == slab.shape[1] * slab.shape[2], "norm_partial: residual shape")
+    out = torch.empty_like(residual)
+    with device_guard(residual):
+        check(_lib.load().nmv_fused_add_rms_norm_partial(
+            ptr(out), ptr(slab), slab.shape[0], ptr(residual), ptr(weight), epsilon, slab.shape[1],
+            slab.shape[2], dtype_code(residual.dtype), stream_of(residual)))
+    return out
+
+
+def rotary_embedding_and_cache_partial(positions, slab, num_heads, num_kv_heads, head_size, cos_sin_cache,
+                                       key_cache, value_cache, slot_mapping, kv_cache_dtype, kv_scale,
+                                       dtype) -> torch.Tensor:
+    """qkv = round(sum of the split-K slabs); neox rope on q / k; k / v -> paged cache (skipped when
+    key_cache is None); returns the rounded, rotated qkv row [T, (heads + 2 kv_heads) * head_size]"""
+    _req(slab.dim() == 3 and slab.dtype == torch.float32 and slab.is_contiguous(), "rope_partial: slab [S, T, N] fp32")
+    s_, t, n = slab.shape
+    _req(n == (num_heads + 2 * num_kv_heads) * head_size, "rope_partial: slab width != qkv width")
+    _req(positions.dtype == torch.int64 and positions.numel() == t, "positions must be int64 [T]")
+    _req(cos_sin_cache.dtype == dtype and cos_sin_cache.shape[1] == head_size and cos_sin_cache.is_contiguous(),
+         "rope_partial: cos_sin_cache must be [max_pos, head_size] in the model dtype (rot_dim == head_size)")
+    out = torch.empty((t, n), dtype=dtype, device=slab.device)
+    block_size = 0
+    if key_cache is not None:
+        _req(slot_mapping.dtype == torch.int64 and slot_mapping.numel() == t, "slot_mapping must be int64 [T]")
+        _req(key_cache.is_contiguous() and value_cache.is_contiguous(), "caches must be contiguous")
+        _req(key_cache.shape[1] == num_kv_heads and value_cache.shape[1] == num_kv_heads, "cache kv-head count")
+        block_size = key_cache.shape[3]
+    with device_guard(slab):
+        check(_lib.load().nmv_rotary_embedding_and_cache_partial(
+            ptr(positions), ptr(slab), s_, ptr(out), t, num_heads, num_kv_heads, head_size,
+            ptr(cos_sin_cache), ptr(key_cache), ptr(value_cache), ptr(slot_mapping), block_size,
+            dtype_code(dtype), kv_dtype_code(kv_cache_dtype), kv_scale, stream_of(slab)))
+    return out
+
+
 def rms_norm_dynamic_int8_quant(input, residual, weight, epsilon):
     """(fused_add_)rms_norm -> dynamic per-token scaled_int8_quant; returns (int8 [T, H], scales [T, 1]);
     residual (or None) is updated in place as fused_add_rms_norm does, input is left untouched"""

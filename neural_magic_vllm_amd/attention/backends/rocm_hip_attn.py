@@ -143,6 +143,29 @@ class ROCmHipAttentionImpl(AttentionImpl):
                                        kv_scale)
         return True
 
+    def rope_and_cache_partial(self, positions: torch.Tensor, slab: torch.Tensor, rotary_emb,
+                               kv_cache: Optional[torch.Tensor],
+                               attn_metadata: ROCmHipAttentionMetadata, kv_scale: float,
+                               dtype: torch.dtype) -> Optional[torch.Tensor]:
+        """rope_and_cache() whose qkv row is still the fp32 split-K slabs of the qkv projection
+        (ops.gptq_marlin_gemm_partial): returns the rounded, rotated qkv [T, (H + 2 KVH) * D] with k / v
+        already in the cache, or None when the fused form does not apply (GPT-J style rope, partial
+        rotary dim)."""
+        if not rotary_emb.is_neox_style or rotary_emb.rotary_dim != self.head_size \
+                or dtype not in (torch.float16, torch.bfloat16):
+            return None
+        cos_sin = rotary_emb.cos_sin_cache
+        if cos_sin.device != slab.device or cos_sin.dtype != dtype:
+            cos_sin = rotary_emb.cos_sin_cache = cos_sin.to(slab.device, dtype=dtype)
+        key_cache = value_cache = slots = None
+        if kv_cache is not None:
+            key_cache, value_cache = PagedAttention.split_kv_cache(kv_cache, self.num_kv_heads,
+                                                                   self.head_size)
+            slots = attn_metadata.slot_mapping.flatten()
+        return ops.rotary_embedding_and_cache_partial(positions, slab, self.num_heads, self.num_kv_heads,
+                                                      self.head_size, cos_sin, key_cache, value_cache,
+                                                      slots, self.kv_cache_dtype, kv_scale, dtype)
+
     def forward(self, query: torch.Tensor, key: torch.Tensor, value: torch.Tensor,
                 kv_cache: Optional[torch.Tensor], attn_metadata: ROCmHipAttentionMetadata,
                 kv_scale: float = 1.0, cache_written: bool = False) -> torch.Tensor:

@@ -60,6 +60,15 @@ class Attention(nn.Module):
             return False
         return fused(positions, query, key, value, rotary_emb, kv_cache, attn_metadata, self._kv_scale)
 
+    def rope_and_cache_partial(self, positions: torch.Tensor, slab: torch.Tensor, rotary_emb,
+                               kv_cache: Optional[torch.Tensor], attn_metadata: AttentionMetadata,
+                               dtype: torch.dtype) -> Optional[torch.Tensor]:
+        """as rope_and_cache, from the un-reduced split-K slabs of the qkv projection"""
+        fused = getattr(self.impl, "rope_and_cache_partial", None)
+        if fused is None:
+            return None
+        return fused(positions, slab, rotary_emb, kv_cache, attn_metadata, self._kv_scale, dtype)
+
     def extra_repr(self) -> str:
         return (f"head_size={self.impl.head_size}, num_heads={self.impl.num_heads}, "
                 f"num_kv_heads={self.impl.num_kv_heads}, scale={self.impl.scale}, "

@@ -144,26 +144,45 @@ __global__ __launch_bounds__(256) void rms_norm_kernel(uint16_t* out,       // [
 // QUANT: the normalised row (rounded to the model dtype exactly as the stand-alone op does) is not
 // stored but quantised to int8 with a dynamic per-token scale, i.e. rms_norm -> scaled_int8_quant
 // (dynamic) in one launch for the W8A8 linears.
-template <typename T, bool FUSED_ADD, int NV, bool QUANT>
-__global__ __launch_bounds__(256) void rms_norm_reg_kernel(void* out_v, uint16_t* input,
+// SLABS: the input row is the sum of `splits` fp32 split-K slabs of the preceding GEMM
+// (nmv_gptq_marlin_gemm_partial), added in split order from +0 and rounded to the model dtype --
+// exactly what the GEMM's own last-arriver pass would have stored.
+template <typename T, bool FUSED_ADD, int NV, bool QUANT, bool SLABS = false, int THREADS = 256>
+__global__ __launch_bounds__(THREADS) void rms_norm_reg_kernel(void* out_v, uint16_t* input,
                                                            uint16_t* residual,
                                                            const uint16_t* __restrict__ weight,
                                                            float* __restrict__ q_scale,
-                                                           float epsilon, int hidden) {
+                                                           float epsilon, int hidden,
+                                                           const float* __restrict__ slab = nullptr,
+                                                           int splits = 0, int64_t slab_stride = 0) {
   __shared__ float red[16];
   const int64_t row = (int64_t)blockIdx.x * hidden;
   const int nv = hidden / 8;
   uint32_t xs[NV][4];
   uint4 w[NV];
   float var = 0.f;
+  float terms[4] = {0.f, 0.f, 0.f, 0.f};  // THREADS > 256 (NV == 1): the four addends of this lane's vector
+  static_assert(THREADS == 256 || (NV == 1 && FUSED_ADD), "the wide form holds one vector per lane");
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
-    const int v = threadIdx.x + i * 256;
+    const int v = threadIdx.x + i * THREADS;
     const bool ok = v < nv;
     const int vc = ok ? v : nv - 1;
     w[i] = ld16(weight + vc * 8);
-    const uint4 x = ld16(input + row + vc * 8);
-    xs[i][0] = x.x, xs[i][1] = x.y, xs[i][2] = x.z, xs[i][3] = x.w;
+    if constexpr (SLABS) {
+      f32x4_t lo4 = {0.f, 0.f, 0.f, 0.f}, hi4 = {0.f, 0.f, 0.f, 0.f};
+      const float* src = slab + row + vc * 8;
+#pragma unroll 4
+      for (int sp = 0; sp < splits; ++sp) {
+        lo4 += *reinterpret_cast<const f32x4_t*>(src + sp * slab_stride);
+        hi4 += *reinterpret_cast<const f32x4_t*>(src + sp * slab_stride + 4);
+      }
+      xs[i][0] = T::pack2(lo4[0], lo4[1]), xs[i][1] = T::pack2(lo4[2], lo4[3]);
+      xs[i][2] = T::pack2(hi4[0], hi4[1]), xs[i][3] = T::pack2(hi4[2], hi4[3]);
+    } else {
+      const uint4 x = ld16(input + row + vc * 8);
+      xs[i][0] = x.x, xs[i][1] = x.y, xs[i][2] = x.z, xs[i][3] = x.w;
+    }
     if constexpr (FUSED_ADD) {
       const uint4 r = ld16(residual + row + vc * 8);
       const uint32_t rs[4] = {r.x, r.y, r.z, r.w};
@@ -174,6 +193,7 @@ __global__ __launch_bounds__(256) void rms_norm_reg_kernel(void* out_v, uint16_t
         const float hi = rnd<T>(hi_f<T>(xs[i][j]) + hi_f<T>(rs[j]));
         xs[i][j] = T::pack2(lo, hi);
         if (ok) var += lo * lo + hi * hi;
+        if constexpr (THREADS > 256) terms[j] = ok ? lo * lo + hi * hi : 0.f;
       }
       if (ok) st16(residual + row + v * 8, make_uint4(xs[i][0], xs[i][1], xs[i][2], xs[i][3]));
     } else {
@@ -184,12 +204,27 @@ __global__ __launch_bounds__(256) void rms_norm_reg_kernel(void* out_v, uint16_t
       }
     }
   }
+  if constexpr (THREADS > 256) {
+    // more lanes than the 256-lane form: replay that form's per-lane accumulation (the four addends
+    // of vector t, then of t + 256, ...) on lanes 0..255 so that the variance is bit-identical to it
+    __shared__ float fold[THREADS][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) fold[threadIdx.x][j] = terms[j];
+    __syncthreads();
+    var = 0.f;
+    if (threadIdx.x < 256) {
+#pragma unroll
+      for (int q = 0; q < THREADS / 256; ++q)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) var += fold[threadIdx.x + q * 256][j];
+    }
+  }
   var = block_sum_256(var, red);
   const float s = rsqrtf(var / hidden + epsilon);
   float amax = 0.f;
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
-    const int v = threadIdx.x + i * 256;
+    const int v = threadIdx.x + i * THREADS;
     const uint32_t ws[4] = {w[i].x, w[i].y, w[i].z, w[i].w};
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -212,7 +247,7 @@ __global__ __launch_bounds__(256) void rms_norm_reg_kernel(void* out_v, uint16_t
     const float mul = 127.0f / amax;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const int v = threadIdx.x + i * 256;
+      const int v = threadIdx.x + i * THREADS;
       uint2 o;
       o.x = q8(lo_f<T>(xs[i][0]), mul) | (q8(hi_f<T>(xs[i][0]), mul) << 8) |
             (q8(lo_f<T>(xs[i][1]), mul) << 16) | (q8(hi_f<T>(xs[i][1]), mul) << 24);
@@ -369,6 +404,101 @@ __global__ void rope_and_cache_kernel(const int64_t* __restrict__ positions, uin
     const int rot_offset = i % embed_dim;
     rope_one<T, IS_NEOX>(query + token_idx * query_stride + (int64_t)head_idx * head_size, cos_ptr,
                          sin_ptr, rot_offset, embed_dim);
+  }
+}
+
+// rope_and_cache_kernel whose q / k / v come from the fp32 split-K slabs of the qkv projection
+// (nmv_gptq_marlin_gemm_partial): each element is the slab sum in split order from +0, rounded to
+// the model dtype -- what the GEMM's own last-arriver pass would have stored -- then exactly the
+// arithmetic above.  A lane owns 4 consecutive head dims (16-byte slab reads): for neox pairs
+// (d, d + rot/2) that is 4 pairs of a q or k head, or 4 v elements.  The rounded qkv row is also
+// written out ([T, (heads + 2 kv_heads) * head_size]) for the attention kernels.  neox style,
+// rot_dim == head_size.
+template <typename T, bool FP8>
+__global__ __launch_bounds__(512) void rope_and_cache_slab_kernel(
+    const int64_t* __restrict__ positions, const float* __restrict__ slab, int splits,
+    int64_t slab_stride, uint16_t* __restrict__ qkv_out, const uint16_t* __restrict__ cos_sin_cache,
+    int num_heads, int num_kv_heads, int head_size, void* key_cache, void* value_cache,
+    const int64_t* __restrict__ slot_mapping, int block_size, float kv_scale) {
+  const int token_idx = blockIdx.x;
+  const int64_t pos = positions[token_idx];
+  const int64_t slot_idx = (key_cache != nullptr) ? slot_mapping[token_idx] : -1;
+  const bool cached = slot_idx >= 0;
+  const int64_t block_idx = cached ? slot_idx / block_size : 0;
+  const int64_t block_offset = cached ? slot_idx % block_size : 0;
+  const int embed_dim = head_size / 2;
+  const uint16_t* cos_ptr = cos_sin_cache + pos * head_size;
+  const uint16_t* sin_ptr = cos_ptr + embed_dim;
+  const int row_elems = (num_heads + 2 * num_kv_heads) * head_size;
+  const float* src_row = slab + (int64_t)token_idx * row_elems;
+  uint16_t* dst_row = qkv_out + (int64_t)token_idx * row_elems;
+  auto slab_sum4 = [&](int col, float (&o)[4]) {
+    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int sp = 0; sp < splits; ++sp)
+      acc += *reinterpret_cast<const f32x4_t*>(src_row + sp * slab_stride + col);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = rnd<T>(acc[i]);  // the GEMM's output rounding
+  };
+  const int quads = embed_dim / 4;                 // items per rotated head
+  const int n_rot = (num_heads + num_kv_heads) * quads;
+  const int n_v = num_kv_heads * head_size / 4;
+  for (int it = threadIdx.x; it < n_rot + n_v; it += blockDim.x) {
+    if (it < n_rot) {
+      const int head = it / quads;                 // q heads first, then k heads (qkv column order)
+      const int d0 = (it % quads) * 4;
+      const int col = head * head_size + d0;
+      float x[4], y[4];
+      slab_sum4(col, x);
+      slab_sum4(col + embed_dim, y);
+      const uint2 cw = *reinterpret_cast<const uint2*>(cos_ptr + d0);
+      const uint2 sw = *reinterpret_cast<const uint2*>(sin_ptr + d0);
+      const uint32_t cs[2] = {cw.x, cw.y}, sn[2] = {sw.x, sw.y};
+      uint16_t xo[4], yo[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float c = (i & 1) ? hi_f<T>(cs[i >> 1]) : lo_f<T>(cs[i >> 1]);
+        const float s = (i & 1) ? hi_f<T>(sn[i >> 1]) : lo_f<T>(sn[i >> 1]);
+        xo[i] = T::from_float(rnd<T>(x[i] * c) - rnd<T>(y[i] * s));
+        yo[i] = T::from_float(rnd<T>(y[i] * c) + rnd<T>(x[i] * s));
+      }
+      uint2 px, py;
+      px.x = xo[0] | ((uint32_t)xo[1] << 16), px.y = xo[2] | ((uint32_t)xo[3] << 16);
+      py.x = yo[0] | ((uint32_t)yo[1] << 16), py.y = yo[2] | ((uint32_t)yo[3] << 16);
+      *reinterpret_cast<uint2*>(dst_row + col) = px;
+      *reinterpret_cast<uint2*>(dst_row + col + embed_dim) = py;
+      if (cached && head >= num_heads) {
+        const int64_t hb = block_idx * num_kv_heads + (head - num_heads);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          cache_store_k<T, FP8>(key_cache, hb, head_size, block_size, block_offset, d0 + i, xo[i], kv_scale);
+          cache_store_k<T, FP8>(key_cache, hb, head_size, block_size, block_offset, d0 + embed_dim + i, yo[i], kv_scale);
+        }
+      }
+    } else {
+      const int e0 = (it - n_rot) * 4;             // element of the v part
+      const int col = (num_heads + num_kv_heads) * head_size + e0;
+      float v[4];
+      slab_sum4(col, v);
+      uint16_t vb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) vb[i] = T::from_float(v[i]);
+      uint2 pv;
+      pv.x = vb[0] | ((uint32_t)vb[1] << 16), pv.y = vb[2] | ((uint32_t)vb[3] << 16);
+      *reinterpret_cast<uint2*>(dst_row + col) = pv;
+      if (cached) {
+        const int head_idx = e0 / head_size, head_off = e0 % head_size;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int64_t tgt =
+              ((block_idx * num_kv_heads + head_idx) * head_size + head_off + i) * block_size + block_offset;
+          if constexpr (!FP8)
+            reinterpret_cast<uint16_t*>(value_cache)[tgt] = vb[i];
+          else
+            reinterpret_cast<uint8_t*>(value_cache)[tgt] = f32_to_fp8(T::to_float(vb[i]) / kv_scale);
+        }
+      }
+    }
   }
 }
 
@@ -567,6 +697,35 @@ extern "C" int nmv_rms_norm_dynamic_int8_quant(void* out_q, float* scales, const
   return NMV_OK;
 }
 
+extern "C" int nmv_fused_add_rms_norm_partial(void* out, const float* slab, int splits, void* residual,
+                                              const void* weight, float epsilon, int num_tokens,
+                                              int hidden_size, nmv_dtype_t dtype, void* stream) {
+  NMV_HALF_ONLY("fused_add_rms_norm_partial");
+  NMV_CHECK(splits >= 1 && residual != nullptr && slab != nullptr, "fused_add_rms_norm_partial: bad arguments");
+  NMV_CHECK(hidden_size % 8 == 0 && hidden_size <= 8192 &&
+                (((uintptr_t)slab | (uintptr_t)out | (uintptr_t)residual | (uintptr_t)weight) & 15) == 0,
+            "fused_add_rms_norm_partial: hidden_size must be a multiple of 8, <= 8192, 16-byte aligned rows");
+  if (num_tokens == 0) return NMV_OK;
+  // one 16-byte vector (8 elements = 2 x 16 bytes of every slab) per lane: the slab reads are the
+  // work here, so the row gets as many waves as it has vectors (up to 16) to keep them in flight
+  dim3 grid(num_tokens);
+  hipStream_t s = (hipStream_t)stream;
+  const int vecs = hidden_size / 8;
+  const int64_t stride = (int64_t)num_tokens * hidden_size;
+#define RMS_SLAB(T, TH_)                                                                               \
+  hipLaunchKernelGGL((rms_norm_reg_kernel<T, true, 1, false, true, TH_>), grid, dim3(TH_), 0, s, out,  \
+                     (uint16_t*)nullptr, (uint16_t*)residual, (const uint16_t*)weight,                 \
+                     (float*)nullptr, epsilon, hidden_size, slab, splits, stride)
+  if (dtype == NMV_F16) {
+    if (vecs <= 256) RMS_SLAB(F16, 256); else if (vecs <= 512) RMS_SLAB(F16, 512); else RMS_SLAB(F16, 1024);
+  } else {
+    if (vecs <= 256) RMS_SLAB(BF16, 256); else if (vecs <= 512) RMS_SLAB(BF16, 512); else RMS_SLAB(BF16, 1024);
+  }
+#undef RMS_SLAB
+  NMV_LAUNCH_CHECK();
+  return NMV_OK;
+}
+
 extern "C" int nmv_silu_and_mul_dynamic_int8_quant(void* out_q, float* scales, const void* input,
                                                    int num_tokens, int d, nmv_dtype_t dtype,
                                                    void* stream) {
@@ -672,6 +831,42 @@ extern "C" int nmv_rotary_embedding_and_cache(const int64_t* positions, void* qu
   if (dtype == NMV_F16) LAUNCH_RC_T(F16) else LAUNCH_RC_T(BF16)
 #undef LAUNCH_RC_T
 #undef LAUNCH_RC
+  NMV_LAUNCH_CHECK();
+  return NMV_OK;
+}
+
+extern "C" int nmv_rotary_embedding_and_cache_partial(const int64_t* positions, const float* slab,
+                                                      int splits, void* qkv_out, int num_tokens,
+                                                      int num_heads, int num_kv_heads, int head_size,
+                                                      const void* cos_sin_cache, void* key_cache,
+                                                      void* value_cache, const int64_t* slot_mapping,
+                                                      int block_size, nmv_dtype_t dtype,
+                                                      nmv_kv_dtype_t kv_dtype, float kv_scale,
+                                                      void* stream) {
+  NMV_HALF_ONLY("rotary_embedding_and_cache_partial");
+  NMV_CHECK(splits >= 1 && slab != nullptr && qkv_out != nullptr, "rotary_embedding_and_cache_partial: bad arguments");
+  NMV_CHECK(head_size % 16 == 0 && num_heads > 0 && num_kv_heads > 0,
+            "rotary_embedding_and_cache_partial: head_size must be a multiple of 16");
+  NMV_CHECK(kv_dtype == NMV_KV_AUTO || kv_dtype == NMV_KV_FP8_E4M3,
+            "rotary_embedding_and_cache_partial: unsupported kv cache dtype %d", (int)kv_dtype);
+  NMV_CHECK((key_cache == nullptr) == (value_cache == nullptr) &&
+                (key_cache == nullptr || (slot_mapping != nullptr && block_size > 0)),
+            "rotary_embedding_and_cache_partial: caches / slot_mapping");
+  if (num_tokens == 0) return NMV_OK;
+  const int64_t stride = (int64_t)num_tokens * (num_heads + 2 * num_kv_heads) * head_size;
+  dim3 grid(num_tokens), block(512);
+  hipStream_t s = (hipStream_t)stream;
+#define LAUNCH_RS(T, FP8)                                                                          \
+  hipLaunchKernelGGL((rope_and_cache_slab_kernel<T, FP8>), grid, block, 0, s, positions, slab,     \
+                     splits, stride, (uint16_t*)qkv_out, (const uint16_t*)cos_sin_cache, num_heads, \
+                     num_kv_heads, head_size, key_cache, value_cache, slot_mapping, block_size,    \
+                     kv_scale)
+  if (dtype == NMV_F16) {
+    if (kv_dtype == NMV_KV_AUTO) LAUNCH_RS(F16, false); else LAUNCH_RS(F16, true);
+  } else {
+    if (kv_dtype == NMV_KV_AUTO) LAUNCH_RS(BF16, false); else LAUNCH_RS(BF16, true);
+  }
+#undef LAUNCH_RS
   NMV_LAUNCH_CHECK();
   return NMV_OK;
 }

@@ -112,6 +112,9 @@ struct GemmParams {
   int splits;
   int epi;                // 1: silu(gate) * up epilogue on column-interleaved gate_up weights (tall
                           //    kernel, splits == 1): c is [M, N/2]
+                          // 2: deferred reduction: every workgroup stores its fp32 partial tile in
+                          //    slab[split] (also when splits == 1) and returns -- no ticket, no
+                          //    last-arriver pass; the consumer kernel sums the slabs
 };
 
 
@@ -136,8 +139,10 @@ __device__ __forceinline__ void splitk_reduce_tile(const GemmParams& p, __amdgpu
   const int f4_per_row = cols >> 2;
   const int n_elems = rows * f4_per_row;
   const int64_t split_stride = (int64_t)p.M * p.N * 4;  // bytes
-  int parts = 1;  // uniform: partitions of the split range
-  while (parts * 2 * n_elems <= GT && parts * 2 <= p.splits) parts *= 2;
+  // uniform: either one split per partition or no partitioning, so that the association is always
+  // ((0 + s0) + s1) + ... -- the order the consumers of deferred slabs (nmv_fused_add_rms_norm_partial)
+  // reproduce bit for bit
+  const int parts = (p.splits * n_elems <= GT) ? p.splits : 1;
   const int per_part = (p.splits + parts - 1) / parts;
   // exactly the loads that are needed, in batches of 16 / 8 / 4 / 2 / 1 all in flight together
   auto sum_range = [&](int off0, int s_begin, int s_end) -> f32x4_t {
@@ -894,7 +899,7 @@ __global__ __launch_bounds__(GT, 2) void w4a16_gemm_tall_kernel(const GemmParams
   const bool writer = (wk == 0) && chunk_ok;
 
   // ---- epilogue ----
-  if (p.splits == 1) {
+  if (p.splits == 1 && p.epi != 2) {
     if (!writer) return;
     if (p.epi) {
       // gate_up with silu_and_mul folded in: the weight columns were interleaved at load time so
@@ -954,6 +959,7 @@ __global__ __launch_bounds__(GT, 2) void w4a16_gemm_tall_kernel(const GemmParams
       }
     }
   }
+  if (p.epi == 2) return;  // deferred: the next kernel in the stream sums the slabs (kernel boundary = release)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __shared__ int ticket_s;
   __syncthreads();
@@ -1286,12 +1292,16 @@ static int marlin_gemm_impl(void* c, const void* a, const int32_t* b_q_weight, c
   // the tall kernel covers the prevalent formats (group 128 / channelwise, no act-order gather);
   // groups of 32 / 64 and act-order stay on the 16-row kernel
   const bool allow_tall = !has_act_order && (group_size == 0 || group_size == 128);
-  const GemmPlan pl = make_plan(size_m, size_n, size_k, workspace ? workspace_len : 0, allow_tall,
-                                num_bits, epi != 0);
-  NMV_CHECK(!epi || (pl.tall && pl.splits == 1 && num_bits == 4 && b_zeros == nullptr && size_n % 128 == 0),
+  const GemmPlan pl = make_plan(size_m, size_n, size_k,
+                                epi == 2 ? INT64_MAX : (workspace ? workspace_len : 0), allow_tall,
+                                num_bits, epi == 1);
+  NMV_CHECK(epi != 2 || (pl.tall && num_bits == 4 && b_zeros == nullptr),
+            "gptq_marlin_gemm_partial: needs 4-bit symmetric codes, group 128 or channelwise, no "
+            "act-order, K %% 256 == 0");
+  NMV_CHECK(epi != 1 || (pl.tall && pl.splits == 1 && num_bits == 4 && b_zeros == nullptr && size_n % 128 == 0),
             "gptq_marlin_gemm_silu_mul: needs 4-bit symmetric codes, group 128 or channelwise, no "
             "act-order, K %% 256 == 0, N %% 128 == 0");
-  const int64_t need = pl.splits > 1 ? (int64_t)pl.splits * size_m * size_n * 4 : 0;
+  const int64_t need = (pl.splits > 1 || epi == 2) ? (int64_t)pl.splits * size_m * size_n * 4 : 0;
   NMV_CHECK(need < (int64_t)1 << 31, "gptq_marlin_gemm: split-K slab too large");
   NMV_CHECK(scratch_bytes >= need && (need == 0 || scratch != nullptr),
             "gptq_marlin_gemm: scratch too small (%lld < %lld)", (long long)scratch_bytes,
@@ -1333,6 +1343,27 @@ extern "C" int nmv_gptq_marlin_gemm_silu_mul(void* c, const void* a, const int32
   return marlin_gemm_impl(c, a, b_q_weight, b_scales, nullptr, nullptr, nullptr, workspace,
                           workspace_len, nullptr, 0, 4, size_m, size_n, size_k, num_groups, 1, dtype,
                           stream, 1);
+}
+
+/* Deferred split-K (not an op of nm-vllm 0.5.1): the GEMM stores its fp32 partial tiles in
+ * slab[splits, size_m, size_n] and returns; the consumer (nmv_fused_add_rms_norm_partial) sums them
+ * in split order -- the same association and rounding as the last-arriver pass of
+ * nmv_gptq_marlin_gemm, which this removes from the critical path (ticket round trip + slab
+ * re-read: 2-3 us per call at decode sizes).  4-bit symmetric codes, group 128 or channelwise, no
+ * act-order, K % 256 == 0.  nmv_gptq_marlin_gemm_partial_splits returns the slab count (>= 1) the
+ * call will write for a shape, or 0 when the shape is not supported. */
+extern "C" int nmv_gptq_marlin_gemm_partial_splits(int size_m, int size_n, int size_k) {
+  if (size_m <= 0 || size_n <= 0 || size_k <= 0 || size_n % 64 != 0 || size_k % 256 != 0) return 0;
+  const GemmPlan pl = make_plan(size_m, size_n, size_k, INT64_MAX, true, 4, false);
+  return pl.tall ? pl.splits : 0;
+}
+
+extern "C" int nmv_gptq_marlin_gemm_partial(float* slab, int64_t slab_bytes, const void* a,
+                                            const int32_t* b_q_weight, const void* b_scales,
+                                            int size_m, int size_n, int size_k, int num_groups,
+                                            nmv_dtype_t dtype, void* stream) {
+  return marlin_gemm_impl(nullptr, a, b_q_weight, b_scales, nullptr, nullptr, nullptr, nullptr, 0, slab,
+                          slab_bytes, 4, size_m, size_n, size_k, num_groups, 1, dtype, stream, 2);
 }
 
 /* legacy Marlin checkpoints (csrc/quantization/marlin/dense/marlin_cuda_kernel.cu:1045-1136):

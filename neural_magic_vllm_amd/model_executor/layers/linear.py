@@ -11,6 +11,8 @@ row-parallel all-reduce goes through RCCL (distributed/communication_op.py).
 from typing import List, Optional, Tuple
 
 import torch
+
+from ... import _custom_ops as ops
 import torch.nn.functional as F
 from torch.nn.parameter import Parameter
 
@@ -145,6 +147,19 @@ class ColumnParallelLinear(LinearBase):
             loaded_weight = loaded_weight.reshape(1)
         assert param_data.shape == loaded_weight.shape
         param_data.copy_(loaded_weight)
+
+    def forward_partial(self, input_):
+        """Deferred split-K (not in the reference): the fp32 slabs [splits, T, N_partition] of X A for
+        a consumer that sums them (ops.rotary_embedding_and_cache_partial), or None when this layer
+        cannot defer (bias, gathered output, quantisation method / shape without the partial GEMM)."""
+        qm = self.quant_method
+        if self.bias is not None or self.gather_output or not hasattr(qm, "apply_partial") \
+                or not isinstance(input_, torch.Tensor) or not input_.is_cuda or not qm.can_defer_reduce(self):
+            return None
+        rows = input_.numel() // input_.shape[-1]
+        if ops.gptq_marlin_gemm_partial_splits(rows, self.output_size_per_partition, self.input_size) < 1:
+            return None
+        return qm.apply_partial(self, input_)
 
     def forward(self, input_):
         bias = self.bias if not self.skip_bias_add else None
@@ -324,6 +339,21 @@ class RowParallelLinear(LinearBase):
             loaded_weight = loaded_weight.reshape(1)
         assert param_data.shape == loaded_weight.shape
         param_data.copy_(loaded_weight)
+
+    def forward_partial(self, input_):
+        """Deferred split-K (not in the reference): the fp32 slabs [splits, T, N] of X A, for a
+        consumer that sums them (ops.fused_add_rms_norm_partial), or None when this layer cannot
+        defer -- a result that still has to be all-reduced or biased, or a quantisation method /
+        shape without the partial GEMM."""
+        qm = self.quant_method
+        if self.tp_size > 1 or self.bias is not None or not self.input_is_parallel \
+                or not hasattr(qm, "apply_partial") or not qm.can_defer_reduce(self) or not input_.is_cuda \
+                or self.output_size % 8 != 0 or self.output_size > 8192:
+            return None
+        rows = input_.numel() // input_.shape[-1]
+        if ops.gptq_marlin_gemm_partial_splits(rows, self.output_size, self.input_size_per_partition) < 1:
+            return None
+        return qm.apply_partial(self, input_)
 
     def forward(self, input_):
         if self.input_is_parallel:

@@ -253,6 +253,24 @@ class GPTQMarlinLinearMethod(LinearMethodBase):
                                               cfg.group_size, cfg.weight_bits)
         replace_tensor("scales", marlin_scales)
 
+    # ---- deferred split-K: the GEMM leaves fp32 slabs, the following fused_add_rms_norm sums them
+    # (ops.gptq_marlin_gemm_partial; not part of the reference's LinearMethod) ----
+    def can_defer_reduce(self, layer: torch.nn.Module) -> bool:
+        cfg = self.quant_config
+        return (cfg.weight_bits == 4 and not cfg.desc_act and cfg.group_size in (-1, 128)
+                and layer.input_size_per_partition % 256 == 0 and layer.is_k_full
+                and not getattr(layer, "gate_up_interleaved", False))
+
+    def apply_partial(self, layer: torch.nn.Module, x: torch.Tensor) -> torch.Tensor:
+        """x @ W as fp32 split-K slabs [splits, T, N]; their sum in split order, rounded to the model
+        dtype, is bit-identical to apply()"""
+        reshaped_x = x.reshape(-1, x.shape[-1])
+        if layer.marlin_state == GPTQMarlinState.REPACK:
+            layer.marlin_state = GPTQMarlinState.READY
+            self._repack(layer)
+        return ops.gptq_marlin_gemm_partial(reshaped_x, layer.qweight, layer.scales, reshaped_x.shape[0],
+                                            layer.output_size_per_partition, layer.input_size_per_partition)
+
     # ---- gate_up with silu_and_mul folded into the GEMM epilogue (ops.gptq_marlin_gemm_silu_mul;
     # not part of the reference's LinearMethod) ----
     def can_fuse_silu_mul(self, layer: torch.nn.Module) -> bool:

@@ -8,7 +8,7 @@ carried through fused_add_rms_norm.  Checkpoint name mapping, LoRA, pipeline par
 rope scaling are outside the hot-path scope.
 """
 import os
-from typing import Any, Iterable, List, Optional, Tuple
+from typing import Any, Iterable, List, NamedTuple, Optional, Tuple
 
 import torch
 from torch import nn
@@ -33,6 +33,20 @@ def fused_glue_default() -> bool:
     return os.environ.get("NMV_FUSED_GLUE", "1") != "0"
 
 
+class SplitKPartial(NamedTuple):
+    """the un-reduced output of a row-parallel projection: fp32 split-K slabs [splits, T, hidden]
+    (RowParallelLinear.forward_partial); the next fused_add_rms_norm sums them"""
+    slab: torch.Tensor
+
+
+def _add_norm(norm: RMSNorm, hidden_states, residual: torch.Tensor):
+    """fused_add_rms_norm whose input may be a SplitKPartial; returns (normed, residual)"""
+    if isinstance(hidden_states, SplitKPartial):
+        return ops.fused_add_rms_norm_partial(hidden_states.slab, residual, norm.weight.data,
+                                              norm.variance_epsilon), residual
+    return norm(hidden_states, residual)
+
+
 class LlamaMLP(nn.Module):
 
     def __init__(self, hidden_size: int, intermediate_size: int, hidden_act: str,
@@ -53,14 +67,21 @@ class LlamaMLP(nn.Module):
         if self.fused_glue and not isinstance(x, Int8Activations) and x.is_cuda \
                 and hasattr(qm, "apply_silu_mul") and qm.can_fuse_silu_mul(self.gate_up_proj):
             # W4A16: silu_and_mul folded into the gate_up GEMM's epilogue (column-interleaved weights)
-            x, _ = self.down_proj(qm.apply_silu_mul(self.gate_up_proj, x))
-            return x
+            x = qm.apply_silu_mul(self.gate_up_proj, x)
+            return self._down(x)
         gate_up, _ = self.gate_up_proj(x)
         if self.fused_glue and gate_up.is_cuda and accepts_int8_activations(self.down_proj):
             # silu_and_mul + dynamic per-token int8 quantisation of down_proj's input: one launch
             x = Int8Activations(*ops.silu_and_mul_dynamic_int8_quant(gate_up), gate_up.dtype)
         else:
             x = self.act_fn(gate_up)
+        return self._down(x)
+
+    def _down(self, x):
+        if self.fused_glue and not isinstance(x, Int8Activations):
+            slab = self.down_proj.forward_partial(x)
+            if slab is not None:
+                return SplitKPartial(slab)   # summed by the next layer's input_layernorm
         x, _ = self.down_proj(x)
         return x
 
@@ -106,6 +127,17 @@ class LlamaAttention(nn.Module):
 
     def forward(self, positions: torch.Tensor, hidden_states: torch.Tensor,
                 kv_cache: Optional[torch.Tensor], attn_metadata: AttentionMetadata) -> torch.Tensor:
+        qkv = None
+        if self.fused_glue and isinstance(hidden_states, torch.Tensor) and hidden_states.dim() == 2:
+            # deferred split-K: the rope + cache launch sums the qkv projection's fp32 slabs
+            slab = self.qkv_proj.forward_partial(hidden_states)
+            if slab is not None:
+                qkv = self.attn.rope_and_cache_partial(positions, slab, self.rotary_emb, kv_cache,
+                                                       attn_metadata, hidden_states.dtype)
+        if qkv is not None:
+            q, k, v = qkv.split([self.q_size, self.kv_size, self.kv_size], dim=-1)
+            attn_output = self.attn(q, k, v, kv_cache, attn_metadata, cache_written=True)
+            return self._o(attn_output)
         qkv, _ = self.qkv_proj(hidden_states)
         q, k, v = qkv.split([self.q_size, self.kv_size, self.kv_size], dim=-1)
         if self.fused_glue and q.is_cuda and self.attn.rope_and_cache(positions, q, k, v, self.rotary_emb,
@@ -114,6 +146,13 @@ class LlamaAttention(nn.Module):
         else:
             q, k = self.rotary_emb(positions, q, k)
             attn_output = self.attn(q, k, v, kv_cache, attn_metadata)
+        return self._o(attn_output)
+
+    def _o(self, attn_output: torch.Tensor):
+        if self.fused_glue:
+            slab = self.o_proj.forward_partial(attn_output)
+            if slab is not None:
+                return SplitKPartial(slab)   # summed by post_attention_layernorm
         output, _ = self.o_proj(attn_output)
         return output
 
@@ -145,7 +184,7 @@ class LlamaDecoderLayer(nn.Module):
     def forward(self, positions: torch.Tensor, hidden_states: torch.Tensor,
                 kv_cache: Optional[torch.Tensor], attn_metadata: AttentionMetadata,
                 residual: Optional[torch.Tensor]) -> Tuple[torch.Tensor, torch.Tensor]:
-        fuse_q = self.fused_glue and hidden_states.is_cuda
+        fuse_q = self.fused_glue and isinstance(hidden_states, torch.Tensor) and hidden_states.is_cuda
         if fuse_q and accepts_int8_activations(self.self_attn.qkv_proj):
             # (fused_add_)rms_norm + dynamic per-token int8 quantisation of qkv_proj's input
             ln = self.input_layernorm
@@ -160,7 +199,7 @@ class LlamaDecoderLayer(nn.Module):
             residual = hidden_states
             hidden_states = self.input_layernorm(hidden_states)
         else:
-            hidden_states, residual = self.input_layernorm(hidden_states, residual)
+            hidden_states, residual = _add_norm(self.input_layernorm, hidden_states, residual)
         hidden_states = self.self_attn(positions=positions, hidden_states=hidden_states,
                                        kv_cache=kv_cache, attn_metadata=attn_metadata)
         if fuse_q and accepts_int8_activations(self.mlp.gate_up_proj):
@@ -169,7 +208,7 @@ class LlamaDecoderLayer(nn.Module):
                                                     ln.variance_epsilon)
             hidden_states = Int8Activations(q, sc, residual.dtype)
         else:
-            hidden_states, residual = self.post_attention_layernorm(hidden_states, residual)
+            hidden_states, residual = _add_norm(self.post_attention_layernorm, hidden_states, residual)
         hidden_states = self.mlp(hidden_states)
         return hidden_states, residual
 
@@ -195,7 +234,7 @@ class LlamaModel(nn.Module):
         for i, layer in enumerate(self.layers):
             hidden_states, residual = layer(positions, hidden_states, kv_caches[i], attn_metadata,
                                             residual)
-        hidden_states, _ = self.norm(hidden_states, residual)
+        hidden_states, _ = _add_norm(self.norm, hidden_states, residual)
         return hidden_states
 
 

@@ -275,3 +275,80 @@ def test_gemm_silu_mul_epilogue_matches_separate_ops(gpu_device, monkeypatch, m,
     assert got.shape == (m, inter)
     assert torch.equal(got.view(torch.int16), ref.view(torch.int16))
     assert int(ws.abs().sum()) == 0
+
+
+@pytest.mark.parametrize("m", [1, 5, 16, 64, 200])
+@pytest.mark.parametrize("k,n", [(4096, 4096), (14336, 4096), (512, 512), (1024, 8192)])
+@pytest.mark.parametrize("dtype", [torch.half, torch.bfloat16])
+def test_deferred_split_k_matches_gemm_then_norm(gpu_device, m, k, n, dtype):
+    """gptq_marlin_gemm_partial (fp32 slabs, no ticket / last-arriver pass) + fused_add_rms_norm_partial
+    (sums the slabs in split order) against gptq_marlin_gemm + fused_add_rms_norm: the normalised
+    output and the updated residual, bit for bit"""
+    from neural_magic_vllm_amd import _custom_ops as ops
+    d = gpu_device
+    pr = helpers.make_w4a16_problem(7, m, k, n, 4, 128, False, dtype)
+    a, mq, ms = pr["a"].to(d), pr["marlin_q_w"].to(d), pr["marlin_s"].to(d)
+    g = torch.Generator().manual_seed(8)
+    res = torch.randn((m, n), generator=g).to(dtype).to(d)
+    w = (1 + 0.1 * torch.randn((n, ), generator=g)).to(dtype).to(d)
+    e = torch.empty(0, dtype=torch.int32, device=d)
+    ws = torch.zeros(max(n // 64 * 16, 16), dtype=torch.int32, device=d)
+    out = ops.gptq_marlin_gemm(a, mq, ms, e, e, ws, 4, m, n, k, True)
+    ref_res = res.clone()
+    ops.fused_add_rms_norm(out, ref_res, w, 1e-5)
+    splits = ops.gptq_marlin_gemm_partial_splits(m, n, k)
+    slab = ops.gptq_marlin_gemm_partial(a, mq, ms, m, n, k)
+    assert slab.shape == (splits, m, n) and slab.dtype == torch.float32
+    got_res = res.clone()
+    got = ops.fused_add_rms_norm_partial(slab, got_res, w, 1e-5)
+    assert torch.equal(got_res.view(torch.int16), ref_res.view(torch.int16))
+    assert torch.equal(got.view(torch.int16), out.view(torch.int16))
+
+
+@pytest.mark.parametrize("m", [1, 19, 64])
+@pytest.mark.parametrize("kv_cache_dtype", ["auto", "fp8"])
+@pytest.mark.parametrize("dtype", [torch.half, torch.bfloat16])
+def test_deferred_split_k_qkv_rope_cache(gpu_device, m, kv_cache_dtype, dtype):
+    """qkv projection as fp32 slabs + rotary_embedding_and_cache_partial against gptq_marlin_gemm +
+    rotary_embedding_and_cache: rotated qkv row and both caches, bit for bit"""
+    from neural_magic_vllm_amd import _custom_ops as ops
+    d = gpu_device
+    heads, kv_heads, hs, k = 8, 2, 128, 1024
+    n = (heads + 2 * kv_heads) * hs
+    pr = helpers.make_w4a16_problem(9, m, k, n, 4, 128, False, dtype)
+    a, mq, ms = pr["a"].to(d), pr["marlin_q_w"].to(d), pr["marlin_s"].to(d)
+    g = torch.Generator().manual_seed(10)
+    block_size, num_blocks, max_pos = 16, 9, 2048
+    cos_sin = torch.randn((max_pos, hs), generator=g).to(dtype).to(d)
+    positions = torch.randint(0, max_pos, (m, ), generator=g).to(d)
+    slots = torch.randperm(num_blocks * block_size, generator=g)[:m].to(d)
+    if m > 3:
+        slots[3] = -1
+    cdt = torch.uint8 if kv_cache_dtype == "fp8" else dtype
+    x = 16 // torch.tensor([], dtype=cdt).element_size()
+    kv_scale = 0.5 if kv_cache_dtype == "fp8" else 1.0
+
+    def caches():
+        gen = torch.Generator().manual_seed(1)
+        kc = torch.randint(0, 100, (num_blocks, kv_heads, hs // x, block_size, x), generator=gen)
+        vc = torch.randint(0, 100, (num_blocks, kv_heads, hs, block_size), generator=gen)
+        return kc.to(cdt).to(d), vc.to(cdt).to(d)
+
+    e = torch.empty(0, dtype=torch.int32, device=d)
+    ws = torch.zeros(n // 64 * 16, dtype=torch.int32, device=d)
+    ref = ops.gptq_marlin_gemm(a, mq, ms, e, e, ws, 4, m, n, k, True)
+    q, kk, v = ref.split([heads * hs, kv_heads * hs, kv_heads * hs], dim=-1)
+    ref_kc, ref_vc = caches()
+    ops.rotary_embedding_and_cache(positions, q, kk, v, hs, cos_sin, True, ref_kc, ref_vc, slots,
+                                   kv_cache_dtype, kv_scale)
+    slab = ops.gptq_marlin_gemm_partial(a, mq, ms, m, n, k)
+    kc, vc = caches()
+    got = ops.rotary_embedding_and_cache_partial(positions, slab, heads, kv_heads, hs, cos_sin, kc, vc, slots,
+                                                 kv_cache_dtype, kv_scale, dtype)
+    assert torch.equal(got.view(torch.int16), ref.view(torch.int16))
+    assert torch.equal(kc.view(torch.uint8), ref_kc.view(torch.uint8))
+    assert torch.equal(vc.view(torch.uint8), ref_vc.view(torch.uint8))
+    # without caches: rope only
+    got2 = ops.rotary_embedding_and_cache_partial(positions, slab, heads, kv_heads, hs, cos_sin, None, None,
+                                                  None, kv_cache_dtype, kv_scale, dtype)
+    assert torch.equal(got2.view(torch.int16), ref.view(torch.int16))
