@@ -66,12 +66,21 @@ def gemm_roofline(runner, batch, dev, groups=32):
     xs = [torch.randn((batch, m.input_size_per_partition), device=dev, dtype=runner.dtype)
           for m in mods]
 
+    as_model = [False]  # second pass: the launches exactly as the model issues them
+
     def run(li, only=None):
         for j, (m, x) in enumerate(zip(mods_of(layers[li % len(layers)]), xs)):
-            if only is None or only == j:
+            if only is not None and only != j:
+                continue
+            k, n = m.input_size_per_partition, m.output_size_per_partition
+            if as_model[0] and getattr(m, "gate_up_interleaved", False):
+                ops.gptq_marlin_gemm_silu_mul(x, m.qweight, m.scales, m.workspace, batch, n, k)
+            elif as_model[0] and j != 2 and ops.gptq_marlin_gemm_partial_splits(batch, n, k) >= 1:
+                ops.gptq_marlin_gemm_partial(x, m.qweight, m.scales, batch, n, k)
+            else:
+                # gate_up weights may be column-interleaved for the silu epilogue: same bytes, same time
                 ops.gptq_marlin_gemm(x, m.qweight, m.scales, m.g_idx, m.g_idx_sort_indices,
-                                     m.workspace, 4, batch, m.output_size_per_partition,
-                                     m.input_size_per_partition, m.is_k_full)
+                                     m.workspace, 4, batch, n, k, m.is_k_full)
 
     def timed(only):
         run(0, only)
@@ -105,6 +114,16 @@ def gemm_roofline(runner, batch, dev, groups=32):
     for v in per.values():
         v["GB/s"] = round(v["algorithmic_bytes"] / v["us"] / 1e3, 1)
     achieved = alg / (us * 1e-6) / 1e9
+    in_model = None
+    if os.environ.get("NMV_FUSED_GLUE", "1") != "0":
+        as_model[0] = True
+        in_model = {"avg_us_per_launch_group": round(timed(None), 2),
+                    "per_gemm_us": {nm: round(timed(j), 2) for j, nm in enumerate(names)},
+                    "note": "the same four launches as the decode step issues them: qkv / o / down leave "
+                            "fp32 split-K slabs that the following rope+cache / norm launch sums (deferred "
+                            "reduction), gate_up applies silu_and_mul in its epilogue; `achieved` above is "
+                            "for the self-contained op (reduction inside the launch)"}
+        as_model[0] = False
     # HBM traffic from the PMC pass (FETCH_SIZE/WRITE_SIZE, separate rocprofv3 runs, gfx950
     # correction applied): measured offline with tools/gpu_ci.sh, summary committed under profiles/
     traffic = None
@@ -118,7 +137,8 @@ def gemm_roofline(runner, batch, dev, groups=32):
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
             "algorithmic_bytes_per_launch_group": alg, "avg_us_per_launch_group": round(us, 2),
-            "launches_per_group": 4, "timing": "HIP events around a hipGraph replay", "per_gemm": per}
+            "launches_per_group": 4, "timing": "HIP events around a hipGraph replay", "per_gemm": per,
+            "in_model": in_model}
 
 
 @torch.inference_mode()
