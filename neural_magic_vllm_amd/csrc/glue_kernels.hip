@@ -415,7 +415,7 @@ __global__ void rope_and_cache_kernel(const int64_t* __restrict__ positions, uin
 // written out ([T, (heads + 2 kv_heads) * head_size]) for the attention kernels.  neox style,
 // rot_dim == head_size.
 template <typename T, bool FP8>
-__global__ __launch_bounds__(512) void rope_and_cache_slab_kernel(
+__global__ __launch_bounds__(256) void rope_and_cache_slab_kernel(
     const int64_t* __restrict__ positions, const float* __restrict__ slab, int splits,
     int64_t slab_stride, uint16_t* __restrict__ qkv_out, const uint16_t* __restrict__ cos_sin_cache,
     int num_heads, int num_kv_heads, int head_size, void* key_cache, void* value_cache,
@@ -443,7 +443,11 @@ __global__ __launch_bounds__(512) void rope_and_cache_slab_kernel(
   const int quads = embed_dim / 4;                 // items per rotated head
   const int n_rot = (num_heads + num_kv_heads) * quads;
   const int n_v = num_kv_heads * head_size / 4;
-  for (int it = threadIdx.x; it < n_rot + n_v; it += blockDim.x) {
+  // the items of a token are independent: they are spread over gridDim.y workgroups, one item per
+  // lane, so that the slab reads of a row are all in flight at once (at B = 1 a single workgroup
+  // per token would be the whole grid)
+  const int it = blockIdx.y * blockDim.x + threadIdx.x;
+  if (it < n_rot + n_v) {
     if (it < n_rot) {
       const int head = it / quads;                 // q heads first, then k heads (qkv column order)
       const int d0 = (it % quads) * 4;
@@ -854,7 +858,8 @@ extern "C" int nmv_rotary_embedding_and_cache_partial(const int64_t* positions, 
             "rotary_embedding_and_cache_partial: caches / slot_mapping");
   if (num_tokens == 0) return NMV_OK;
   const int64_t stride = (int64_t)num_tokens * (num_heads + 2 * num_kv_heads) * head_size;
-  dim3 grid(num_tokens), block(512);
+  const int items = ((num_heads + num_kv_heads) * (head_size / 2) + num_kv_heads * head_size) / 4;
+  dim3 grid(num_tokens, (items + 255) / 256), block(256);
   hipStream_t s = (hipStream_t)stream;
 #define LAUNCH_RS(T, FP8)                                                                          \
   hipLaunchKernelGGL((rope_and_cache_slab_kernel<T, FP8>), grid, block, 0, s, positions, slab,     \
