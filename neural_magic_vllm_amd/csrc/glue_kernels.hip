@@ -343,6 +343,8 @@ __global__ void rope_and_cache_kernel(const int64_t* __restrict__ positions, uin
                                       const int64_t* __restrict__ slot_mapping, int block_size,
                                       float kv_scale) {
   const int token_idx = blockIdx.x;
+  // the pairs / elements of a token are independent: spread over gridDim.y workgroups
+  const int tid0 = blockIdx.y * blockDim.x + threadIdx.x, tstride = blockDim.x * gridDim.y;
   const int64_t pos = positions[token_idx];
   const int64_t slot_idx = slot_mapping[token_idx];
   const bool cached = slot_idx >= 0;  // padding tokens are rotated but not cached (cache_kernels.cu:166-169)
@@ -354,7 +356,7 @@ __global__ void rope_and_cache_kernel(const int64_t* __restrict__ positions, uin
   const uint16_t* sin_ptr = cache_ptr + embed_dim;
   // ---- K: rotate, write back, store in the cache ----
   const int nk = num_kv_heads * embed_dim;
-  for (int i = threadIdx.x; i < nk; i += blockDim.x) {
+  for (int i = tid0; i < nk; i += tstride) {
     const int head_idx = i / embed_dim;
     const int rot_offset = i % embed_dim;
     uint16_t* arr = key + token_idx * key_stride + (int64_t)head_idx * head_size;
@@ -377,7 +379,7 @@ __global__ void rope_and_cache_kernel(const int64_t* __restrict__ positions, uin
   if (cached) {
     // K dims beyond rot_dim pass through unrotated
     const int pass = head_size - rot_dim;
-    for (int i = threadIdx.x; i < num_kv_heads * pass; i += blockDim.x) {
+    for (int i = tid0; i < num_kv_heads * pass; i += tstride) {
       const int head_idx = i / pass, d = rot_dim + i % pass;
       cache_store_k<T, FP8>(key_cache, block_idx * num_kv_heads + head_idx, head_size, block_size,
                             block_offset, d, key[token_idx * key_stride + (int64_t)head_idx * head_size + d],
@@ -385,7 +387,7 @@ __global__ void rope_and_cache_kernel(const int64_t* __restrict__ positions, uin
     }
     // ---- V: element scatter, as write_token_to_cache (cache_write.h) ----
     const int n = num_kv_heads * head_size;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    for (int i = tid0; i < n; i += tstride) {
       const int head_idx = i / head_size;
       const int head_off = i % head_size;
       const int64_t tgt =
@@ -399,7 +401,7 @@ __global__ void rope_and_cache_kernel(const int64_t* __restrict__ positions, uin
   }
   // ---- Q ----
   const int nq = num_heads * embed_dim;
-  for (int i = threadIdx.x; i < nq; i += blockDim.x) {
+  for (int i = tid0; i < nq; i += tstride) {
     const int head_idx = i / embed_dim;
     const int rot_offset = i % embed_dim;
     rope_one<T, IS_NEOX>(query + token_idx * query_stride + (int64_t)head_idx * head_size, cos_ptr,
@@ -818,7 +820,8 @@ extern "C" int nmv_rotary_embedding_and_cache(const int64_t* positions, void* qu
             head_size, x);
   NMV_CHECK(block_size > 0 && num_kv_heads > 0 && num_heads > 0, "rotary_embedding_and_cache: bad shape");
   if (num_tokens == 0) return NMV_OK;
-  dim3 grid(num_tokens), block(std::min(std::max(num_heads * rot_dim / 2, 64), 512));
+  const int pairs = num_heads * rot_dim / 2;
+  dim3 grid(num_tokens, std::min(std::max(pairs / 512, 1), 8)), block(std::min(std::max(pairs, 64), 512));
   hipStream_t s = (hipStream_t)stream;
 #define LAUNCH_RC(T, NEOX, FP8)                                                                  \
   hipLaunchKernelGGL((rope_and_cache_kernel<T, NEOX, FP8>), grid, block, 0, s, positions,        \
