@@ -371,6 +371,23 @@ int nmv_cutlass_scaled_mm_supports_fp8(int64_t cuda_device_capability);
 int64_t nmv_get_device_attribute(int64_t attribute, int64_t device_id);
 int64_t nmv_get_max_shared_memory_per_block_device_attribute(int64_t device_id);
 
+/* ------------------------------------------------------------------------------------------
+ * One-shot P2P all-reduce over HIP IPC (the analogue of csrc/custom_all_reduce.cuh:130-250 /
+ * the `_C_custom_ar` ops of torch_bindings.cpp:262-294, which the reference compiles out on ROCm).
+ * nmv_ar_create allocates this rank's staging block on the current device and exports its IPC
+ * handle (nmv_ar_handle_bytes() bytes); nmv_ar_open maps the peers' blocks (handles: world
+ * handles in rank order); nmv_ar_all_reduce sums `numel` fp16 / bf16 elements (bytes % 16 == 0,
+ * <= max_bytes) across the ranks in fp32, rank order, one kernel launch, capturable into a
+ * hipGraph.  Flag waits are bounded: nmv_ar_error reports (after a device sync) whether one ran out.
+ * ------------------------------------------------------------------------------------------ */
+int nmv_ar_handle_bytes(void);
+int nmv_ar_create(void** state_out, int rank, int world, int64_t max_bytes, void* handle_out);
+int nmv_ar_open(void* state, const void* handles);
+int nmv_ar_all_reduce(void* state, const void* inp, void* out, int64_t numel, nmv_dtype_t dtype,
+                      void* stream);
+int nmv_ar_error(void* state);
+int nmv_ar_destroy(void* state);
+
 #ifdef __cplusplus
 }
 #endif

@@ -62,6 +62,12 @@ SIGNATURES = {
     "nmv_fused_add_rms_norm_partial": (_I, [_P, _P, _I, _P, _P, _F, _I, _I, _I, _P]),
     "nmv_rotary_embedding_and_cache_partial": (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _I, _I,
                                                     _F, _P]),
+    "nmv_ar_handle_bytes": (_I, []),
+    "nmv_ar_create": (_I, [_P, _I, _I, _L, _P]),
+    "nmv_ar_open": (_I, [_P, _P]),
+    "nmv_ar_all_reduce": (_I, [_P, _P, _P, _L, _I, _P]),
+    "nmv_ar_error": (_I, [_P]),
+    "nmv_ar_destroy": (_I, [_P]),
     "nmv_greedy_sample_scratch_bytes": (_L, [_I]),
     "nmv_greedy_sample_advance": (_I, [_P, _P, _L, _I, _I, _I, _P, _L, _P, _P, _P, _P, _P, _I, _I, _P]),
     "nmv_rms_norm_dynamic_int8_quant": (_I, [_P, _P, _P, _P, _P, _F, _I, _I, _I, _P]),

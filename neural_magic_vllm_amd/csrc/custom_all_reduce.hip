@@ -1,0 +1,211 @@
+// One-shot P2P all-reduce over HIP IPC for the tensor-parallel decode step: the gfx950 analogue of
+// the reference's csrc/custom_all_reduce.cuh:130-250 (cross_device_reduce_1stage), which the
+// reference compiles out on ROCm (torch_bindings.cpp:261).  Decode all-reduces a [B, hidden]
+// activation (8 KB .. 1 MB) twice per layer; at that size a ring collective is pure latency, while
+// xGMI lets every GPU read every peer's buffer directly (7 links x ~150 GB/s per GPU).
+//
+// Protocol (all ranks launch the same grid; block b of every rank owns slice b of the message):
+//   1. block b copies slice b of its input into its rank's IPC-mapped staging buffer (two buffers,
+//      alternating per call, so that no trailing barrier is needed: a rank can only reach call n+2
+//      after every peer has passed the flag wait of call n+1, i.e. has finished reading call n);
+//   2. system-scope release, then lanes 0..W-1 store the block's call number into slot
+//      [b][my_rank] of every rank's flag array and spin (bounded) until slots [b][0..W-1] of the
+//      own array carry it;
+//   3. system-scope acquire; every lane sums slice b of all W staging buffers in rank order (the
+//      same order on every rank => bit-identical results everywhere, deterministic) in fp32 and
+//      writes the output.
+// Call numbers live in device memory and are advanced by the kernel itself, so a captured launch
+// can be replayed.  The spin is bounded in time (2 s): a lost peer sets an error word instead of
+// hanging the GPU.
+// Staging and flags are allocated uncached / fine-grained when the runtime allows it.
+#include "common.h"
+
+#include <cstring>
+#include <vector>
+
+namespace nmv {
+
+constexpr int AR_MAX_RANKS = 8;
+constexpr int AR_MAX_BLOCKS = 64;
+constexpr int AR_THREADS = 512;
+constexpr uint64_t AR_SPIN_TICKS = 200ull * 1000 * 1000;  // s_memrealtime runs at 100 MHz: give up after 2 s
+
+struct ArComm {
+  uint32_t flags[AR_MAX_BLOCKS][AR_MAX_RANKS];  // [block][source rank] = call number
+  uint32_t seq[AR_MAX_BLOCKS];                  // this rank's call number per block
+  uint32_t error;                               // set when a spin ran out
+  uint32_t pad[63];
+};
+
+struct ArPeers {
+  ArComm* comm[AR_MAX_RANKS];
+  uint8_t* data[AR_MAX_RANKS];  // staging: 2 x max_bytes each
+};
+
+struct ArState {
+  int rank, world;
+  int64_t max_bytes;
+  void* base;        // one allocation: ArComm + 2 staging buffers
+  size_t alloc_bytes;
+  hipIpcMemHandle_t handle;
+  void* peer_base[AR_MAX_RANKS];
+  ArPeers peers;
+  bool opened;
+};
+
+template <typename T>
+__global__ __launch_bounds__(AR_THREADS) void one_shot_all_reduce_kernel(ArPeers peers, int rank, int world,
+                                                                         const uint16_t* __restrict__ inp,
+                                                                         uint16_t* __restrict__ out,
+                                                                         int64_t n_vec /* 16-byte vectors */,
+                                                                         int64_t buf_bytes) {
+  const int b = blockIdx.x;
+  ArComm* mine = peers.comm[rank];
+  const uint32_t seq = mine->seq[b] + 1;  // only this block touches seq[b]
+  const int64_t parity_off = (seq & 1) ? buf_bytes : 0;
+  const int64_t per = (n_vec + gridDim.x - 1) / gridDim.x;
+  const int64_t v0 = (int64_t)b * per, v1 = min(v0 + per, n_vec);
+  // 1. my slice -> my staging buffer
+  uint4* stage = reinterpret_cast<uint4*>(peers.data[rank] + parity_off);
+  const uint4* src = reinterpret_cast<const uint4*>(inp);
+  for (int64_t v = v0 + threadIdx.x; v < v1; v += AR_THREADS) stage[v] = src[v];
+  __threadfence_system();
+  __syncthreads();
+  // 2. signal every rank (myself included), wait for every rank
+  if (threadIdx.x < world) {
+    const int q = threadIdx.x;
+    __hip_atomic_store(&peers.comm[q]->flags[b][rank], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+    while ((int32_t)(__hip_atomic_load(&mine->flags[b][q], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - seq) < 0) {
+      if (__builtin_amdgcn_s_memrealtime() - t0 > AR_SPIN_TICKS) {
+        __hip_atomic_store(&mine->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+  }
+  __syncthreads();
+  // system-scope acquire on every lane: drop whatever the caches hold of the peers' buffers
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+  // 3. sum slice b of every rank's buffer, rank order, fp32
+  uint4* dst = reinterpret_cast<uint4*>(out);
+  for (int64_t v = v0 + threadIdx.x; v < v1; v += AR_THREADS) {
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int q = 0; q < world; ++q) {
+      const uint4 x = reinterpret_cast<const uint4*>(peers.data[q] + parity_off)[v];
+      const uint32_t xs[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc[2 * j] += lo_f<T>(xs[j]);
+        acc[2 * j + 1] += hi_f<T>(xs[j]);
+      }
+    }
+    dst[v] = make_uint4(T::pack2(acc[0], acc[1]), T::pack2(acc[2], acc[3]), T::pack2(acc[4], acc[5]),
+                        T::pack2(acc[6], acc[7]));
+  }
+  if (threadIdx.x == 0) mine->seq[b] = seq;
+}
+
+}  // namespace nmv
+
+using namespace nmv;
+
+#define AR_HIP(call)                                                                     \
+  do {                                                                                   \
+    hipError_t e_ = (call);                                                              \
+    if (e_ != hipSuccess) {                                                              \
+      ::nmv::set_error("custom_all_reduce: %s failed: %s", #call, hipGetErrorString(e_));   \
+      return NMV_ERR_HIP;                                                                \
+    }                                                                                    \
+  } while (0)
+
+extern "C" int nmv_ar_handle_bytes(void) { return (int)sizeof(hipIpcMemHandle_t); }
+
+/* allocate this rank's comm block + staging (2 x max_bytes) on the current device and export it */
+extern "C" int nmv_ar_create(void** state_out, int rank, int world, int64_t max_bytes, void* handle_out) {
+  NMV_CHECK(world >= 2 && world <= AR_MAX_RANKS && rank >= 0 && rank < world, "custom_all_reduce: bad rank / world");
+  NMV_CHECK(max_bytes > 0 && max_bytes % 16 == 0, "custom_all_reduce: max_bytes must be a multiple of 16");
+  ArState* st = new ArState();
+  std::memset(st, 0, sizeof(ArState));
+  st->rank = rank; st->world = world; st->max_bytes = max_bytes;
+  st->alloc_bytes = sizeof(ArComm) + 2 * (size_t)max_bytes;
+  hipError_t e = hipExtMallocWithFlags(&st->base, st->alloc_bytes, hipDeviceMallocUncached);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    e = hipMalloc(&st->base, st->alloc_bytes);
+  }
+  if (e != hipSuccess) {
+    delete st;
+    ::nmv::set_error("custom_all_reduce: allocation failed: %s", hipGetErrorString(e));
+    return NMV_ERR_HIP;
+  }
+  AR_HIP(hipMemset(st->base, 0, sizeof(ArComm)));
+  AR_HIP(hipDeviceSynchronize());
+  AR_HIP(hipIpcGetMemHandle(&st->handle, st->base));
+  std::memcpy(handle_out, &st->handle, sizeof(hipIpcMemHandle_t));
+  *state_out = st;
+  return NMV_OK;
+}
+
+/* handles: world x nmv_ar_handle_bytes() bytes, rank order (the own slot is ignored) */
+extern "C" int nmv_ar_open(void* state, const void* handles) {
+  ArState* st = (ArState*)state;
+  NMV_CHECK(st != nullptr && !st->opened, "custom_all_reduce: bad state");
+  for (int q = 0; q < st->world; ++q) {
+    if (q == st->rank) {
+      st->peer_base[q] = st->base;
+    } else {
+      hipIpcMemHandle_t h;
+      std::memcpy(&h, (const uint8_t*)handles + (size_t)q * sizeof(h), sizeof(h));
+      AR_HIP(hipIpcOpenMemHandle(&st->peer_base[q], h, hipIpcMemLazyEnablePeerAccess));
+    }
+    st->peers.comm[q] = (ArComm*)st->peer_base[q];
+    st->peers.data[q] = (uint8_t*)st->peer_base[q] + sizeof(ArComm);
+  }
+  st->opened = true;
+  return NMV_OK;
+}
+
+extern "C" int nmv_ar_all_reduce(void* state, const void* inp, void* out, int64_t numel, nmv_dtype_t dtype,
+                                 void* stream) {
+  ArState* st = (ArState*)state;
+  NMV_CHECK(st != nullptr && st->opened, "custom_all_reduce: not initialised");
+  NMV_CHECK(dtype == NMV_F16 || dtype == NMV_BF16, "custom_all_reduce: fp16 / bf16 only");
+  const int64_t bytes = numel * 2;
+  NMV_CHECK(bytes > 0 && bytes % 16 == 0 && bytes <= st->max_bytes,
+            "custom_all_reduce: message must be a multiple of 16 bytes and <= %lld", (long long)st->max_bytes);
+  NMV_CHECK((((uintptr_t)inp | (uintptr_t)out) & 15) == 0, "custom_all_reduce: 16-byte aligned tensors");
+  const int64_t n_vec = bytes / 16;
+  const int blocks = (int)std::min<int64_t>(AR_MAX_BLOCKS, (n_vec + AR_THREADS - 1) / AR_THREADS);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == NMV_F16)
+    hipLaunchKernelGGL((one_shot_all_reduce_kernel<F16>), dim3(blocks), dim3(AR_THREADS), 0, s, st->peers,
+                       st->rank, st->world, (const uint16_t*)inp, (uint16_t*)out, n_vec, st->max_bytes);
+  else
+    hipLaunchKernelGGL((one_shot_all_reduce_kernel<BF16>), dim3(blocks), dim3(AR_THREADS), 0, s, st->peers,
+                       st->rank, st->world, (const uint16_t*)inp, (uint16_t*)out, n_vec, st->max_bytes);
+  NMV_LAUNCH_CHECK();
+  return NMV_OK;
+}
+
+/* 1 when a bounded spin ran out on this rank since creation (synchronises the device) */
+extern "C" int nmv_ar_error(void* state) {
+  ArState* st = (ArState*)state;
+  if (st == nullptr) return 1;
+  uint32_t err = 1;
+  if (hipDeviceSynchronize() != hipSuccess) return 1;
+  if (hipMemcpy(&err, &((ArComm*)st->base)->error, 4, hipMemcpyDeviceToHost) != hipSuccess) return 1;
+  return (int)err;
+}
+
+extern "C" int nmv_ar_destroy(void* state) {
+  ArState* st = (ArState*)state;
+  if (st == nullptr) return NMV_OK;
+  (void)hipDeviceSynchronize();
+  if (st->opened)
+    for (int q = 0; q < st->world; ++q)
+      if (q != st->rank && st->peer_base[q]) (void)hipIpcCloseMemHandle(st->peer_base[q]);
+  if (st->base) (void)hipFree(st->base);
+  delete st;
+  return NMV_OK;
+}

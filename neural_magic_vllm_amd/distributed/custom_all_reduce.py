@@ -1,0 +1,133 @@
+"""One-shot P2P all-reduce over HIP IPC (csrc/custom_all_reduce.hip) -- the ROCm analogue of the
+reference's vllm/distributed/device_communicators/custom_all_reduce.py (CUDA only there; its
+kernels are compiled out on ROCm, csrc/torch_bindings.cpp:261).
+
+Every rank allocates one staging block on its GPU, the IPC handles are exchanged over the gloo
+twin of the tensor-parallel group, and `all_reduce` launches one kernel per call (capturable into
+a hipGraph: the call counters live in device memory).  Before the communicator is used it runs a
+self-test against a CPU reference on the actual devices; any mismatch, a bounded-spin timeout or a
+failed IPC mapping on ANY rank disables it on ALL ranks and RCCL is used instead -- the custom
+path can make the decode step faster, never wrong."""
+import ctypes
+import os
+import socket
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+
+from .. import _lib
+from .._torch_bindings import check, dtype_code, ptr, stream_of
+
+MAX_BYTES = 8 << 20  # the reference's max_size (custom_all_reduce.py:43)
+
+
+class CustomAllReduce:
+
+    def __init__(self, cpu_group, rank_in_group: int, world_size: int, device: torch.device,
+                 max_bytes: int = MAX_BYTES) -> None:
+        self.cpu_group, self.rank, self.world, self.device = cpu_group, rank_in_group, world_size, device
+        self.max_bytes = max_bytes
+        self.state = None
+        self.disabled_reason: Optional[str] = None
+        self.enabled = False
+        lib = _lib.load()
+        ok, handle = True, b""
+        try:
+            hb = lib.nmv_ar_handle_bytes()
+            buf = ctypes.create_string_buffer(hb)
+            st = ctypes.c_void_p()
+            with torch.cuda.device(device):
+                check(lib.nmv_ar_create(ctypes.byref(st), rank_in_group, world_size, max_bytes, buf))
+            self.state, handle = st, buf.raw
+        except Exception as e:  # allocation / IPC export refused
+            ok, self.disabled_reason = False, f"create: {e}"
+        gathered: List = [None] * world_size
+        dist.all_gather_object(gathered, (ok, handle, socket.gethostname()), group=cpu_group)
+        if not all(g[0] for g in gathered):
+            self.disabled_reason = self.disabled_reason or "a peer could not create its buffer"
+            return self._close()
+        if len({g[2] for g in gathered}) != 1:
+            self.disabled_reason = "ranks on different hosts"
+            return self._close()
+        try:
+            with torch.cuda.device(device):
+                check(lib.nmv_ar_open(self.state, b"".join(g[1] for g in gathered)))
+        except Exception as e:
+            ok, self.disabled_reason = False, f"open: {e}"
+        if not self._all_agree(ok):
+            self.disabled_reason = self.disabled_reason or "a peer could not map the buffers"
+            return self._close()
+        self.enabled = True  # for the self-test calls
+        good = self._self_test()
+        if not self._all_agree(good):
+            self.disabled_reason = self.disabled_reason or "self-test failed on a peer"
+            self.enabled = False
+            return self._close()
+
+    # ------------------------------------------------------------------
+    def _all_agree(self, flag: bool) -> bool:
+        flags: List = [None] * self.world
+        dist.all_gather_object(flags, bool(flag), group=self.cpu_group)
+        return all(flags)
+
+    def _close(self) -> None:
+        if self.state is not None:
+            with torch.cuda.device(self.device):
+                _lib.load().nmv_ar_destroy(self.state)
+            self.state = None
+        self.enabled = False
+
+    def close(self) -> None:
+        self._close()
+
+    def _self_test(self) -> bool:
+        """bit-exact against the fp32 rank-order sum computed on the CPU, several sizes and rounds"""
+        try:
+            for rnd, numel in enumerate((8, 4096, 64 * 4096, 64 * 4096 + 8, self.max_bytes // 2)):
+                for dtype in (torch.bfloat16, torch.float16):
+                    g = torch.Generator().manual_seed(1000 * rnd + self.rank)
+                    x = torch.randn(numel, generator=g).to(dtype)
+                    parts: List = [None] * self.world
+                    dist.all_gather_object(parts, x, group=self.cpu_group)
+                    ref = torch.zeros(numel, dtype=torch.float32)
+                    for p in parts:
+                        ref += p.float()
+                    got = self.all_reduce(x.to(self.device))
+                    torch.cuda.synchronize(self.device)
+                    if not torch.equal(got.cpu().view(torch.int16), ref.to(dtype).view(torch.int16)):
+                        self.disabled_reason = f"self-test mismatch (numel={numel}, {dtype})"
+                        return False
+            if _lib.load().nmv_ar_error(self.state):
+                self.disabled_reason = "self-test: a flag wait timed out"
+                return False
+            return True
+        except Exception as e:
+            self.disabled_reason = f"self-test: {e}"
+            return False
+
+    # ------------------------------------------------------------------
+    def should_use(self, t: torch.Tensor) -> bool:
+        nbytes = t.numel() * t.element_size()
+        return (self.enabled and t.is_cuda and t.dtype in (torch.float16, torch.bfloat16) and t.is_contiguous()
+                and 0 < nbytes <= self.max_bytes and nbytes % 16 == 0 and t.data_ptr() % 16 == 0)
+
+    def all_reduce(self, t: torch.Tensor) -> torch.Tensor:
+        """out-of-place sum over the group; the same bits on every rank"""
+        out = torch.empty_like(t)
+        check(_lib.load().nmv_ar_all_reduce(self.state, ptr(t), ptr(out), t.numel(), dtype_code(t.dtype),
+                                            stream_of(t)))
+        return out
+
+
+def maybe_create(cpu_group, rank_in_group: int, world_size: int, device: torch.device,
+                 backend: str) -> Optional[CustomAllReduce]:
+    """NMV_CUSTOM_ALLREDUCE: "1" (default) = on for RCCL groups of 2..8 GPUs, "0" = off,
+    "force" = also over a gloo group (the single-GPU rehearsal of the tests)"""
+    mode = os.environ.get("NMV_CUSTOM_ALLREDUCE", "1")
+    if mode == "0" or world_size < 2 or world_size > 8 or device.type != "cuda":
+        return None
+    if backend != "nccl" and mode != "force":
+        return None
+    car = CustomAllReduce(cpu_group, rank_in_group, world_size, device)
+    return car if car.enabled else None

@@ -40,6 +40,13 @@ class GroupCoordinator:
             self.device = torch.device(f"cuda:{local_rank}")
         else:
             self.device = torch.device("cpu")
+        # one-shot P2P all-reduce over HIP IPC for the decode-sized messages (custom_all_reduce.py);
+        # None when disabled, unavailable or when its self-test did not pass on every rank
+        self.custom_ar = None
+        if self.world_size > 1 and torch.cuda.is_available():
+            from .custom_all_reduce import maybe_create
+            ar_dev = self.device if self.device.type == "cuda" else torch.device("cuda", torch.cuda.current_device())
+            self.custom_ar = maybe_create(self.cpu_group, self.rank_in_group, self.world_size, ar_dev, backend)
 
     @property
     def first_rank(self):
@@ -53,6 +60,8 @@ class GroupCoordinator:
         """in-place sum all-reduce (parallel_state.py:273-293)"""
         if self.world_size == 1:
             return input_
+        if self.custom_ar is not None and self.custom_ar.should_use(input_):
+            return self.custom_ar.all_reduce(input_)
         dist.all_reduce(input_, group=self.device_group)
         return input_
 
@@ -140,6 +149,9 @@ class GroupCoordinator:
         dist.barrier(group=self.cpu_group)
 
     def destroy(self):
+        if getattr(self, "custom_ar", None) is not None:
+            self.custom_ar.close()
+            self.custom_ar = None
         if self.device_group is not None:
             dist.destroy_process_group(self.device_group)
             self.device_group = None

@@ -1,0 +1,121 @@
+"""GPU: the one-shot P2P all-reduce over HIP IPC (csrc/custom_all_reduce.hip), rehearsed with 2 and 4
+processes that share the one GPU of the test box (IPC mapping, flag protocol, double buffering,
+graph replay, the self-test / fallback logic).  The cross-device part -- xGMI peer reads -- cannot be
+exercised here; on a multi-GPU node the communicator's own start-up self-test decides whether it is
+used (custom_all_reduce.py)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _expected(world, numel, dtype, it):
+    ref = torch.zeros(numel, dtype=torch.float32)
+    for r in range(world):
+        g = torch.Generator().manual_seed(977 * it + r)
+        ref += torch.randn(numel, generator=g).to(dtype).float()
+    return ref.to(dtype)
+
+
+def _worker(rank, world, port, q, run_model):
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                          HSA_ENABLE_IPC_MODE_LEGACY="0", NMV_CUSTOM_ALLREDUCE="force")
+        import torch.distributed as dist
+        from neural_magic_vllm_amd import _lib
+        from neural_magic_vllm_amd import distributed as nd
+        torch.cuda.set_device(0)
+        dev = torch.device("cuda:0")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        nd.initialize_model_parallel(world, backend="gloo", local_rank=0)
+        tp = nd.get_tp_group()
+        car = tp.custom_ar
+        assert car is not None and car.enabled, getattr(car, "disabled_reason", "custom all-reduce not created")
+        out = {}
+        if run_model:
+            from neural_magic_vllm_amd.worker import decode_runner as dr
+            import test_gpu_tp
+            runner = dr.DecodeRunner(dr.TINY, dev, torch.bfloat16, test_gpu_tp.QUANT, dr.CacheConfig(16, "auto"))
+            out["tokens"] = test_gpu_tp._run(runner).tolist()
+        else:
+            it = 0
+            for dtype in (torch.bfloat16, torch.float16):
+                for numel in (8, 4096, 64 * 4096, 3 * 4096 + 8, 2 << 20):
+                    for _ in range(3):   # consecutive calls alternate the staging buffers
+                        g = torch.Generator().manual_seed(977 * it + rank)
+                        x = torch.randn(numel, generator=g).to(dtype).to(dev)
+                        assert car.should_use(x)
+                        y = tp.all_reduce(x)
+                        assert torch.equal(y.cpu().view(torch.int16), _expected(world, numel, dtype, it).view(torch.int16)), \
+                            (numel, dtype, it)
+                        it += 1
+            # messages the custom path does not take go to the group's backend
+            odd = torch.ones(5, dtype=torch.bfloat16, device=dev)
+            assert not car.should_use(odd)
+            assert float(tp.all_reduce(odd.clone())[0]) == world
+            # captured: three dependent all-reduces per replay, call counters advance on the device
+            x = torch.full((64, 4096), float(rank + 1), dtype=torch.bfloat16, device=dev)
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                tp.all_reduce(x)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            dist.barrier()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                y = tp.all_reduce(tp.all_reduce(tp.all_reduce(x)))
+            total = sum(range(1, world + 1))
+            for _ in range(5):
+                graph.replay()
+                torch.cuda.synchronize()
+                assert torch.equal(y.float().cpu(), torch.full((64, 4096), float(total * world * world)))
+            assert _lib.load().nmv_ar_error(car.state) == 0
+        dist.barrier()
+        nd.destroy_model_parallel()
+        dist.destroy_process_group()
+        q.put(("ok", out))
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put(("err", f"rank {rank}: {e!r}\n{traceback.format_exc()}"))
+
+
+def _spawn(world, run_model):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, run_model)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    errs = [r[1] for r in res if r[0] != "ok"]
+    assert not errs, "\n".join(errs)
+    return [r[1] for r in res]
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_custom_all_reduce_bit_exact_and_graph_replay(gpu_device, world):
+    _spawn(world, run_model=False)
+
+
+def test_tp_model_over_custom_all_reduce(gpu_device):
+    """the tensor-parallel tiny Llama with the row-parallel all-reduces on the custom path reproduces
+    the single-process tokens"""
+    from neural_magic_vllm_amd.worker import decode_runner as dr
+    import test_gpu_tp
+    ref_runner = dr.DecodeRunner(dr.TINY, gpu_device, torch.bfloat16, test_gpu_tp.QUANT, dr.CacheConfig(16, "auto"))
+    ref = test_gpu_tp._run(ref_runner).tolist()
+    outs = _spawn(2, run_model=True)
+    assert all(o["tokens"] == ref for o in outs)
