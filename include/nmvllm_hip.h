@@ -200,6 +200,20 @@ int nmv_greedy_sample_advance(int64_t* next_tokens, const void* logits, int64_t 
                               int64_t scratch_bytes, int64_t* input_ids, int64_t* positions,
                               int* seq_lens, int64_t* slot_mapping, const int* block_tables,
                               int max_blocks_per_seq, int block_size, void* stream);
+/* Vocab-parallel greedy sampling without gathering the logits: every rank reduces its shard
+ * [num_seqs, local_vocab] to a record -- float value[p] then int32 global_index[p], p =
+ * nmv_greedy_record_elems(num_seqs) -- the records are all-gathered (nmv_ar_all_gather or any
+ * all-gather) and nmv_greedy_sample_finish picks the winner per row (ties -> lowest global index =
+ * torch.argmax of the gathered logits) and optionally advances the decode batch like
+ * nmv_greedy_sample_advance.  scratch as for nmv_greedy_sample_advance. */
+int nmv_greedy_record_elems(int num_seqs);
+int nmv_greedy_sample_shard(void* record, const void* logits, int64_t row_stride, int num_seqs,
+                            int local_vocab, int index_offset, nmv_dtype_t dtype, void* scratch,
+                            int64_t scratch_bytes, void* stream);
+int nmv_greedy_sample_finish(int64_t* next_tokens, const void* gathered, int world, int num_seqs,
+                             int64_t* input_ids, int64_t* positions, int* seq_lens,
+                             int64_t* slot_mapping, const int* block_tables, int max_blocks_per_seq,
+                             int block_size, void* stream);
 /* rotary_embedding (pos_encoding_kernels.cu:121-160) followed by reshape_and_cache
  * (cache_kernels.cu:253-278): query / key rotated in place, then key / value of every token with
  * slot_mapping[t] >= 0 written to the paged cache. */
@@ -385,6 +399,9 @@ int nmv_ar_create(void** state_out, int rank, int world, int64_t max_bytes, void
 int nmv_ar_open(void* state, const void* handles);
 int nmv_ar_all_reduce(void* state, const void* inp, void* out, int64_t numel, nmv_dtype_t dtype,
                       void* stream);
+/* out[q * bytes_per_rank ...] = rank q's inp: all-gather of small per-rank records with the same
+ * protocol (bytes_per_rank % 16 == 0, <= max_bytes) */
+int nmv_ar_all_gather(void* state, const void* inp, void* out, int64_t bytes_per_rank, void* stream);
 int nmv_ar_error(void* state);
 int nmv_ar_destroy(void* state);
 

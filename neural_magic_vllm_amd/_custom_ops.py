@@ -368,3 +368,17 @@ def rotary_embedding_and_cache_partial(positions: torch.Tensor, slab: torch.Tens
     return tb.rotary_embedding_and_cache_partial(positions, slab, num_heads, num_kv_heads, head_size,
                                                  cos_sin_cache, key_cache, value_cache, slot_mapping,
                                                  kv_cache_dtype, kv_scale, dtype)
+
+
+def greedy_sample_shard(logits: torch.Tensor, index_offset: int) -> torch.Tensor:
+    from neural_magic_vllm_amd import _torch_bindings as tb
+    return tb.greedy_sample_shard(logits, index_offset)
+
+
+def greedy_sample_finish(gathered: torch.Tensor, world: int, num_seqs: int,
+                         input_ids: Optional[torch.Tensor] = None, positions: Optional[torch.Tensor] = None,
+                         seq_lens: Optional[torch.Tensor] = None, slot_mapping: Optional[torch.Tensor] = None,
+                         block_tables: Optional[torch.Tensor] = None, block_size: int = 0) -> torch.Tensor:
+    from neural_magic_vllm_amd import _torch_bindings as tb
+    return tb.greedy_sample_finish(gathered, world, num_seqs, input_ids, positions, seq_lens, slot_mapping,
+                                   block_tables, block_size)

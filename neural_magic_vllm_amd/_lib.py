@@ -66,7 +66,11 @@ SIGNATURES = {
     "nmv_ar_create": (_I, [_P, _I, _I, _L, _P]),
     "nmv_ar_open": (_I, [_P, _P]),
     "nmv_ar_all_reduce": (_I, [_P, _P, _P, _L, _I, _P]),
+    "nmv_ar_all_gather": (_I, [_P, _P, _P, _L, _P]),
     "nmv_ar_error": (_I, [_P]),
+    "nmv_greedy_record_elems": (_I, [_I]),
+    "nmv_greedy_sample_shard": (_I, [_P, _P, _L, _I, _I, _I, _I, _P, _L, _P]),
+    "nmv_greedy_sample_finish": (_I, [_P, _P, _I, _I, _P, _P, _P, _P, _P, _I, _I, _P]),
     "nmv_ar_destroy": (_I, [_P]),
     "nmv_greedy_sample_scratch_bytes": (_L, [_I]),
     "nmv_greedy_sample_advance": (_I, [_P, _P, _L, _I, _I, _I, _P, _L, _P, _P, _P, _P, _P, _I, _I, _P]),

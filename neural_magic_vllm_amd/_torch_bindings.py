@@ -679,6 +679,38 @@ def rotary_embedding_and_cache_partial(positions, slab, num_heads, num_kv_heads,
     return out
 
 
+def greedy_sample_shard(logits, index_offset: int) -> torch.Tensor:
+    """argmax of one vocab shard [B, V_local] -> record (float32 view): value[p], int32 global index[p]"""
+    _req(logits.dim() == 2 and logits.stride(1) == 1, "greedy_sample: logits must be [B, V] with contiguous rows")
+    _req(logits.dtype in (torch.float16, torch.bfloat16), "greedy_sample: fp16 / bf16 logits")
+    b, v = logits.shape
+    lib = _lib.load()
+    p_ = lib.nmv_greedy_record_elems(b)
+    record = torch.zeros(2 * p_, dtype=torch.float32, device=logits.device)
+    sb = lib.nmv_greedy_sample_scratch_bytes(b)
+    scratch = torch.empty(max(sb, 1), dtype=torch.uint8, device=logits.device)
+    with device_guard(logits):
+        check(lib.nmv_greedy_sample_shard(ptr(record), ptr(logits), logits.stride(0), b, v, index_offset,
+                                          dtype_code(logits.dtype), ptr(scratch), sb, stream_of(logits)))
+    return record
+
+
+def greedy_sample_finish(gathered, world: int, num_seqs: int, input_ids=None, positions=None, seq_lens=None,
+                         slot_mapping=None, block_tables=None, block_size=0) -> torch.Tensor:
+    """winner over the `world` shard records (ties -> lowest global index) -> int64 [B]; with the state
+    tensors also the on-device advance of the decode batch"""
+    lib = _lib.load()
+    _req(gathered.dtype == torch.float32 and gathered.is_contiguous()
+         and gathered.numel() == world * 2 * lib.nmv_greedy_record_elems(num_seqs), "greedy_sample_finish: record size")
+    out = torch.empty((num_seqs, ), dtype=torch.int64, device=gathered.device)
+    with device_guard(gathered):
+        check(lib.nmv_greedy_sample_finish(
+            ptr(out), ptr(gathered), world, num_seqs, ptr(input_ids), ptr(positions), ptr(seq_lens),
+            ptr(slot_mapping), ptr(block_tables), block_tables.shape[1] if block_tables is not None else 0,
+            block_size, stream_of(gathered)))
+    return out
+
+
 def rms_norm_dynamic_int8_quant(input, residual, weight, epsilon):
     """(fused_add_)rms_norm -> dynamic per-token scaled_int8_quant; returns (int8 [T, H], scales [T, 1]);
     residual (or None) is updated in place as fused_add_rms_norm does, input is left untouched"""

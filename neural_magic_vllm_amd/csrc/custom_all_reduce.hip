@@ -53,7 +53,9 @@ struct ArState {
   bool opened;
 };
 
-template <typename T>
+// GATHER: same protocol, but slice b of every rank's buffer is copied to out[q * n_vec + slice]
+// instead of summed (all-gather of small per-rank records, e.g. the per-shard argmax of the sampler)
+template <typename T, bool GATHER = false>
 __global__ __launch_bounds__(AR_THREADS) void one_shot_all_reduce_kernel(ArPeers peers, int rank, int world,
                                                                          const uint16_t* __restrict__ inp,
                                                                          uint16_t* __restrict__ out,
@@ -89,6 +91,13 @@ __global__ __launch_bounds__(AR_THREADS) void one_shot_all_reduce_kernel(ArPeers
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
   // 3. sum slice b of every rank's buffer, rank order, fp32
   uint4* dst = reinterpret_cast<uint4*>(out);
+  if constexpr (GATHER) {
+    for (int q = 0; q < world; ++q)
+      for (int64_t v = v0 + threadIdx.x; v < v1; v += AR_THREADS)
+        dst[q * n_vec + v] = reinterpret_cast<const uint4*>(peers.data[q] + parity_off)[v];
+    if (threadIdx.x == 0) mine->seq[b] = seq;
+    return;
+  }
   for (int64_t v = v0 + threadIdx.x; v < v1; v += AR_THREADS) {
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (int q = 0; q < world; ++q) {
@@ -184,6 +193,23 @@ extern "C" int nmv_ar_all_reduce(void* state, const void* inp, void* out, int64_
   else
     hipLaunchKernelGGL((one_shot_all_reduce_kernel<BF16>), dim3(blocks), dim3(AR_THREADS), 0, s, st->peers,
                        st->rank, st->world, (const uint16_t*)inp, (uint16_t*)out, n_vec, st->max_bytes);
+  NMV_LAUNCH_CHECK();
+  return NMV_OK;
+}
+
+/* out[q * bytes_per_rank ...] = rank q's inp (bytes_per_rank % 16 == 0, <= max_bytes) */
+extern "C" int nmv_ar_all_gather(void* state, const void* inp, void* out, int64_t bytes_per_rank,
+                                 void* stream) {
+  ArState* st = (ArState*)state;
+  NMV_CHECK(st != nullptr && st->opened, "custom_all_reduce: not initialised");
+  NMV_CHECK(bytes_per_rank > 0 && bytes_per_rank % 16 == 0 && bytes_per_rank <= st->max_bytes,
+            "custom all_gather: record must be a multiple of 16 bytes and <= %lld", (long long)st->max_bytes);
+  NMV_CHECK((((uintptr_t)inp | (uintptr_t)out) & 15) == 0, "custom all_gather: 16-byte aligned tensors");
+  const int64_t n_vec = bytes_per_rank / 16;
+  const int blocks = (int)std::min<int64_t>(AR_MAX_BLOCKS, (n_vec + AR_THREADS - 1) / AR_THREADS);
+  hipLaunchKernelGGL((one_shot_all_reduce_kernel<BF16, true>), dim3(blocks), dim3(AR_THREADS), 0,
+                     (hipStream_t)stream, st->peers, st->rank, st->world, (const uint16_t*)inp,
+                     (uint16_t*)out, n_vec, st->max_bytes);
   NMV_LAUNCH_CHECK();
   return NMV_OK;
 }

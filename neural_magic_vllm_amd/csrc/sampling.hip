@@ -74,18 +74,24 @@ __global__ __launch_bounds__(AM_THREADS) void argmax_partial_kernel(const uint16
   }
 }
 
-// one wave per row: merge the partial results, publish the token and (optionally) advance the
-// sequence: input_ids = token, positions += 1, seq_lens += 1, slot = block_table[pos / bs] * bs + pos % bs
+// one wave per row: merge up to 64 candidates (value pval[row * row_stride + c * cand_stride], index
+// likewise from pidx), then either publish the winner as a (value, index + idx_offset) record
+// (pair_val / pair_idx: the per-shard result of a vocab-parallel lm_head) or publish the token and
+// (optionally) advance the sequence: input_ids = token, positions += 1, seq_lens += 1,
+// slot = block_table[pos / bs] * bs + pos % bs
 __global__ __launch_bounds__(64) void argmax_final_kernel(const float* __restrict__ pval,
-                                                          const int* __restrict__ pidx,
+                                                          const int* __restrict__ pidx, int n_cand,
+                                                          int64_t cand_stride, int64_t row_stride,
+                                                          float* __restrict__ pair_val,
+                                                          int* __restrict__ pair_idx, int idx_offset,
                                                           int64_t* __restrict__ next_tokens,
                                                           int64_t* input_ids, int64_t* positions,
                                                           int* seq_lens, int64_t* slot_mapping,
                                                           const int* __restrict__ block_tables,
                                                           int max_blocks_per_seq, int block_size) {
   const int row = blockIdx.x, lane = threadIdx.x;
-  float best = lane < AM_SPLITS ? pval[row * AM_SPLITS + lane] : -INFINITY;
-  int best_i = lane < AM_SPLITS ? pidx[row * AM_SPLITS + lane] : 0x7fffffff;
+  float best = lane < n_cand ? pval[row * row_stride + lane * cand_stride] : -INFINITY;
+  int best_i = lane < n_cand ? pidx[row * row_stride + lane * cand_stride] : 0x7fffffff;
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
     const float ov = __shfl_xor(best, off);
@@ -93,6 +99,11 @@ __global__ __launch_bounds__(64) void argmax_final_kernel(const float* __restric
     am_better(best, best_i, ov, oi);
   }
   if (lane != 0) return;
+  if (pair_val != nullptr) {
+    pair_val[row] = best;
+    pair_idx[row] = best_i + idx_offset;
+    return;
+  }
   next_tokens[row] = best_i;
   if (positions == nullptr) return;
   input_ids[row] = best_i;
@@ -135,7 +146,67 @@ extern "C" int nmv_greedy_sample_advance(int64_t* next_tokens, const void* logit
   else
     hipLaunchKernelGGL((argmax_partial_kernel<BF16>), grid, dim3(AM_THREADS), 0, s,
                        (const uint16_t*)logits, row_stride, vocab_size, pval, pidx);
-  hipLaunchKernelGGL(argmax_final_kernel, dim3(num_seqs), dim3(64), 0, s, pval, pidx, next_tokens,
+  hipLaunchKernelGGL(argmax_final_kernel, dim3(num_seqs), dim3(64), 0, s, pval, pidx, AM_SPLITS,
+                     (int64_t)1, (int64_t)AM_SPLITS, (float*)nullptr, (int*)nullptr, 0, next_tokens,
+                     input_ids, positions, seq_lens, slot_mapping, block_tables, max_blocks_per_seq,
+                     block_size);
+  NMV_LAUNCH_CHECK();
+  return NMV_OK;
+}
+
+/* Vocab-parallel greedy sampling, shard side: the argmax of this rank's logits [num_seqs, local
+ * vocab] as a record = float value[padded] followed by int32 global_index[padded] (padded =
+ * nmv_greedy_record_elems(num_seqs), a multiple of 4 so that the record is a multiple of 16 bytes);
+ * entries past num_seqs are left untouched.  The records of all ranks are then all-gathered
+ * (nmv_ar_all_gather) and nmv_greedy_sample_finish picks the winner. */
+extern "C" int nmv_greedy_record_elems(int num_seqs) { return (std::max(num_seqs, 1) + 3) / 4 * 4; }
+
+extern "C" int nmv_greedy_sample_shard(void* record, const void* logits, int64_t row_stride, int num_seqs,
+                                       int local_vocab, int index_offset, nmv_dtype_t dtype,
+                                       void* scratch, int64_t scratch_bytes, void* stream) {
+  NMV_CHECK(dtype == NMV_F16 || dtype == NMV_BF16, "greedy_sample: unsupported dtype %d", (int)dtype);
+  NMV_CHECK(local_vocab > 0 && row_stride >= local_vocab, "greedy_sample: bad vocab_size / row stride");
+  NMV_CHECK(scratch != nullptr && scratch_bytes >= nmv_greedy_sample_scratch_bytes(num_seqs),
+            "greedy_sample: scratch too small");
+  if (num_seqs == 0) return NMV_OK;
+  float* pval = reinterpret_cast<float*>(scratch);
+  int* pidx = reinterpret_cast<int*>(pval + (int64_t)num_seqs * AM_SPLITS);
+  const int padded = nmv_greedy_record_elems(num_seqs);
+  float* rec_val = reinterpret_cast<float*>(record);
+  int* rec_idx = reinterpret_cast<int*>(rec_val + padded);
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid(AM_SPLITS, num_seqs);
+  if (dtype == NMV_F16)
+    hipLaunchKernelGGL((argmax_partial_kernel<F16>), grid, dim3(AM_THREADS), 0, s,
+                       (const uint16_t*)logits, row_stride, local_vocab, pval, pidx);
+  else
+    hipLaunchKernelGGL((argmax_partial_kernel<BF16>), grid, dim3(AM_THREADS), 0, s,
+                       (const uint16_t*)logits, row_stride, local_vocab, pval, pidx);
+  hipLaunchKernelGGL(argmax_final_kernel, dim3(num_seqs), dim3(64), 0, s, pval, pidx, AM_SPLITS,
+                     (int64_t)1, (int64_t)AM_SPLITS, rec_val, rec_idx, index_offset,
+                     (int64_t*)nullptr, (int64_t*)nullptr, (int64_t*)nullptr, (int*)nullptr,
+                     (int64_t*)nullptr, (const int*)nullptr, 0, 0);
+  NMV_LAUNCH_CHECK();
+  return NMV_OK;
+}
+
+/* gathered: world records back to back (rank order); the winner per row (ties -> lowest global
+ * index, i.e. torch.argmax of the gathered logits) goes to next_tokens and, with the state tensors,
+ * advances the decode batch as nmv_greedy_sample_advance does. */
+extern "C" int nmv_greedy_sample_finish(int64_t* next_tokens, const void* gathered, int world,
+                                        int num_seqs, int64_t* input_ids, int64_t* positions,
+                                        int* seq_lens, int64_t* slot_mapping, const int* block_tables,
+                                        int max_blocks_per_seq, int block_size, void* stream) {
+  NMV_CHECK(world >= 1 && world <= 64, "greedy_sample_finish: world must be 1..64");
+  NMV_CHECK(positions == nullptr || (input_ids && seq_lens && slot_mapping && block_tables &&
+                                     max_blocks_per_seq > 0 && block_size > 0),
+            "greedy_sample: the state advance needs every state tensor");
+  if (num_seqs == 0) return NMV_OK;
+  const int padded = nmv_greedy_record_elems(num_seqs);
+  const float* val = reinterpret_cast<const float*>(gathered);
+  const int* idx = reinterpret_cast<const int*>(val + padded);
+  hipLaunchKernelGGL(argmax_final_kernel, dim3(num_seqs), dim3(64), 0, (hipStream_t)stream, val, idx, world,
+                     (int64_t)2 * padded, (int64_t)1, (float*)nullptr, (int*)nullptr, 0, next_tokens,
                      input_ids, positions, seq_lens, slot_mapping, block_tables, max_blocks_per_seq,
                      block_size);
   NMV_LAUNCH_CHECK();

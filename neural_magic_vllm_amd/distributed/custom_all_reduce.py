@@ -98,6 +98,9 @@ class CustomAllReduce:
                     if not torch.equal(got.cpu().view(torch.int16), ref.to(dtype).view(torch.int16)):
                         self.disabled_reason = f"self-test mismatch (numel={numel}, {dtype})"
                         return False
+            if not self._gather_ok():
+                self.disabled_reason = "self-test: all_gather mismatch"
+                return False
             if _lib.load().nmv_ar_error(self.state):
                 self.disabled_reason = "self-test: a flag wait timed out"
                 return False
@@ -118,6 +121,22 @@ class CustomAllReduce:
         check(_lib.load().nmv_ar_all_reduce(self.state, ptr(t), ptr(out), t.numel(), dtype_code(t.dtype),
                                             stream_of(t)))
         return out
+
+
+    def all_gather_record(self, t: torch.Tensor) -> torch.Tensor:
+        """[world, *t.shape]: every rank's small contiguous record (nbytes % 16 == 0), rank order"""
+        nbytes = t.numel() * t.element_size()
+        assert self.enabled and t.is_contiguous() and nbytes % 16 == 0 and nbytes <= self.max_bytes
+        out = torch.empty((self.world, ) + tuple(t.shape), dtype=t.dtype, device=t.device)
+        check(_lib.load().nmv_ar_all_gather(self.state, ptr(t), ptr(out), nbytes, stream_of(t)))
+        return out
+
+    # also part of the self-test
+    def _gather_ok(self) -> bool:
+        x = torch.arange(64, dtype=torch.float32, device=self.device) + 1000.0 * self.rank
+        got = self.all_gather_record(x).cpu()
+        ref = torch.stack([torch.arange(64, dtype=torch.float32) + 1000.0 * r for r in range(self.world)])
+        return torch.equal(got, ref)
 
 
 def maybe_create(cpu_group, rank_in_group: int, world_size: int, device: torch.device,

@@ -25,7 +25,7 @@ import torch
 from .. import _custom_ops as ops
 from ..attention.backends.rocm_hip_attn import ROCmHipAttentionMetadata
 from ..distributed import (get_tensor_model_parallel_rank, get_tensor_model_parallel_world_size,
-                           tensor_model_parallel_all_gather)
+                           get_tp_group, tensor_model_parallel_all_gather)
 from ..model_executor.layers.quantization import get_quantization_config
 from ..model_executor.models.llama import LlamaForCausalLM
 
@@ -245,6 +245,21 @@ class DecodeRunner:
             # argmax + state advance in two launches (csrc/sampling.hip) instead of torch.argmax and
             # five element-wise kernels
             logits = torch.matmul(hidden, self.model.lm_head.weight.t())
+            car = get_tp_group().custom_ar if self.tp_size > 1 else None
+            if car is not None:
+                # vocab-parallel lm_head without gathering the logits: per-shard argmax record ->
+                # P2P all-gather of B x 8 bytes per rank -> winner + state advance (no RCCL in the step)
+                shard = logits.shape[1]
+                lo = get_tensor_model_parallel_rank() * shard
+                valid = max(0, min(shard, self.arch.vocab_size - lo))
+                if valid == 0:  # a shard that is all padding never wins
+                    rec = ops.greedy_sample_shard(torch.full_like(logits[:, :1], float("-inf")), lo)
+                else:
+                    rec = ops.greedy_sample_shard(logits[:, :valid], lo)
+                return ops.greedy_sample_finish(car.all_gather_record(rec), self.tp_size, logits.shape[0],
+                                                self.input_ids, self.positions, self.seq_lens,
+                                                self.slot_mapping, self.block_tables,
+                                                self.cache_config.block_size)
             if self.tp_size > 1:
                 logits = tensor_model_parallel_all_gather(logits)
             return ops.greedy_sample_advance(logits[:, :self.arch.vocab_size], self.input_ids, self.positions,

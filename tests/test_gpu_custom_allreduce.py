@@ -47,6 +47,16 @@ def _worker(rank, world, port, q, run_model):
             import test_gpu_tp
             runner = dr.DecodeRunner(dr.TINY, dev, torch.bfloat16, test_gpu_tp.QUANT, dr.CacheConfig(16, "auto"))
             out["tokens"] = test_gpu_tp._run(runner).tolist()
+            # with the all-reduces and the sampler's gather on the P2P path the decode step holds no
+            # collective of the process group any more: it captures into a hipGraph even over gloo
+            runner.setup_batch(test_gpu_tp.BATCH, test_gpu_tp.PROMPT, test_gpu_tp.STEPS + 4)
+            first = runner.prefill(test_gpu_tp.PROMPT, seed=7)
+            runner.input_ids.copy_(first)
+            dist.barrier()
+            assert runner.capture() is True
+            runner.input_ids.copy_(first)
+            toks = [first.cpu()] + [runner.decode_step().clone().cpu() for _ in range(test_gpu_tp.STEPS)]
+            out["graph_tokens"] = torch.stack(toks).tolist()
         else:
             it = 0
             for dtype in (torch.bfloat16, torch.float16):
@@ -80,6 +90,20 @@ def _worker(rank, world, port, q, run_model):
                 graph.replay()
                 torch.cuda.synchronize()
                 assert torch.equal(y.float().cpu(), torch.full((64, 4096), float(total * world * world)))
+            # vocab-parallel greedy sampling: per-shard argmax records, P2P all-gather, winner --
+            # against torch.argmax of the gathered logits (exact ties across shards -> lowest index)
+            from neural_magic_vllm_amd import _custom_ops as ops
+            b, shard = 7, 1000
+            g = torch.Generator().manual_seed(4242)
+            full = torch.randn((b, world * shard), generator=g).to(torch.bfloat16)
+            full[0, 5] = full[0, shard + 5] = 50.0       # a tie between shards 0 and 1
+            full[1, world * shard - 1] = 60.0            # winner in the last shard
+            mine = full[:, rank * shard:(rank + 1) * shard].contiguous().to(dev)
+            rec = ops.greedy_sample_shard(mine, rank * shard)
+            tok = ops.greedy_sample_finish(car.all_gather_record(rec), world, b).cpu()
+            ref = torch.stack([(row == row.max()).nonzero()[0, 0] for row in full.float()])
+            assert torch.equal(tok, ref), (tok, ref)
+            assert int(tok[0]) == 5 and int(tok[1]) == world * shard - 1
             assert _lib.load().nmv_ar_error(car.state) == 0
         dist.barrier()
         nd.destroy_model_parallel()
@@ -118,4 +142,4 @@ def test_tp_model_over_custom_all_reduce(gpu_device):
     ref_runner = dr.DecodeRunner(dr.TINY, gpu_device, torch.bfloat16, test_gpu_tp.QUANT, dr.CacheConfig(16, "auto"))
     ref = test_gpu_tp._run(ref_runner).tolist()
     outs = _spawn(2, run_model=True)
-    assert all(o["tokens"] == ref for o in outs)
+    assert all(o["tokens"] == ref and o["graph_tokens"] == ref for o in outs)
