@@ -26,7 +26,11 @@
 namespace nmv {
 
 constexpr int AR_MAX_RANKS = 8;
-constexpr int AR_MAX_BLOCKS = 64;
+// Every call launches the same number of blocks, whatever the message size: all per-block call
+// counters then advance in lockstep, which is what makes "two alternating staging buffers" safe (a
+// block count that varied with the size would let the buffer parity of different blocks drift apart
+// and a later call's block overwrite a region some peer is still reading for the previous call).
+constexpr int AR_MAX_BLOCKS = 16;
 constexpr int AR_THREADS = 512;
 constexpr uint64_t AR_SPIN_TICKS = 200ull * 1000 * 1000;  // s_memrealtime runs at 100 MHz: give up after 2 s
 
@@ -185,7 +189,7 @@ extern "C" int nmv_ar_all_reduce(void* state, const void* inp, void* out, int64_
             "custom_all_reduce: message must be a multiple of 16 bytes and <= %lld", (long long)st->max_bytes);
   NMV_CHECK((((uintptr_t)inp | (uintptr_t)out) & 15) == 0, "custom_all_reduce: 16-byte aligned tensors");
   const int64_t n_vec = bytes / 16;
-  const int blocks = (int)std::min<int64_t>(AR_MAX_BLOCKS, (n_vec + AR_THREADS - 1) / AR_THREADS);
+  const int blocks = AR_MAX_BLOCKS;
   hipStream_t s = (hipStream_t)stream;
   if (dtype == NMV_F16)
     hipLaunchKernelGGL((one_shot_all_reduce_kernel<F16>), dim3(blocks), dim3(AR_THREADS), 0, s, st->peers,
@@ -206,7 +210,7 @@ extern "C" int nmv_ar_all_gather(void* state, const void* inp, void* out, int64_
             "custom all_gather: record must be a multiple of 16 bytes and <= %lld", (long long)st->max_bytes);
   NMV_CHECK((((uintptr_t)inp | (uintptr_t)out) & 15) == 0, "custom all_gather: 16-byte aligned tensors");
   const int64_t n_vec = bytes_per_rank / 16;
-  const int blocks = (int)std::min<int64_t>(AR_MAX_BLOCKS, (n_vec + AR_THREADS - 1) / AR_THREADS);
+  const int blocks = AR_MAX_BLOCKS;
   hipLaunchKernelGGL((one_shot_all_reduce_kernel<BF16, true>), dim3(blocks), dim3(AR_THREADS), 0,
                      (hipStream_t)stream, st->peers, st->rank, st->world, (const uint16_t*)inp,
                      (uint16_t*)out, n_vec, st->max_bytes);
