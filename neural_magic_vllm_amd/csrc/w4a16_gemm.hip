@@ -36,6 +36,11 @@
 // split K across workgroups into fp32 slabs that the LAST workgroup of a tile (ticket in the
 // Marlin `workspace`) sums in a fixed order inside the same launch: bit-reproducible, unlike the
 // reference's lock-based fp16 global reduce (:1054-1110).
+// Two optional epilogues of the tall kernel (GemmParams::epi; neither is an op of the reference, both
+// are bit-identical to the op sequence they replace): 1 = silu(gate) * up on column-interleaved
+// gate_up weights, 2 = deferred reduction -- the slabs are left for the next launch of the layer
+// (residual-add + RMSNorm, rope + cache write) to sum, which takes the ticket round trip and the
+// slab re-read (2-3 us per call at decode sizes) off the critical path.
 // HBM-bound for M <= 64: algorithmic bytes K*N/2 + (K/g)*N*2 + 2*M*K + 2*M*N.
 #include <type_traits>
 
