@@ -399,6 +399,10 @@ int nmv_ar_create(void** state_out, int rank, int world, int64_t max_bytes, void
 int nmv_ar_open(void* state, const void* handles);
 int nmv_ar_all_reduce(void* state, const void* inp, void* out, int64_t numel, nmv_dtype_t dtype,
                       void* stream);
+/* all-reduce whose local input is still the fp32 split-K slabs [splits, numel] of the row-parallel
+ * GEMM (nmv_gptq_marlin_gemm_partial); bit-identical to nmv_gptq_marlin_gemm + nmv_ar_all_reduce */
+int nmv_ar_all_reduce_partial(void* state, const float* slab, int splits, void* out, int64_t numel,
+                              nmv_dtype_t dtype, void* stream);
 /* out[q * bytes_per_rank ...] = rank q's inp: all-gather of small per-rank records with the same
  * protocol (bytes_per_rank % 16 == 0, <= max_bytes) */
 int nmv_ar_all_gather(void* state, const void* inp, void* out, int64_t bytes_per_rank, void* stream);

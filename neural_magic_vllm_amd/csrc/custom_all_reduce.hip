@@ -64,7 +64,9 @@ __global__ __launch_bounds__(AR_THREADS) void one_shot_all_reduce_kernel(ArPeers
                                                                          const uint16_t* __restrict__ inp,
                                                                          uint16_t* __restrict__ out,
                                                                          int64_t n_vec /* 16-byte vectors */,
-                                                                         int64_t buf_bytes) {
+                                                                         int64_t buf_bytes,
+                                                                         const float* __restrict__ slab = nullptr,
+                                                                         int splits = 0, int64_t slab_stride = 0) {
   const int b = blockIdx.x;
   ArComm* mine = peers.comm[rank];
   const uint32_t seq = mine->seq[b] + 1;  // only this block touches seq[b]
@@ -74,7 +76,21 @@ __global__ __launch_bounds__(AR_THREADS) void one_shot_all_reduce_kernel(ArPeers
   // 1. my slice -> my staging buffer
   uint4* stage = reinterpret_cast<uint4*>(peers.data[rank] + parity_off);
   const uint4* src = reinterpret_cast<const uint4*>(inp);
-  for (int64_t v = v0 + threadIdx.x; v < v1; v += AR_THREADS) stage[v] = src[v];
+  if (slab != nullptr) {
+    // the input is still the fp32 split-K slabs of the row-parallel GEMM (nmv_gptq_marlin_gemm_partial):
+    // summed in split order from +0 and rounded to the model dtype, as that GEMM's own last pass would
+    for (int64_t v = v0 + threadIdx.x; v < v1; v += AR_THREADS) {
+      f32x4_t lo4 = {0.f, 0.f, 0.f, 0.f}, hi4 = {0.f, 0.f, 0.f, 0.f};
+      for (int sp = 0; sp < splits; ++sp) {
+        lo4 += *reinterpret_cast<const f32x4_t*>(slab + sp * slab_stride + v * 8);
+        hi4 += *reinterpret_cast<const f32x4_t*>(slab + sp * slab_stride + v * 8 + 4);
+      }
+      stage[v] = make_uint4(T::pack2(lo4[0], lo4[1]), T::pack2(lo4[2], lo4[3]), T::pack2(hi4[0], hi4[1]),
+                            T::pack2(hi4[2], hi4[3]));
+    }
+  } else {
+    for (int64_t v = v0 + threadIdx.x; v < v1; v += AR_THREADS) stage[v] = src[v];
+  }
   __threadfence_system();
   __syncthreads();
   // 2. signal every rank (myself included), wait for every rank
@@ -197,6 +213,32 @@ extern "C" int nmv_ar_all_reduce(void* state, const void* inp, void* out, int64_
   else
     hipLaunchKernelGGL((one_shot_all_reduce_kernel<BF16>), dim3(blocks), dim3(AR_THREADS), 0, s, st->peers,
                        st->rank, st->world, (const uint16_t*)inp, (uint16_t*)out, n_vec, st->max_bytes);
+  NMV_LAUNCH_CHECK();
+  return NMV_OK;
+}
+
+/* all-reduce whose local input is the sum of `splits` fp32 slabs [splits, numel] (deferred split-K of
+ * the row-parallel projection): bit-identical to nmv_gptq_marlin_gemm followed by nmv_ar_all_reduce */
+extern "C" int nmv_ar_all_reduce_partial(void* state, const float* slab, int splits, void* out,
+                                         int64_t numel, nmv_dtype_t dtype, void* stream) {
+  ArState* st = (ArState*)state;
+  NMV_CHECK(st != nullptr && st->opened, "custom_all_reduce: not initialised");
+  NMV_CHECK(dtype == NMV_F16 || dtype == NMV_BF16, "custom_all_reduce: fp16 / bf16 only");
+  NMV_CHECK(slab != nullptr && splits >= 1, "custom_all_reduce: bad slabs");
+  const int64_t bytes = numel * 2;
+  NMV_CHECK(bytes > 0 && bytes % 16 == 0 && bytes <= st->max_bytes,
+            "custom_all_reduce: message must be a multiple of 16 bytes and <= %lld", (long long)st->max_bytes);
+  NMV_CHECK((((uintptr_t)slab | (uintptr_t)out) & 15) == 0, "custom_all_reduce: 16-byte aligned tensors");
+  const int64_t n_vec = bytes / 16;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == NMV_F16)
+    hipLaunchKernelGGL((one_shot_all_reduce_kernel<F16>), dim3(AR_MAX_BLOCKS), dim3(AR_THREADS), 0, s, st->peers,
+                       st->rank, st->world, (const uint16_t*)nullptr, (uint16_t*)out, n_vec, st->max_bytes, slab,
+                       splits, numel);
+  else
+    hipLaunchKernelGGL((one_shot_all_reduce_kernel<BF16>), dim3(AR_MAX_BLOCKS), dim3(AR_THREADS), 0, s, st->peers,
+                       st->rank, st->world, (const uint16_t*)nullptr, (uint16_t*)out, n_vec, st->max_bytes, slab,
+                       splits, numel);
   NMV_LAUNCH_CHECK();
   return NMV_OK;
 }

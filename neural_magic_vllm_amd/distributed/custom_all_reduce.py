@@ -123,6 +123,17 @@ class CustomAllReduce:
         return out
 
 
+    def all_reduce_partial(self, slab: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+        """all-reduce of round(sum of the fp32 split-K slabs [S, T, N]) -> [T, N] in `dtype`"""
+        assert self.enabled and slab.dtype == torch.float32 and slab.is_contiguous() and slab.dim() == 3
+        out = torch.empty(slab.shape[1:], dtype=dtype, device=slab.device)
+        check(_lib.load().nmv_ar_all_reduce_partial(self.state, ptr(slab), slab.shape[0], ptr(out), out.numel(),
+                                                    dtype_code(dtype), stream_of(slab)))
+        return out
+
+    def can_reduce(self, numel: int) -> bool:
+        return self.enabled and 0 < numel * 2 <= self.max_bytes and (numel * 2) % 16 == 0
+
     def all_gather_record(self, t: torch.Tensor) -> torch.Tensor:
         """[world, *t.shape]: every rank's small contiguous record (nbytes % 16 == 0), rank order"""
         nbytes = t.numel() * t.element_size()

@@ -8,16 +8,17 @@ attributes (input_dim / output_dim / packed_dim / pack_factor) and the same weig
 sharding rules, so quantisation methods written for the reference plug in unchanged.  The
 row-parallel all-reduce goes through RCCL (distributed/communication_op.py).
 """
+import os
 from typing import List, Optional, Tuple
 
 import torch
-
-from ... import _custom_ops as ops
 import torch.nn.functional as F
 from torch.nn.parameter import Parameter
 
+from ... import _custom_ops as ops
 from ...distributed import (get_tensor_model_parallel_rank, get_tensor_model_parallel_world_size,
-                            tensor_model_parallel_all_gather, tensor_model_parallel_all_reduce)
+                            get_tp_group, tensor_model_parallel_all_gather,
+                            tensor_model_parallel_all_reduce)
 from ..utils import set_weight_attrs
 from .quantization.base_config import (LinearMethodBase, QuantizationConfig,  # noqa: F401
                                        QuantizeMethodBase)
@@ -313,6 +314,7 @@ class RowParallelLinear(LinearBase):
         super().__init__(input_size, output_size, skip_bias_add, params_dtype, quant_config)
         self.input_is_parallel = input_is_parallel
         self.reduce_results = reduce_results
+        self.defer_into_all_reduce = os.environ.get("NMV_FUSED_GLUE", "1") != "0"
         self.tp_size = get_tensor_model_parallel_world_size()
         self.input_size_per_partition = divide(input_size, self.tp_size)
         assert self.quant_method is not None
@@ -345,15 +347,18 @@ class RowParallelLinear(LinearBase):
         consumer that sums them (ops.fused_add_rms_norm_partial), or None when this layer cannot
         defer -- a result that still has to be all-reduced or biased, or a quantisation method /
         shape without the partial GEMM."""
+        if self.tp_size > 1 or not self._can_defer(input_):
+            return None
+        return self.quant_method.apply_partial(self, input_)
+
+    def _can_defer(self, input_) -> bool:
         qm = self.quant_method
-        if self.tp_size > 1 or self.bias is not None or not self.input_is_parallel \
-                or not hasattr(qm, "apply_partial") or not qm.can_defer_reduce(self) or not input_.is_cuda \
+        if self.bias is not None or not self.input_is_parallel or not hasattr(qm, "apply_partial") \
+                or not qm.can_defer_reduce(self) or not input_.is_cuda \
                 or self.output_size % 8 != 0 or self.output_size > 8192:
-            return None
+            return False
         rows = input_.numel() // input_.shape[-1]
-        if ops.gptq_marlin_gemm_partial_splits(rows, self.output_size, self.input_size_per_partition) < 1:
-            return None
-        return qm.apply_partial(self, input_)
+        return ops.gptq_marlin_gemm_partial_splits(rows, self.output_size, self.input_size_per_partition) >= 1
 
     def forward(self, input_):
         if self.input_is_parallel:
@@ -362,6 +367,15 @@ class RowParallelLinear(LinearBase):
             tp_rank = get_tensor_model_parallel_rank()
             input_parallel = torch.chunk(input_, self.tp_size, dim=-1)[tp_rank].contiguous()
         assert self.quant_method is not None
+        if self.reduce_results and self.tp_size > 1 and self.defer_into_all_reduce:
+            # the P2P all-reduce sums this rank's fp32 split-K slabs itself (deferred reduction under TP)
+            car = get_tp_group().custom_ar
+            rows = input_parallel.numel() // input_parallel.shape[-1]
+            if car is not None and car.can_reduce(rows * self.output_size) and self._can_defer(input_parallel):
+                slab = self.quant_method.apply_partial(self, input_parallel)
+                output_ = car.all_reduce_partial(slab, input_parallel.dtype).reshape(
+                    input_parallel.shape[:-1] + (self.output_size, ))
+                return output_, None
         output_parallel = self.quant_method.apply(self, input_parallel)
         if self.reduce_results and self.tp_size > 1:
             output_ = tensor_model_parallel_all_reduce(output_parallel)  # RCCL over xGMI

@@ -90,6 +90,12 @@ def _worker(rank, world, port, q, run_model):
                 graph.replay()
                 torch.cuda.synchronize()
                 assert torch.equal(y.float().cpu(), torch.full((64, 4096), float(total * world * world)))
+            # all-reduce whose local input is still fp32 split-K slabs (deferred reduction under TP)
+            slabs = torch.stack([torch.full((5, 4096), float(rank + 1) * (sp + 1) * 0.25, device=dev)
+                                 for sp in range(3)])
+            got = car.all_reduce_partial(slabs, torch.bfloat16)
+            want = sum((r + 1) * 1.5 for r in range(world))
+            assert got.shape == (5, 4096) and torch.equal(got.float().cpu(), torch.full((5, 4096), float(want)))
             # vocab-parallel greedy sampling: per-shard argmax records, P2P all-gather, winner --
             # against torch.argmax of the gathered logits (exact ties across shards -> lowest index)
             from neural_magic_vllm_amd import _custom_ops as ops
