@@ -403,6 +403,12 @@ int nmv_ar_all_reduce(void* state, const void* inp, void* out, int64_t numel, nm
  * GEMM (nmv_gptq_marlin_gemm_partial); bit-identical to nmv_gptq_marlin_gemm + nmv_ar_all_reduce */
 int nmv_ar_all_reduce_partial(void* state, const float* slab, int splits, void* out, int64_t numel,
                               nmv_dtype_t dtype, void* stream);
+/* all-reduce + fused_add_rms_norm in one launch: x = inp [rows, hidden] (model dtype) or, with
+ * inp == NULL, the fp32 slabs [splits, rows, hidden]; residual += all_reduce(x) in place, out =
+ * rms_norm(residual) * weight.  hidden % 8 == 0, <= 8192.  Bit-identical to the separate launches. */
+int nmv_ar_all_reduce_add_rms_norm(void* state, const void* inp, const float* slab, int splits,
+                                   void* residual, const void* weight, void* out, float epsilon,
+                                   int rows, int hidden, nmv_dtype_t dtype, void* stream);
 /* out[q * bytes_per_rank ...] = rank q's inp: all-gather of small per-rank records with the same
  * protocol (bytes_per_rank % 16 == 0, <= max_bytes) */
 int nmv_ar_all_gather(void* state, const void* inp, void* out, int64_t bytes_per_rank, void* stream);

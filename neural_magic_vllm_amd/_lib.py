@@ -67,6 +67,7 @@ SIGNATURES = {
     "nmv_ar_open": (_I, [_P, _P]),
     "nmv_ar_all_reduce": (_I, [_P, _P, _P, _L, _I, _P]),
     "nmv_ar_all_reduce_partial": (_I, [_P, _P, _I, _P, _L, _I, _P]),
+    "nmv_ar_all_reduce_add_rms_norm": (_I, [_P, _P, _P, _I, _P, _P, _P, _F, _I, _I, _I, _P]),
     "nmv_ar_all_gather": (_I, [_P, _P, _P, _L, _P]),
     "nmv_ar_error": (_I, [_P]),
     "nmv_greedy_record_elems": (_I, [_I]),

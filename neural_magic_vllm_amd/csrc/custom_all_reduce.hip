@@ -23,6 +23,9 @@
 #include <cstring>
 #include <vector>
 
+// the fused residual-add + RMSNorm below reproduces glue_kernels.hip's roundings: no contraction
+#pragma clang fp contract(off)
+
 namespace nmv {
 
 constexpr int AR_MAX_RANKS = 8;
@@ -135,6 +138,141 @@ __global__ __launch_bounds__(AR_THREADS) void one_shot_all_reduce_kernel(ArPeers
   if (threadIdx.x == 0) mine->seq[b] = seq;
 }
 
+// ---------------------------------------------------------------------------------------------
+// all-reduce + residual-add + RMSNorm in one launch (tensor-parallel decode: o_proj / down_proj
+// -> all-reduce -> fused_add_rms_norm is three launches per projection otherwise).  Same protocol;
+// the slices are whole rows (block b owns rows [b R, (b+1) R)), so after the handshake a block holds
+// complete reduced rows and can finish them: sum over ranks (fp32, rank order) rounded to the model
+// dtype = what nmv_ar_all_reduce writes; + residual, rounded, stored back; variance with the per-lane
+// accumulation order of rms_norm_reg_kernel's 256-lane form (replayed through LDS, as its wide form
+// does); x * rsqrt rounded, times weight.  Bit-identical to the three launches.
+template <typename T>
+__device__ __forceinline__ float ar_rnd(float f) {
+  uint32_t b = T::from_float(f);
+  asm volatile("" : "+v"(b));  // keep the rounding (see glue_kernels.hip: pin())
+  return T::to_float((uint16_t)b);
+}
+
+template <typename T>
+__global__ __launch_bounds__(AR_THREADS) void one_shot_all_reduce_norm_kernel(
+    ArPeers peers, int rank, int world, const uint16_t* __restrict__ inp, const float* __restrict__ slab,
+    int splits, int64_t slab_stride, uint16_t* __restrict__ residual, const uint16_t* __restrict__ weight,
+    uint16_t* __restrict__ out, float epsilon, int rows, int hidden, int64_t buf_bytes) {
+  __shared__ float fold[2 * AR_THREADS][4];
+  __shared__ float red[AR_THREADS / 64];
+  const int b = blockIdx.x;
+  ArComm* mine = peers.comm[rank];
+  const uint32_t seq = mine->seq[b] + 1;
+  const int64_t parity_off = (seq & 1) ? buf_bytes : 0;
+  const int hv = hidden / 8;                         // 16-byte vectors per row (<= 2 * AR_THREADS)
+  const int per = (rows + gridDim.x - 1) / gridDim.x;
+  const int r0 = b * per, r1 = min(r0 + per, rows);
+  uint4* stage = reinterpret_cast<uint4*>(peers.data[rank] + parity_off);
+  // 1. my rows -> my staging buffer
+  for (int r = r0; r < r1; ++r)
+    for (int v = threadIdx.x; v < hv; v += AR_THREADS) {
+      const int64_t e = (int64_t)r * hv + v;
+      if (slab != nullptr) {
+        f32x4_t lo4 = {0.f, 0.f, 0.f, 0.f}, hi4 = {0.f, 0.f, 0.f, 0.f};
+        for (int sp = 0; sp < splits; ++sp) {
+          lo4 += *reinterpret_cast<const f32x4_t*>(slab + sp * slab_stride + e * 8);
+          hi4 += *reinterpret_cast<const f32x4_t*>(slab + sp * slab_stride + e * 8 + 4);
+        }
+        stage[e] = make_uint4(T::pack2(lo4[0], lo4[1]), T::pack2(lo4[2], lo4[3]), T::pack2(hi4[0], hi4[1]),
+                              T::pack2(hi4[2], hi4[3]));
+      } else {
+        stage[e] = reinterpret_cast<const uint4*>(inp)[e];
+      }
+    }
+  __threadfence_system();
+  __syncthreads();
+  // 2. handshake
+  if (threadIdx.x < world) {
+    const int q = threadIdx.x;
+    __hip_atomic_store(&peers.comm[q]->flags[b][rank], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+    while ((int32_t)(__hip_atomic_load(&mine->flags[b][q], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - seq) < 0) {
+      if (__builtin_amdgcn_s_memrealtime() - t0 > AR_SPIN_TICKS) {
+        __hip_atomic_store(&mine->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+  }
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+  // 3. finish my rows
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int r = r0; r < r1; ++r) {
+    uint32_t z[2][4];
+    float terms[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int v = threadIdx.x + i * AR_THREADS;
+      const bool ok = v < hv;
+      const int64_t e = (int64_t)r * hv + (ok ? v : 0);
+      float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      for (int q = 0; q < world; ++q) {
+        const uint4 x = reinterpret_cast<const uint4*>(peers.data[q] + parity_off)[e];
+        const uint32_t xs[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          acc[2 * j] += lo_f<T>(xs[j]);
+          acc[2 * j + 1] += hi_f<T>(xs[j]);
+        }
+      }
+      const uint4 rs4 = ld16(residual + e * 8);
+      const uint32_t rs[4] = {rs4.x, rs4.y, rs4.z, rs4.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        // all-reduce output rounded to the model dtype, then z = x + residual rounded (layernorm_kernels.cu:271-274)
+        const float lo = ar_rnd<T>(ar_rnd<T>(acc[2 * j]) + lo_f<T>(rs[j]));
+        const float hi = ar_rnd<T>(ar_rnd<T>(acc[2 * j + 1]) + hi_f<T>(rs[j]));
+        z[i][j] = T::pack2(lo, hi);
+        terms[i][j] = ok ? lo * lo + hi * hi : 0.f;
+      }
+      if (ok) st16(residual + e * 8, make_uint4(z[i][0], z[i][1], z[i][2], z[i][3]));
+    }
+    // variance in the 256-lane form's order: lane t adds the four addends of vector t, t + 256, ...
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fold[threadIdx.x + i * AR_THREADS][j] = terms[i][j];
+    __syncthreads();
+    float var = 0.f;
+    if (threadIdx.x < 256) {
+      for (int qv = threadIdx.x; qv < hv; qv += 256)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) var += fold[qv][j];
+    }
+    var = wave_sum(var);
+    if (lane == 0) red[wave] = var;
+    __syncthreads();
+    float tot = 0.f;
+#pragma unroll
+    for (int w = 0; w < AR_THREADS / 64; ++w) tot += red[w];
+    const float sc = rsqrtf(tot / hidden + epsilon);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int v = threadIdx.x + i * AR_THREADS;
+      if (v >= hv) continue;
+      const uint4 w4 = ld16(weight + v * 8);
+      const uint32_t ws[4] = {w4.x, w4.y, w4.z, w4.w};
+      uint32_t o[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        // ((scalar_t)(x * s_variance)) * weight  (layernorm_kernels.cu:41-42)
+        const float lo = ar_rnd<T>(lo_f<T>(z[i][j]) * sc) * lo_f<T>(ws[j]);
+        const float hi = ar_rnd<T>(hi_f<T>(z[i][j]) * sc) * hi_f<T>(ws[j]);
+        o[j] = T::pack2(lo, hi);
+      }
+      st16(out + ((int64_t)r * hv + v) * 8, make_uint4(o[0], o[1], o[2], o[3]));
+    }
+  }
+  if (threadIdx.x == 0) mine->seq[b] = seq;
+}
+
 }  // namespace nmv
 
 using namespace nmv;
@@ -239,6 +377,40 @@ extern "C" int nmv_ar_all_reduce_partial(void* state, const float* slab, int spl
     hipLaunchKernelGGL((one_shot_all_reduce_kernel<BF16>), dim3(AR_MAX_BLOCKS), dim3(AR_THREADS), 0, s, st->peers,
                        st->rank, st->world, (const uint16_t*)nullptr, (uint16_t*)out, n_vec, st->max_bytes, slab,
                        splits, numel);
+  NMV_LAUNCH_CHECK();
+  return NMV_OK;
+}
+
+/* all-reduce (input: inp [rows, hidden] in the model dtype, or -- inp == NULL -- the fp32 slabs
+ * [splits, rows, hidden]) + fused_add_rms_norm in one launch: residual += all_reduce(x) (in place),
+ * out = rms_norm(residual) * weight.  hidden % 8 == 0, hidden <= 8192.  Bit-identical to
+ * nmv_ar_all_reduce(_partial) + nmv_fused_add_rms_norm. */
+extern "C" int nmv_ar_all_reduce_add_rms_norm(void* state, const void* inp, const float* slab, int splits,
+                                              void* residual, const void* weight, void* out,
+                                              float epsilon, int rows, int hidden, nmv_dtype_t dtype,
+                                              void* stream) {
+  ArState* st = (ArState*)state;
+  NMV_CHECK(st != nullptr && st->opened, "custom_all_reduce: not initialised");
+  NMV_CHECK(dtype == NMV_F16 || dtype == NMV_BF16, "custom_all_reduce: fp16 / bf16 only");
+  NMV_CHECK((inp != nullptr) != (slab != nullptr) && (slab == nullptr || splits >= 1),
+            "all_reduce_add_rms_norm: exactly one of inp / slab");
+  NMV_CHECK(rows > 0 && hidden % 8 == 0 && hidden <= 8192 && (int64_t)rows * hidden * 2 <= st->max_bytes,
+            "all_reduce_add_rms_norm: hidden must be a multiple of 8, <= 8192; message <= %lld bytes",
+            (long long)st->max_bytes);
+  NMV_CHECK((((uintptr_t)inp | (uintptr_t)slab | (uintptr_t)residual | (uintptr_t)weight | (uintptr_t)out) & 15) == 0,
+            "all_reduce_add_rms_norm: 16-byte aligned tensors");
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t stride = (int64_t)rows * hidden;
+  if (dtype == NMV_F16)
+    hipLaunchKernelGGL((one_shot_all_reduce_norm_kernel<F16>), dim3(AR_MAX_BLOCKS), dim3(AR_THREADS), 0, s,
+                       st->peers, st->rank, st->world, (const uint16_t*)inp, slab, splits, stride,
+                       (uint16_t*)residual, (const uint16_t*)weight, (uint16_t*)out, epsilon, rows, hidden,
+                       st->max_bytes);
+  else
+    hipLaunchKernelGGL((one_shot_all_reduce_norm_kernel<BF16>), dim3(AR_MAX_BLOCKS), dim3(AR_THREADS), 0, s,
+                       st->peers, st->rank, st->world, (const uint16_t*)inp, slab, splits, stride,
+                       (uint16_t*)residual, (const uint16_t*)weight, (uint16_t*)out, epsilon, rows, hidden,
+                       st->max_bytes);
   NMV_LAUNCH_CHECK();
   return NMV_OK;
 }

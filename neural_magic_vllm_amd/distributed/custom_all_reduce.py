@@ -101,6 +101,9 @@ class CustomAllReduce:
             if not self._gather_ok():
                 self.disabled_reason = "self-test: all_gather mismatch"
                 return False
+            if not self._fused_ok():
+                self.disabled_reason = "self-test: fused all-reduce + norm mismatch"
+                return False
             if _lib.load().nmv_ar_error(self.state):
                 self.disabled_reason = "self-test: a flag wait timed out"
                 return False
@@ -131,6 +134,21 @@ class CustomAllReduce:
                                                     dtype_code(dtype), stream_of(slab)))
         return out
 
+    def all_reduce_add_rms_norm(self, x: torch.Tensor, residual: torch.Tensor, weight: torch.Tensor,
+                                epsilon: float) -> torch.Tensor:
+        """x: [T, H] in the model dtype, or the fp32 split-K slabs [S, T, H]; residual += all_reduce(x)
+        in place; returns rms_norm(residual) * weight -- one launch"""
+        slabs = x.dtype == torch.float32
+        assert self.enabled and x.is_contiguous() and residual.is_contiguous() and x.dim() == (3 if slabs else 2)
+        rows, hidden = x.shape[-2], x.shape[-1]
+        assert residual.numel() == rows * hidden
+        out = torch.empty_like(residual)
+        check(_lib.load().nmv_ar_all_reduce_add_rms_norm(
+            self.state, None if slabs else ptr(x), ptr(x) if slabs else None, x.shape[0] if slabs else 0,
+            ptr(residual), ptr(weight), ptr(out), epsilon, rows, hidden, dtype_code(residual.dtype),
+            stream_of(residual)))
+        return out
+
     def can_reduce(self, numel: int) -> bool:
         return self.enabled and 0 < numel * 2 <= self.max_bytes and (numel * 2) % 16 == 0
 
@@ -148,6 +166,31 @@ class CustomAllReduce:
         got = self.all_gather_record(x).cpu()
         ref = torch.stack([torch.arange(64, dtype=torch.float32) + 1000.0 * r for r in range(self.world)])
         return torch.equal(got, ref)
+
+
+    def _fused_ok(self) -> bool:
+        """the slab-consuming and the norm-fusing variants against the (just verified) plain all-reduce
+        followed by the stand-alone fused_add_rms_norm: bit for bit"""
+        from .. import _custom_ops as ops
+        for rows, hidden in ((64, 4096), (3, 8192)):
+            g = torch.Generator().manual_seed(99 + self.rank)
+            x = torch.randn((rows, hidden), generator=g).to(torch.bfloat16).to(self.device)
+            g2 = torch.Generator().manual_seed(5)
+            res = torch.randn((rows, hidden), generator=g2).to(torch.bfloat16).to(self.device)
+            w = (1 + 0.1 * torch.randn((hidden, ), generator=g2)).to(torch.bfloat16).to(self.device)
+            ref = self.all_reduce(x)
+            slabs = torch.stack([x.float() * 0.5, x.float() * 0.5])
+            if not torch.equal(self.all_reduce_partial(slabs, torch.bfloat16), ref):
+                return False
+            ref_res = res.clone()
+            ops.fused_add_rms_norm(ref, ref_res, w, 1e-5)
+            for inp in (x, slabs):
+                got_res = res.clone()
+                got = self.all_reduce_add_rms_norm(inp, got_res, w, 1e-5)
+                if not (torch.equal(got, ref) and torch.equal(got_res, ref_res)):
+                    return False
+        torch.cuda.synchronize(self.device)
+        return True
 
 
 def maybe_create(cpu_group, rank_in_group: int, world_size: int, device: torch.device,

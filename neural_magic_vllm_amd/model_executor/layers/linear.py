@@ -347,8 +347,15 @@ class RowParallelLinear(LinearBase):
         consumer that sums them (ops.fused_add_rms_norm_partial), or None when this layer cannot
         defer -- a result that still has to be all-reduced or biased, or a quantisation method /
         shape without the partial GEMM."""
-        if self.tp_size > 1 or not self._can_defer(input_):
+        if not self._can_defer(input_):
             return None
+        if self.tp_size > 1:
+            # under TP the slabs still have to be all-reduced: only worth leaving to the consumer
+            # when the P2P communicator can take them (all_reduce_add_rms_norm)
+            car = get_tp_group().custom_ar
+            rows = input_.numel() // input_.shape[-1]
+            if not self.reduce_results or car is None or not car.can_reduce(rows * self.output_size):
+                return None
         return self.quant_method.apply_partial(self, input_)
 
     def _can_defer(self, input_) -> bool:

@@ -15,7 +15,7 @@ from torch import nn
 
 from ... import _custom_ops as ops
 from ...attention import Attention, AttentionMetadata
-from ...distributed import get_tensor_model_parallel_world_size
+from ...distributed import get_tensor_model_parallel_world_size, get_tp_group
 from ..layers.activation import SiluAndMul
 from ..layers.layernorm import RMSNorm
 from ..layers.linear import MergedColumnParallelLinear, QKVParallelLinear, RowParallelLinear
@@ -42,6 +42,10 @@ class SplitKPartial(NamedTuple):
 def _add_norm(norm: RMSNorm, hidden_states, residual: torch.Tensor):
     """fused_add_rms_norm whose input may be a SplitKPartial; returns (normed, residual)"""
     if isinstance(hidden_states, SplitKPartial):
+        if get_tensor_model_parallel_world_size() > 1:
+            # row-parallel projection under TP: all-reduce + residual-add + RMSNorm in one launch
+            return get_tp_group().custom_ar.all_reduce_add_rms_norm(
+                hidden_states.slab, residual, norm.weight.data, norm.variance_epsilon), residual
         return ops.fused_add_rms_norm_partial(hidden_states.slab, residual, norm.weight.data,
                                               norm.variance_epsilon), residual
     return norm(hidden_states, residual)

@@ -58,6 +58,7 @@ def _worker(rank, world, port, q, run_model):
             toks = [first.cpu()] + [runner.decode_step().clone().cpu() for _ in range(test_gpu_tp.STEPS)]
             out["graph_tokens"] = torch.stack(toks).tolist()
         else:
+            from neural_magic_vllm_amd import _custom_ops as ops
             it = 0
             for dtype in (torch.bfloat16, torch.float16):
                 for numel in (8, 4096, 64 * 4096, 3 * 4096 + 8, 2 << 20):
@@ -96,9 +97,29 @@ def _worker(rank, world, port, q, run_model):
             got = car.all_reduce_partial(slabs, torch.bfloat16)
             want = sum((r + 1) * 1.5 for r in range(world))
             assert got.shape == (5, 4096) and torch.equal(got.float().cpu(), torch.full((5, 4096), float(want)))
+            # all-reduce + residual-add + RMSNorm in one launch against the three separate launches
+            for dtype in (torch.bfloat16, torch.float16):
+                for rows, hidden in ((1, 4096), (5, 512), (64, 4096), (100, 5120), (16, 8192)):
+                    g = torch.Generator().manual_seed(31 * rows + hidden + rank)
+                    x = torch.randn((rows, hidden), generator=g).to(dtype).to(dev)
+                    g2 = torch.Generator().manual_seed(7)      # same residual / weight on every rank
+                    res = torch.randn((rows, hidden), generator=g2).to(dtype).to(dev)
+                    w = (1 + 0.1 * torch.randn((hidden, ), generator=g2)).to(dtype).to(dev)
+                    ref_res = res.clone()
+                    ref = car.all_reduce(x)
+                    ops.fused_add_rms_norm(ref, ref_res, w, 1e-5)
+                    got_res = res.clone()
+                    got = car.all_reduce_add_rms_norm(x, got_res, w, 1e-5)
+                    assert torch.equal(got_res.view(torch.int16), ref_res.view(torch.int16)), (rows, hidden, dtype)
+                    assert torch.equal(got.view(torch.int16), ref.view(torch.int16)), (rows, hidden, dtype)
+                    # the same from fp32 slabs whose sum rounds to x
+                    slabs = torch.stack([x.float() * 0.5, x.float() * 0.25, x.float() * 0.25])
+                    got_res2 = res.clone()
+                    got2 = car.all_reduce_add_rms_norm(slabs, got_res2, w, 1e-5)
+                    assert torch.equal(got2.view(torch.int16), ref.view(torch.int16)), (rows, hidden, dtype, "slabs")
+                    assert torch.equal(got_res2.view(torch.int16), ref_res.view(torch.int16))
             # vocab-parallel greedy sampling: per-shard argmax records, P2P all-gather, winner --
             # against torch.argmax of the gathered logits (exact ties across shards -> lowest index)
-            from neural_magic_vllm_amd import _custom_ops as ops
             b, shard = 7, 1000
             g = torch.Generator().manual_seed(4242)
             full = torch.randn((b, world * shard), generator=g).to(torch.bfloat16)
