@@ -188,6 +188,25 @@ int nmv_rotary_embedding_and_cache_partial(const int64_t* positions, const float
                                            const int64_t* slot_mapping, int block_size,
                                            nmv_dtype_t dtype, nmv_kv_dtype_t kv_dtype, float kv_scale,
                                            void* stream);
+/* paged_attention_v1 / v2 whose query and new key / value are still the fp32 split-K slabs of the
+ * qkv projection (slab [splits, num_seqs, (heads + 2 kv_heads) * head_size]): sum + round, neox
+ * rotary embedding (rot_dim == head_size), the new token's k / v stored at slot_mapping[seq], then
+ * attention over the cache -- rotary_embedding + reshape_and_cache + paged_attention in one launch,
+ * bit-identical to them.  Decode batches only (one new token per sequence, positions[seq] ==
+ * seq_lens[seq] - 1); no ALiBi. */
+int nmv_paged_attention_v1_rope_partial(
+    void* out, const float* slab, int splits, const int64_t* positions, const void* cos_sin_cache,
+    const int64_t* slot_mapping, void* key_cache, void* value_cache, int num_seqs, int num_heads,
+    int head_size, int num_kv_heads, float scale, const int32_t* block_tables, const int32_t* seq_lens,
+    int block_size, int max_seq_len, int max_num_blocks_per_seq, int64_t kv_block_stride,
+    int64_t kv_head_stride, nmv_dtype_t dtype, nmv_kv_dtype_t kv_dtype, float kv_scale, void* stream);
+int nmv_paged_attention_v2_rope_partial(
+    void* out, float* exp_sums, float* max_logits, void* tmp_out, const float* slab, int splits,
+    const int64_t* positions, const void* cos_sin_cache, const int64_t* slot_mapping, void* key_cache,
+    void* value_cache, int num_seqs, int num_heads, int head_size, int num_kv_heads, float scale,
+    const int32_t* block_tables, const int32_t* seq_lens, int block_size, int max_seq_len,
+    int max_num_blocks_per_seq, int64_t kv_block_stride, int64_t kv_head_stride, nmv_dtype_t dtype,
+    nmv_kv_dtype_t kv_dtype, float kv_scale, void* stream);
 /* greedy sampling (torch.argmax of the reference's Sampler greedy branch; ties -> lowest index) of
  * logits [num_seqs, vocab_size] (row stride in elements) into next_tokens int64[num_seqs], and --
  * when positions != NULL -- the on-device advance of a decode batch: input_ids = token,

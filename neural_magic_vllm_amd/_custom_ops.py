@@ -382,3 +382,15 @@ def greedy_sample_finish(gathered: torch.Tensor, world: int, num_seqs: int,
     from neural_magic_vllm_amd import _torch_bindings as tb
     return tb.greedy_sample_finish(gathered, world, num_seqs, input_ids, positions, seq_lens, slot_mapping,
                                    block_tables, block_size)
+
+
+def paged_attention_rope_partial(out: torch.Tensor, slab: torch.Tensor, positions: torch.Tensor,
+                                 cos_sin_cache: torch.Tensor, slot_mapping: torch.Tensor,
+                                 key_cache: torch.Tensor, value_cache: torch.Tensor, num_heads: int,
+                                 num_kv_heads: int, head_size: int, scale: float, block_tables: torch.Tensor,
+                                 seq_lens: torch.Tensor, block_size: int, max_seq_len: int, kv_cache_dtype: str,
+                                 kv_scale: float, partition_bufs=None) -> None:
+    from neural_magic_vllm_amd import _torch_bindings as tb
+    tb.paged_attention_rope_partial(out, slab, positions, cos_sin_cache, slot_mapping, key_cache, value_cache,
+                                    num_heads, num_kv_heads, head_size, scale, block_tables, seq_lens,
+                                    block_size, max_seq_len, kv_cache_dtype, kv_scale, partition_bufs)

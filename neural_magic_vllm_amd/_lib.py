@@ -74,6 +74,10 @@ SIGNATURES = {
     "nmv_greedy_sample_shard": (_I, [_P, _P, _L, _I, _I, _I, _I, _P, _L, _P]),
     "nmv_greedy_sample_finish": (_I, [_P, _P, _I, _I, _P, _P, _P, _P, _P, _I, _I, _P]),
     "nmv_ar_destroy": (_I, [_P]),
+    "nmv_paged_attention_v1_rope_partial": (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P, _P, _I, _I,
+                                                 _I, _L, _L, _I, _I, _F, _P]),
+    "nmv_paged_attention_v2_rope_partial": (_I, [_P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P,
+                                                 _P, _I, _I, _I, _L, _L, _I, _I, _F, _P]),
     "nmv_greedy_sample_scratch_bytes": (_L, [_I]),
     "nmv_greedy_sample_advance": (_I, [_P, _P, _L, _I, _I, _I, _P, _L, _P, _P, _P, _P, _P, _I, _I, _P]),
     "nmv_rms_norm_dynamic_int8_quant": (_I, [_P, _P, _P, _P, _P, _F, _I, _I, _I, _P]),

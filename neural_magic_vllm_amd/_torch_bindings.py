@@ -80,6 +80,41 @@ def paged_attention_v2(out, exp_sums, max_logits, tmp_out, query, key_cache, val
             dtype_code(query.dtype), kv_dtype_code(kv_cache_dtype), kv_scale, stream_of(query)))
 
 
+def paged_attention_rope_partial(out, slab, positions, cos_sin_cache, slot_mapping, key_cache, value_cache,
+                                 num_heads, num_kv_heads, head_size, scale, block_tables, seq_lens,
+                                 block_size, max_seq_len, kv_cache_dtype, kv_scale, partition_bufs=None) -> None:
+    """rotary_embedding + reshape_and_cache + paged_attention_v1 / v2 in one launch, from the qkv
+    projection's fp32 split-K slabs (include/nmvllm_hip.h: nmv_paged_attention_v*_rope_partial);
+    partition_bufs = (exp_sums, max_logits, tmp_out) selects v2"""
+    _req(slab.dim() == 3 and slab.dtype == torch.float32 and slab.is_contiguous(), "pa_rope_partial: slab [S, B, N] fp32")
+    s_, b, n = slab.shape
+    _req(n == (num_heads + 2 * num_kv_heads) * head_size, "pa_rope_partial: slab width != qkv width")
+    _req(out.shape == (b, num_heads, head_size) and out.is_contiguous(), "pa_rope_partial: out [B, H, D]")
+    _req(positions.dtype == torch.int64 and slot_mapping.dtype == torch.int64
+         and positions.numel() == b and slot_mapping.numel() == b, "pa_rope_partial: int64 [B] positions / slots")
+    _req(cos_sin_cache.dtype == out.dtype and cos_sin_cache.shape[1] == head_size and cos_sin_cache.is_contiguous(),
+         "pa_rope_partial: cos_sin_cache [max_pos, head_size] in the model dtype (rot_dim == head_size)")
+    _req(block_tables.dtype == torch.int32 and seq_lens.dtype == torch.int32, "block_tables / seq_lens must be int32")
+    _req(key_cache.is_contiguous() and value_cache.is_contiguous(), "caches must be contiguous")
+    L = _lib.load()
+    with device_guard(slab):
+        if partition_bufs is None:
+            check(L.nmv_paged_attention_v1_rope_partial(
+                ptr(out), ptr(slab), s_, ptr(positions), ptr(cos_sin_cache), ptr(slot_mapping), ptr(key_cache),
+                ptr(value_cache), b, num_heads, head_size, num_kv_heads, scale, ptr(block_tables),
+                ptr(seq_lens), block_size, max_seq_len, block_tables.shape[1], key_cache.stride(0),
+                key_cache.stride(1), dtype_code(out.dtype), kv_dtype_code(kv_cache_dtype), kv_scale,
+                stream_of(slab)))
+        else:
+            exp_sums, max_logits, tmp_out = partition_bufs
+            check(L.nmv_paged_attention_v2_rope_partial(
+                ptr(out), ptr(exp_sums), ptr(max_logits), ptr(tmp_out), ptr(slab), s_, ptr(positions),
+                ptr(cos_sin_cache), ptr(slot_mapping), ptr(key_cache), ptr(value_cache), b, num_heads,
+                head_size, num_kv_heads, scale, ptr(block_tables), ptr(seq_lens), block_size, max_seq_len,
+                block_tables.shape[1], key_cache.stride(0), key_cache.stride(1), dtype_code(out.dtype),
+                kv_dtype_code(kv_cache_dtype), kv_scale, stream_of(slab)))
+
+
 # ----------------------------------------------------------------------------- glue
 def _rows(t: torch.Tensor) -> int:
     return t.numel() // t.shape[-1] if t.numel() else 0

@@ -143,6 +143,28 @@ class ROCmHipAttentionImpl(AttentionImpl):
                                        kv_scale)
         return True
 
+    def decode_rope_partial(self, positions: torch.Tensor, slab: torch.Tensor, rotary_emb,
+                            kv_cache: Optional[torch.Tensor], attn_metadata: ROCmHipAttentionMetadata,
+                            kv_scale: float, dtype: torch.dtype) -> Optional[torch.Tensor]:
+        """decode-only batch, qkv still as the projection's split-K slabs: rope + cache write + paged
+        attention in ONE launch (PagedAttention.forward_decode_rope_partial).  Returns [T, hidden] or
+        None when the fused form does not apply (then rope_and_cache_partial + forward)."""
+        dm = attn_metadata.decode_metadata
+        if kv_cache is None or dm is None or attn_metadata.prefill_metadata is not None \
+                or attn_metadata.num_prefill_tokens != 0 or self.alibi_slopes is not None \
+                or not rotary_emb.is_neox_style or rotary_emb.rotary_dim != self.head_size \
+                or dtype not in (torch.float16, torch.bfloat16) or slab.shape[1] != attn_metadata.num_decode_tokens:
+            return None
+        cos_sin = rotary_emb.cos_sin_cache
+        if cos_sin.device != slab.device or cos_sin.dtype != dtype:
+            cos_sin = rotary_emb.cos_sin_cache = cos_sin.to(slab.device, dtype=dtype)
+        key_cache, value_cache = PagedAttention.split_kv_cache(kv_cache, self.num_kv_heads, self.head_size)
+        out = PagedAttention.forward_decode_rope_partial(
+            slab, positions, cos_sin, attn_metadata.slot_mapping.flatten(), key_cache, value_cache,
+            dm.block_tables, dm.seq_lens_tensor, dm.max_decode_seq_len, self.kv_cache_dtype, self.num_heads,
+            self.num_kv_heads, self.head_size, self.scale, kv_scale, dtype)
+        return out.view(out.shape[0], self.num_heads * self.head_size)
+
     def rope_and_cache_partial(self, positions: torch.Tensor, slab: torch.Tensor, rotary_emb,
                                kv_cache: Optional[torch.Tensor],
                                attn_metadata: ROCmHipAttentionMetadata, kv_scale: float,

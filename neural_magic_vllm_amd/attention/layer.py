@@ -69,6 +69,15 @@ class Attention(nn.Module):
             return None
         return fused(positions, slab, rotary_emb, kv_cache, attn_metadata, self._kv_scale, dtype)
 
+    def decode_rope_partial(self, positions: torch.Tensor, slab: torch.Tensor, rotary_emb,
+                            kv_cache: Optional[torch.Tensor], attn_metadata: AttentionMetadata,
+                            dtype: torch.dtype) -> Optional[torch.Tensor]:
+        """rope + cache write + decode attention in one launch, from the qkv projection's slabs"""
+        fused = getattr(self.impl, "decode_rope_partial", None)
+        if fused is None:
+            return None
+        return fused(positions, slab, rotary_emb, kv_cache, attn_metadata, self._kv_scale, dtype)
+
     def extra_repr(self) -> str:
         return (f"head_size={self.impl.head_size}, num_heads={self.impl.num_heads}, "
                 f"num_kv_heads={self.impl.num_kv_heads}, scale={self.impl.scale}, "

@@ -89,6 +89,29 @@ class PagedAttention:
         return output
 
     @staticmethod
+    def forward_decode_rope_partial(slab: torch.Tensor, positions: torch.Tensor, cos_sin_cache: torch.Tensor,
+                                    slot_mapping: torch.Tensor, key_cache: torch.Tensor,
+                                    value_cache: torch.Tensor, block_tables: torch.Tensor,
+                                    seq_lens: torch.Tensor, max_seq_len: int, kv_cache_dtype: str,
+                                    num_heads: int, num_kv_heads: int, head_size: int, scale: float,
+                                    kv_scale: float, dtype: torch.dtype) -> torch.Tensor:
+        """forward_decode whose query and new key / value are still the qkv projection's split-K slabs:
+        rope + cache write + attention in one launch (not in the reference)"""
+        num_seqs = slab.shape[1]
+        output = torch.empty((num_seqs, num_heads, head_size), dtype=dtype, device=slab.device)
+        block_size = value_cache.shape[3]
+        bufs = None
+        if not PagedAttention.use_v1(max_seq_len, num_seqs, num_heads):
+            parts = (max_seq_len + _PARTITION_SIZE - 1) // _PARTITION_SIZE
+            exp_sums = torch.empty((num_seqs, num_heads, parts), dtype=torch.float32, device=slab.device)
+            bufs = (exp_sums, torch.empty_like(exp_sums),
+                    torch.empty((num_seqs, num_heads, parts, head_size), dtype=dtype, device=slab.device))
+        ops.paged_attention_rope_partial(output, slab, positions, cos_sin_cache, slot_mapping, key_cache,
+                                         value_cache, num_heads, num_kv_heads, head_size, scale, block_tables,
+                                         seq_lens, block_size, max_seq_len, kv_cache_dtype, kv_scale, bufs)
+        return output
+
+    @staticmethod
     def forward_prefix(query: torch.Tensor, key: torch.Tensor, value: torch.Tensor,
                        key_cache: torch.Tensor, value_cache: torch.Tensor,
                        block_tables: torch.Tensor, query_start_loc: torch.Tensor,

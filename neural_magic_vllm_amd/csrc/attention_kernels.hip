@@ -26,6 +26,7 @@
 // There is no logits[max_seq_len] buffer, so v1 has no LDS-imposed context limit.
 // HBM-bound by construction: algorithmic bytes = 2 * L * D * sizeof(cache_t) per (seq, kv head).
 #include "common.h"
+#include "cache_write.h"
 
 namespace nmv {
 
@@ -64,6 +65,24 @@ __device__ __forceinline__ void fp8x4_to_pairs(uint32_t w, uint32_t& p0, uint32_
   p1 = T::pack2(b.x, b.y);
 }
 
+// Fused decode prologue (nmv_paged_attention_*_rope_partial; not in the reference): the qkv
+// projection's output is still its fp32 split-K slabs [splits][num_seqs][row_elems].  The workgroup
+// sums and rounds the query heads of its group and this kv head's new key / value (what the GEMM
+// would have stored), applies neox rotary embedding to q and k exactly as rotary_embedding does,
+// keeps q in LDS, and -- if the new token falls into this workgroup's token range -- stores k / v
+// into the paged cache before it walks the cache (its own stores are visible to it after the
+// barrier; workgroups that share the kv head store identical bytes).  One launch less per layer
+// than rope + cache write followed by attention.  slab == nullptr: the plain kernel.
+struct PAFused {
+  const float* slab;
+  int splits;
+  int64_t slab_stride;          // elements between slabs = num_seqs * row_elems
+  int row_elems;                // (num_heads + 2 num_kv_heads) * head_size
+  const int64_t* positions;     // [num_seqs] position of the new token (= seq_len - 1)
+  const uint16_t* cos_sin;      // [max_pos, head_size] model dtype: cos | sin
+  const int64_t* slot_mapping;  // [num_seqs] cache slot of the new token (< 0: padding)
+};
+
 // NW waves per workgroup: 4 when the grid fills the chip, 8 when it does not (few sequences):
 // the same KV run is then split over twice the waves and the per-wave chain of dependent windows
 // halves (B=1, L=530: 14.7 -> 10.9 us; at B=64 the 4-wave form is 15 % faster).
@@ -73,11 +92,13 @@ __global__ __launch_bounds__(NW * WAVE) void paged_attention_kernel(
     float* __restrict__ max_logits,  // same
     uint16_t* __restrict__ out,      // [num_seqs, num_heads, (max_num_partitions,) head_size]
     const uint16_t* __restrict__ q,  // [num_seqs, num_heads, head_size], row stride q_stride
-    const uint8_t* __restrict__ k_cache, const uint8_t* __restrict__ v_cache, int num_heads,
+    const uint8_t* k_cache, const uint8_t* v_cache,  // no restrict: the fused prologue stores the new token
+    int num_heads,
     int num_kv_heads, float scale, const int* __restrict__ block_tables,
     const int* __restrict__ seq_lens, int max_num_blocks_per_seq,
     const float* __restrict__ alibi_slopes, int64_t q_stride, int64_t kv_block_stride,
-    int64_t kv_head_stride, float kv_scale, int partition_size /* 0 = not partitioned */) {
+    int64_t kv_head_stride, float kv_scale, int partition_size /* 0 = not partitioned */,
+    const PAFused f) {
   using G = PAGeom<HEAD_SIZE, BLOCK_SIZE, HG, FP8>;
   const int seq_idx = blockIdx.y;
   const int part_idx = blockIdx.z;
@@ -101,10 +122,82 @@ __global__ __launch_bounds__(NW * WAVE) void paged_attention_kernel(
   __shared__ float out_red[NW][HG][HEAD_SIZE];
 
   // ---- queries of the head group -> LDS (HG*HEAD_SIZE contiguous elements) ----
-  {
+  if (f.slab == nullptr) {
     const uint32_t* q_ptr =
         reinterpret_cast<const uint32_t*>(q + (int64_t)seq_idx * q_stride + (int64_t)head0 * HEAD_SIZE);
     for (int i = threadIdx.x; i < HG * HEAD_SIZE / 2; i += (NW * WAVE)) q_s[i] = q_ptr[i];
+  } else {
+    constexpr int EMBED = HEAD_SIZE / 2, QUADS = EMBED / 4;
+    const int64_t pos = f.positions[seq_idx];
+    const int64_t slot = f.slot_mapping[seq_idx];
+    // the new token is cached by the workgroup(s) whose token range holds it
+    const bool cached = slot >= 0 && pos >= start_tok && pos < end_tok;
+    const int64_t blk_idx = cached ? slot / BLOCK_SIZE : 0, blk_off = cached ? slot % BLOCK_SIZE : 0;
+    const float* row = f.slab + (int64_t)seq_idx * f.row_elems;
+    const uint16_t* cos_ptr = f.cos_sin + pos * HEAD_SIZE;
+    const uint16_t* sin_ptr = cos_ptr + EMBED;
+    auto slab_sum4 = [&](int col, float (&o)[4]) {
+      f32x4_t acc4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+      for (int sp = 0; sp < f.splits; ++sp)
+        acc4 += *reinterpret_cast<const f32x4_t*>(row + sp * f.slab_stride + col);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o[i] = round_trip<T>(acc4[i]);  // the GEMM's output rounding
+    };
+    constexpr int N_Q = HG * QUADS, N_K = QUADS, N_V = HEAD_SIZE / 4;
+    for (int it = threadIdx.x; it < N_Q + N_K + N_V; it += (NW * WAVE)) {
+      if (it < N_Q + N_K) {
+        const bool is_k = it >= N_Q;
+        const int h = is_k ? 0 : it / QUADS;
+        const int d0 = ((is_k ? it - N_Q : it) % QUADS) * 4;
+        const int col = (is_k ? num_heads + kv_head : head0 + h) * HEAD_SIZE + d0;
+        float x[4], y[4];
+        slab_sum4(col, x);
+        slab_sum4(col + EMBED, y);
+        const uint2 cw = *reinterpret_cast<const uint2*>(cos_ptr + d0);
+        const uint2 sw = *reinterpret_cast<const uint2*>(sin_ptr + d0);
+        const uint32_t cs[2] = {cw.x, cw.y}, sn[2] = {sw.x, sw.y};
+        uint16_t xo[4], yo[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float c = (i & 1) ? hi_f<T>(cs[i >> 1]) : lo_f<T>(cs[i >> 1]);
+          const float sv = (i & 1) ? hi_f<T>(sn[i >> 1]) : lo_f<T>(sn[i >> 1]);
+          // pos_encoding_kernels.cu:10-37 with every product rounded to the model dtype
+          xo[i] = T::from_float(round_trip<T>(x[i] * c) - round_trip<T>(y[i] * sv));
+          yo[i] = T::from_float(round_trip<T>(y[i] * c) + round_trip<T>(x[i] * sv));
+        }
+        if (!is_k) {
+          uint32_t* qx = q_s + (h * HEAD_SIZE + d0) / 2;
+          qx[0] = xo[0] | ((uint32_t)xo[1] << 16);
+          qx[1] = xo[2] | ((uint32_t)xo[3] << 16);
+          qx[EMBED / 2] = yo[0] | ((uint32_t)yo[1] << 16);
+          qx[EMBED / 2 + 1] = yo[2] | ((uint32_t)yo[3] << 16);
+        } else if (cached) {
+          const int64_t hb = blk_idx * num_kv_heads + kv_head;
+          void* kc = const_cast<uint8_t*>(k_cache);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            cache_store_k<T, FP8>(kc, hb, HEAD_SIZE, BLOCK_SIZE, blk_off, d0 + i, xo[i], kv_scale);
+            cache_store_k<T, FP8>(kc, hb, HEAD_SIZE, BLOCK_SIZE, blk_off, d0 + EMBED + i, yo[i], kv_scale);
+          }
+        }
+      } else {
+        const int e0 = (it - N_Q - N_K) * 4;
+        float v[4];
+        slab_sum4((num_heads + num_kv_heads + kv_head) * HEAD_SIZE + e0, v);
+        if (cached) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int64_t tgt = ((blk_idx * num_kv_heads + kv_head) * HEAD_SIZE + e0 + i) * BLOCK_SIZE + blk_off;
+            const uint16_t vb = T::from_float(v[i]);
+            if constexpr (!FP8)
+              reinterpret_cast<uint16_t*>(const_cast<uint8_t*>(v_cache))[tgt] = vb;
+            else
+              const_cast<uint8_t*>(v_cache)[tgt] = f32_to_fp8(T::to_float(vb) / kv_scale);
+          }
+        }
+      }
+    }
   }
   __syncthreads();
 
@@ -415,6 +508,7 @@ struct PAArgs {
   int block_size, max_seq_len, max_num_blocks_per_seq;
   const float* alibi_slopes; int64_t q_stride, kv_block_stride, kv_head_stride;
   float kv_scale; bool partitioned; hipStream_t stream;
+  PAFused fused = {nullptr, 0, 0, 0, nullptr, nullptr, nullptr};
 };
 
 template <typename T, bool FP8, int HEAD_SIZE, int BLOCK_SIZE, int HG>
@@ -430,7 +524,7 @@ static void launch_pa(const PAArgs& a) {
                      (const uint8_t*)a.key_cache, (const uint8_t*)a.value_cache, a.num_heads,      \
                      a.num_kv_heads, a.scale, a.block_tables, a.seq_lens,                          \
                      a.max_num_blocks_per_seq, a.alibi_slopes, a.q_stride, a.kv_block_stride,      \
-                     a.kv_head_stride, a.kv_scale, a.partitioned ? PA_PARTITION : 0)
+                     a.kv_head_stride, a.kv_scale, a.partitioned ? PA_PARTITION : 0, a.fused)
   if (wide) NMV_PA_LAUNCH(8); else NMV_PA_LAUNCH(4);
 #undef NMV_PA_LAUNCH
   if (a.partitioned) {
@@ -552,5 +646,52 @@ extern "C" int nmv_paged_attention_v2(void* out, float* exp_sums, float* max_log
            max_seq_len, max_num_blocks_per_seq, alibi_slopes, q_stride, kv_block_stride,
            kv_head_stride, kv_scale, true, (hipStream_t)stream};
   return pa_entry(a, dtype, kv_dtype, "paged_attention_v2");
+}
+
+/* paged attention whose query -- and the new token's key / value -- are still the fp32 split-K slabs
+ * of the qkv projection (nmv_gptq_marlin_gemm_partial): sum + round, neox rotary embedding
+ * (rot_dim == head_size, cos_sin_cache [max_pos, head_size]), k / v of the new token stored at
+ * slot_mapping[seq] of the paged cache, then the v1 / v2 kernel -- rotary_embedding +
+ * reshape_and_cache + paged_attention in one launch, bit-identical to them. */
+static int pa_rope_partial(PAArgs& a, const float* slab, int splits, const int64_t* positions,
+                           const void* cos_sin_cache, const int64_t* slot_mapping, nmv_dtype_t dtype,
+                           nmv_kv_dtype_t kv_dtype, const char* name) {
+  NMV_CHECK(slab != nullptr && splits >= 1 && positions && cos_sin_cache && slot_mapping,
+            "%s: null fused-prologue argument", name);
+  NMV_CHECK(a.alibi_slopes == nullptr, "%s: ALiBi models do not use rotary embedding", name);
+  a.fused = PAFused{slab, splits, (int64_t)a.num_seqs * (a.num_heads + 2 * a.num_kv_heads) * a.head_size,
+                    (a.num_heads + 2 * a.num_kv_heads) * a.head_size, positions,
+                    (const uint16_t*)cos_sin_cache, slot_mapping};
+  return pa_entry(a, dtype, kv_dtype, name);
+}
+
+extern "C" int nmv_paged_attention_v1_rope_partial(
+    void* out, const float* slab, int splits, const int64_t* positions, const void* cos_sin_cache,
+    const int64_t* slot_mapping, void* key_cache, void* value_cache, int num_seqs, int num_heads,
+    int head_size, int num_kv_heads, float scale, const int32_t* block_tables, const int32_t* seq_lens,
+    int block_size, int max_seq_len, int max_num_blocks_per_seq, int64_t kv_block_stride,
+    int64_t kv_head_stride, nmv_dtype_t dtype, nmv_kv_dtype_t kv_dtype, float kv_scale, void* stream) {
+  PAArgs a{nullptr, nullptr, out, nullptr, nullptr, key_cache, value_cache, num_seqs, num_heads,
+           head_size, num_kv_heads, scale, block_tables, seq_lens, block_size, max_seq_len,
+           max_num_blocks_per_seq, nullptr, 0, kv_block_stride, kv_head_stride, kv_scale, false,
+           (hipStream_t)stream};
+  return pa_rope_partial(a, slab, splits, positions, cos_sin_cache, slot_mapping, dtype, kv_dtype,
+                         "paged_attention_v1_rope_partial");
+}
+
+extern "C" int nmv_paged_attention_v2_rope_partial(
+    void* out, float* exp_sums, float* max_logits, void* tmp_out, const float* slab, int splits,
+    const int64_t* positions, const void* cos_sin_cache, const int64_t* slot_mapping, void* key_cache,
+    void* value_cache, int num_seqs, int num_heads, int head_size, int num_kv_heads, float scale,
+    const int32_t* block_tables, const int32_t* seq_lens, int block_size, int max_seq_len,
+    int max_num_blocks_per_seq, int64_t kv_block_stride, int64_t kv_head_stride, nmv_dtype_t dtype,
+    nmv_kv_dtype_t kv_dtype, float kv_scale, void* stream) {
+  NMV_CHECK(exp_sums && max_logits && tmp_out, "paged_attention_v2: null partition buffers");
+  PAArgs a{exp_sums, max_logits, out, tmp_out, nullptr, key_cache, value_cache, num_seqs, num_heads,
+           head_size, num_kv_heads, scale, block_tables, seq_lens, block_size, max_seq_len,
+           max_num_blocks_per_seq, nullptr, 0, kv_block_stride, kv_head_stride, kv_scale, true,
+           (hipStream_t)stream};
+  return pa_rope_partial(a, slab, splits, positions, cos_sin_cache, slot_mapping, dtype, kv_dtype,
+                         "paged_attention_v2_rope_partial");
 }
 #endif

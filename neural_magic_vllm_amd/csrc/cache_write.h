@@ -73,4 +73,18 @@ __device__ __forceinline__ void write_token_to_cache(const uint16_t* __restrict_
   }
 }
 
+// one element of a token's key into the paged K cache ([block][head][d / x][offset][x]); the fused
+// rope + cache kernels store the rounded bits they have just produced
+template <typename T, bool FP8>
+__device__ __forceinline__ void cache_store_k(void* key_cache, int64_t head_base /*(block*heads+head)*/,
+                                              int head_size, int block_size, int64_t block_offset,
+                                              int d, uint16_t bits, float kv_scale) {
+  constexpr int X = FP8 ? 16 : 8;
+  const int64_t tgt = ((head_base * (head_size / X) + d / X) * block_size + block_offset) * X + d % X;
+  if constexpr (FP8)
+    reinterpret_cast<uint8_t*>(key_cache)[tgt] = f32_to_fp8(T::to_float(bits) / kv_scale);
+  else
+    reinterpret_cast<uint16_t*>(key_cache)[tgt] = bits;
+}
+
 }  // namespace nmv

@@ -86,6 +86,16 @@ __device__ __forceinline__ float hi_f(uint32_t pair) {
   return T::to_float((uint16_t)(pair >> 16));
 }
 
+// float -> model dtype -> float with the rounded bits passed through an empty asm, so that the
+// rounding is materialised even when the value never reaches memory (hipcc was seen to drop the
+// float -> _Float16 -> float round trip otherwise; glue_kernels.hip has the story)
+template <typename T>
+__device__ __forceinline__ float round_trip(float f) {
+  uint32_t b = T::from_float(f);
+  asm volatile("" : "+v"(b));
+  return T::to_float((uint16_t)b);
+}
+
 // ---- OCP fp8 e4m3fn (gfx950 native) -----------------------------------------------
 // two fp8 bytes (selected 16-bit half of `w`) -> two floats
 template <bool HI>

@@ -6,6 +6,7 @@
 // and the reference's intermediate roundings to the model dtype are reproduced exactly
 // (e.g. rms_norm rounds x*rsqrt(var) to the model dtype BEFORE multiplying by the weight).
 #include "common.h"
+#include "cache_write.h"
 
 // The reference rounds every intermediate to the model dtype (c10::Half / c10::BFloat16
 // operators).  With contraction on, hipcc folds the fp16 paths into v_fma_f16 and skips one of
@@ -321,18 +322,6 @@ __global__ void rotary_embedding_kernel(const int64_t* __restrict__ positions,
 // that rotates a key pair also stores the two rotated elements (the rounded bits it writes back to
 // `key`) at their place in the paged cache, so there is no barrier and no second read: one
 // load -> rotate -> store chain per lane, as in rotary_embedding alone.
-template <typename T, bool FP8>
-__device__ __forceinline__ void cache_store_k(void* key_cache, int64_t head_base /*(block*heads+head)*/,
-                                              int head_size, int block_size, int64_t block_offset,
-                                              int d, uint16_t bits, float kv_scale) {
-  constexpr int X = FP8 ? 16 : 8;
-  const int64_t tgt = ((head_base * (head_size / X) + d / X) * block_size + block_offset) * X + d % X;
-  if constexpr (FP8)
-    reinterpret_cast<uint8_t*>(key_cache)[tgt] = f32_to_fp8(T::to_float(bits) / kv_scale);
-  else
-    reinterpret_cast<uint16_t*>(key_cache)[tgt] = bits;
-}
-
 template <typename T, bool IS_NEOX, bool FP8>
 __global__ void rope_and_cache_kernel(const int64_t* __restrict__ positions, uint16_t* query,
                                       uint16_t* key, const uint16_t* value,

@@ -92,14 +92,6 @@ template <> struct W4<F16> {
 };
 constexpr float W4_ZP = 24.0f;  // (16 + q) - 24 = q - 8
 
-// float -> model dtype -> float; the bits pass through an empty asm so that the rounding is
-// materialised even when the value never reaches memory (see glue_kernels.hip: pin())
-template <typename T>
-__device__ __forceinline__ float round_trip(float f) {
-  uint32_t b = T::from_float(f);
-  asm volatile("" : "+v"(b));
-  return T::to_float((uint16_t)b);
-}
 
 struct GemmParams {
   const uint16_t* a;      // [M, K]

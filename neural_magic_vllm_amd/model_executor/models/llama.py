@@ -136,6 +136,11 @@ class LlamaAttention(nn.Module):
             # deferred split-K: the rope + cache launch sums the qkv projection's fp32 slabs
             slab = self.qkv_proj.forward_partial(hidden_states)
             if slab is not None:
+                # decode-only batch: rope + cache write + paged attention in one launch
+                attn_output = self.attn.decode_rope_partial(positions, slab, self.rotary_emb, kv_cache,
+                                                            attn_metadata, hidden_states.dtype)
+                if attn_output is not None:
+                    return self._o(attn_output)
                 qkv = self.attn.rope_and_cache_partial(positions, slab, self.rotary_emb, kv_cache,
                                                        attn_metadata, hidden_states.dtype)
         if qkv is not None:

@@ -179,3 +179,60 @@ def test_unsupported_configs_raise(gpu_device):
     with pytest.raises(RuntimeError, match="head size"):
         ops.paged_attention_v1(torch.empty_like(q72), q72, kc, vc, 4, 0.1, bt, sl, 16, 20, None,
                                "auto", 1.0)
+
+
+@pytest.mark.parametrize("heads,kv_heads,head_size", [(32, 8, 128), (8, 8, 64), (16, 2, 128), (4, 1, 128)])
+@pytest.mark.parametrize("kv_cache_dtype", ["auto", "fp8"])
+@pytest.mark.parametrize("dtype", [torch.half, torch.bfloat16])
+@pytest.mark.parametrize("num_seqs,max_ctx", [(5, 530), (3, 1300), (64, 40)])
+def test_paged_attention_rope_partial_matches_separate_launches(gpu_device, heads, kv_heads, head_size,
+                                                                kv_cache_dtype, dtype, num_seqs, max_ctx):
+    """rope + cache write + paged attention (v1 and v2) in one launch, from fp32 split-K slabs of the qkv
+    projection, against rotary_embedding_and_cache_partial + PagedAttention.forward_decode: attention
+    output and both caches, bit for bit"""
+    from neural_magic_vllm_amd import _custom_ops as ops
+    from neural_magic_vllm_amd.attention.ops.paged_attn import PagedAttention
+    d = gpu_device
+    g = torch.Generator().manual_seed(11)
+    n = (heads + 2 * kv_heads) * head_size
+    block_size, max_pos = 16, 4096
+    # positions: new token index per sequence (context = pos tokens already cached), incl. pos = 0
+    pos = torch.randint(1, max_ctx, (num_seqs, ), generator=g)
+    pos[0] = 0
+    pos[-1] = max_ctx - 1
+    seq_lens = (pos + 1).to(torch.int32)
+    blocks_per_seq = (max_ctx + block_size - 1) // block_size
+    num_blocks = num_seqs * blocks_per_seq + 3
+    bt = torch.randperm(num_blocks, generator=g)[:num_seqs * blocks_per_seq].view(num_seqs, blocks_per_seq).to(torch.int32)
+    slots = torch.tensor([int(bt[i, int(pos[i]) // block_size]) * block_size + int(pos[i]) % block_size
+                          for i in range(num_seqs)])
+    slab = (torch.randn((3, num_seqs, n), generator=g) * 0.5).to(d)          # three "splits"
+    cos_sin = torch.randn((max_pos, head_size), generator=g).to(dtype).to(d)
+    cdt = torch.uint8 if kv_cache_dtype == "fp8" else dtype
+    x = 16 // torch.tensor([], dtype=cdt).element_size()
+    kv_scale = 0.5 if kv_cache_dtype == "fp8" else 1.0
+    scale = head_size**-0.5
+
+    def caches():
+        gen = torch.Generator().manual_seed(1)
+        if kv_cache_dtype == "fp8":
+            kc = torch.randint(0, 120, (num_blocks, kv_heads, head_size // x, block_size, x), generator=gen, dtype=torch.uint8)
+            vc = torch.randint(0, 120, (num_blocks, kv_heads, head_size, block_size), generator=gen, dtype=torch.uint8)
+        else:
+            kc = (torch.rand((num_blocks, kv_heads, head_size // x, block_size, x), generator=gen) - 0.5).to(dtype)
+            vc = (torch.rand((num_blocks, kv_heads, head_size, block_size), generator=gen) - 0.5).to(dtype)
+        return kc.to(d), vc.to(d)
+
+    pos_d, slots_d, bt_d, sl_d = pos.to(d), slots.to(d), bt.to(d), seq_lens.to(d)
+    ref_kc, ref_vc = caches()
+    qkv = ops.rotary_embedding_and_cache_partial(pos_d, slab, heads, kv_heads, head_size, cos_sin, ref_kc, ref_vc,
+                                                 slots_d, kv_cache_dtype, kv_scale, dtype)
+    q = qkv[:, :heads * head_size].reshape(num_seqs, heads, head_size)
+    ref = PagedAttention.forward_decode(q, ref_kc, ref_vc, bt_d, sl_d, max_ctx, kv_cache_dtype, kv_heads, scale,
+                                        None, kv_scale)
+    kc, vc = caches()
+    got = PagedAttention.forward_decode_rope_partial(slab, pos_d, cos_sin, slots_d, kc, vc, bt_d, sl_d, max_ctx,
+                                                     kv_cache_dtype, heads, kv_heads, head_size, scale, kv_scale, dtype)
+    assert torch.equal(kc.view(torch.uint8), ref_kc.view(torch.uint8))
+    assert torch.equal(vc.view(torch.uint8), ref_vc.view(torch.uint8))
+    assert torch.equal(got.view(torch.int16), ref.view(torch.int16))
