@@ -192,8 +192,9 @@ int nmv_rotary_embedding_and_cache_partial(const int64_t* positions, const float
  * qkv projection (slab [splits, num_seqs, (heads + 2 kv_heads) * head_size]): sum + round, neox
  * rotary embedding (rot_dim == head_size), the new token's k / v stored at slot_mapping[seq], then
  * attention over the cache -- rotary_embedding + reshape_and_cache + paged_attention in one launch,
- * bit-identical to them.  Decode batches only (one new token per sequence, positions[seq] ==
- * seq_lens[seq] - 1); no ALiBi. */
+ * bit-identical to them.  splits == 0: `slab` is instead the finished, contiguous qkv row in the
+ * model dtype (W8A8 / unquantised projections).  Decode batches only (one new token per sequence,
+ * positions[seq] == seq_lens[seq] - 1); no ALiBi. */
 int nmv_paged_attention_v1_rope_partial(
     void* out, const float* slab, int splits, const int64_t* positions, const void* cos_sin_cache,
     const int64_t* slot_mapping, void* key_cache, void* value_cache, int num_seqs, int num_heads,

@@ -86,8 +86,13 @@ def paged_attention_rope_partial(out, slab, positions, cos_sin_cache, slot_mappi
     """rotary_embedding + reshape_and_cache + paged_attention_v1 / v2 in one launch, from the qkv
     projection's fp32 split-K slabs (include/nmvllm_hip.h: nmv_paged_attention_v*_rope_partial);
     partition_bufs = (exp_sums, max_logits, tmp_out) selects v2"""
-    _req(slab.dim() == 3 and slab.dtype == torch.float32 and slab.is_contiguous(), "pa_rope_partial: slab [S, B, N] fp32")
-    s_, b, n = slab.shape
+    if slab.dtype == torch.float32:
+        _req(slab.dim() == 3 and slab.is_contiguous(), "pa_rope_partial: slab [S, B, N] fp32")
+        s_, b, n = slab.shape
+    else:  # the finished qkv row in the model dtype
+        _req(slab.dim() == 2 and slab.is_contiguous() and slab.dtype == out.dtype,
+             "pa_rope_partial: qkv [B, N] contiguous in the model dtype")
+        s_, (b, n) = 0, slab.shape
     _req(n == (num_heads + 2 * num_kv_heads) * head_size, "pa_rope_partial: slab width != qkv width")
     _req(out.shape == (b, num_heads, head_size) and out.is_contiguous(), "pa_rope_partial: out [B, H, D]")
     _req(positions.dtype == torch.int64 and slot_mapping.dtype == torch.int64

@@ -146,14 +146,15 @@ class ROCmHipAttentionImpl(AttentionImpl):
     def decode_rope_partial(self, positions: torch.Tensor, slab: torch.Tensor, rotary_emb,
                             kv_cache: Optional[torch.Tensor], attn_metadata: ROCmHipAttentionMetadata,
                             kv_scale: float, dtype: torch.dtype) -> Optional[torch.Tensor]:
-        """decode-only batch, qkv still as the projection's split-K slabs: rope + cache write + paged
-        attention in ONE launch (PagedAttention.forward_decode_rope_partial).  Returns [T, hidden] or
+        """decode-only batch, qkv as the projection's split-K slabs [S, T, N] (fp32) or as the finished
+        row [T, N] in the model dtype: rope + cache write + paged attention in ONE launch (PagedAttention.forward_decode_rope_partial).  Returns [T, hidden] or
         None when the fused form does not apply (then rope_and_cache_partial + forward)."""
         dm = attn_metadata.decode_metadata
         if kv_cache is None or dm is None or attn_metadata.prefill_metadata is not None \
                 or attn_metadata.num_prefill_tokens != 0 or self.alibi_slopes is not None \
                 or not rotary_emb.is_neox_style or rotary_emb.rotary_dim != self.head_size \
-                or dtype not in (torch.float16, torch.bfloat16) or slab.shape[1] != attn_metadata.num_decode_tokens:
+                or dtype not in (torch.float16, torch.bfloat16) or slab.shape[-2] != attn_metadata.num_decode_tokens \
+                or not slab.is_contiguous():
             return None
         cos_sin = rotary_emb.cos_sin_cache
         if cos_sin.device != slab.device or cos_sin.dtype != dtype:

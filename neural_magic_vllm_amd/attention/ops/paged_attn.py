@@ -97,7 +97,7 @@ class PagedAttention:
                                     kv_scale: float, dtype: torch.dtype) -> torch.Tensor:
         """forward_decode whose query and new key / value are still the qkv projection's split-K slabs:
         rope + cache write + attention in one launch (not in the reference)"""
-        num_seqs = slab.shape[1]
+        num_seqs = slab.shape[-2]   # slabs [S, B, N] fp32, or the finished qkv [B, N] in the model dtype
         output = torch.empty((num_seqs, num_heads, head_size), dtype=dtype, device=slab.device)
         block_size = value_cache.shape[3]
         bufs = None

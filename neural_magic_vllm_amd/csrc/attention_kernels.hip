@@ -72,9 +72,11 @@ __device__ __forceinline__ void fp8x4_to_pairs(uint32_t w, uint32_t& p0, uint32_
 // keeps q in LDS, and -- if the new token falls into this workgroup's token range -- stores k / v
 // into the paged cache before it walks the cache (its own stores are visible to it after the
 // barrier; workgroups that share the kv head store identical bytes).  One launch less per layer
-// than rope + cache write followed by attention.  slab == nullptr: the plain kernel.
+// than rope + cache write followed by attention.  The same prologue also accepts the finished qkv row
+// in the model dtype (W8A8 / unquantised projections).  slab == qkv == nullptr: the plain kernel.
 struct PAFused {
-  const float* slab;
+  const float* slab;            // fp32 split-K slabs of the qkv projection, or
+  const uint16_t* qkv;          // the finished qkv row [num_seqs, row_elems] in the model dtype (slab == nullptr)
   int splits;
   int64_t slab_stride;          // elements between slabs = num_seqs * row_elems
   int row_elems;                // (num_heads + 2 num_kv_heads) * head_size
@@ -122,7 +124,7 @@ __global__ __launch_bounds__(NW * WAVE) void paged_attention_kernel(
   __shared__ float out_red[NW][HG][HEAD_SIZE];
 
   // ---- queries of the head group -> LDS (HG*HEAD_SIZE contiguous elements) ----
-  if (f.slab == nullptr) {
+  if (f.slab == nullptr && f.qkv == nullptr) {
     const uint32_t* q_ptr =
         reinterpret_cast<const uint32_t*>(q + (int64_t)seq_idx * q_stride + (int64_t)head0 * HEAD_SIZE);
     for (int i = threadIdx.x; i < HG * HEAD_SIZE / 2; i += (NW * WAVE)) q_s[i] = q_ptr[i];
@@ -134,9 +136,15 @@ __global__ __launch_bounds__(NW * WAVE) void paged_attention_kernel(
     const bool cached = slot >= 0 && pos >= start_tok && pos < end_tok;
     const int64_t blk_idx = cached ? slot / BLOCK_SIZE : 0, blk_off = cached ? slot % BLOCK_SIZE : 0;
     const float* row = f.slab + (int64_t)seq_idx * f.row_elems;
+    const uint16_t* row16 = f.qkv + (int64_t)seq_idx * f.row_elems;
     const uint16_t* cos_ptr = f.cos_sin + pos * HEAD_SIZE;
     const uint16_t* sin_ptr = cos_ptr + EMBED;
     auto slab_sum4 = [&](int col, float (&o)[4]) {
+      if (f.slab == nullptr) {  // uniform: finished row in the model dtype
+        const uint2 w = *reinterpret_cast<const uint2*>(row16 + col);
+        o[0] = lo_f<T>(w.x), o[1] = hi_f<T>(w.x), o[2] = lo_f<T>(w.y), o[3] = hi_f<T>(w.y);
+        return;
+      }
       f32x4_t acc4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 4
       for (int sp = 0; sp < f.splits; ++sp)
@@ -508,7 +516,7 @@ struct PAArgs {
   int block_size, max_seq_len, max_num_blocks_per_seq;
   const float* alibi_slopes; int64_t q_stride, kv_block_stride, kv_head_stride;
   float kv_scale; bool partitioned; hipStream_t stream;
-  PAFused fused = {nullptr, 0, 0, 0, nullptr, nullptr, nullptr};
+  PAFused fused = {nullptr, nullptr, 0, 0, 0, nullptr, nullptr, nullptr};
 };
 
 template <typename T, bool FP8, int HEAD_SIZE, int BLOCK_SIZE, int HG>
@@ -649,17 +657,21 @@ extern "C" int nmv_paged_attention_v2(void* out, float* exp_sums, float* max_log
 }
 
 /* paged attention whose query -- and the new token's key / value -- are still the fp32 split-K slabs
- * of the qkv projection (nmv_gptq_marlin_gemm_partial): sum + round, neox rotary embedding
+ * of the qkv projection (nmv_gptq_marlin_gemm_partial), or with splits == 0 the finished qkv row
+ * [num_seqs, (heads + 2 kv_heads) * head_size] in the model dtype passed as `slab`: sum + round, neox rotary embedding
  * (rot_dim == head_size, cos_sin_cache [max_pos, head_size]), k / v of the new token stored at
  * slot_mapping[seq] of the paged cache, then the v1 / v2 kernel -- rotary_embedding +
  * reshape_and_cache + paged_attention in one launch, bit-identical to them. */
 static int pa_rope_partial(PAArgs& a, const float* slab, int splits, const int64_t* positions,
                            const void* cos_sin_cache, const int64_t* slot_mapping, nmv_dtype_t dtype,
                            nmv_kv_dtype_t kv_dtype, const char* name) {
-  NMV_CHECK(slab != nullptr && splits >= 1 && positions && cos_sin_cache && slot_mapping,
+  // splits == 0: `slab` is the finished qkv row in the model dtype, not fp32 slabs
+  NMV_CHECK(slab != nullptr && splits >= 0 && positions && cos_sin_cache && slot_mapping,
             "%s: null fused-prologue argument", name);
   NMV_CHECK(a.alibi_slopes == nullptr, "%s: ALiBi models do not use rotary embedding", name);
-  a.fused = PAFused{slab, splits, (int64_t)a.num_seqs * (a.num_heads + 2 * a.num_kv_heads) * a.head_size,
+  NMV_CHECK(((uintptr_t)slab & 15) == 0 && (a.head_size * (splits ? 4 : 2)) % 8 == 0, "%s: misaligned qkv", name);
+  a.fused = PAFused{splits ? slab : nullptr, splits ? nullptr : (const uint16_t*)slab, splits,
+                    (int64_t)a.num_seqs * (a.num_heads + 2 * a.num_kv_heads) * a.head_size,
                     (a.num_heads + 2 * a.num_kv_heads) * a.head_size, positions,
                     (const uint16_t*)cos_sin_cache, slot_mapping};
   return pa_entry(a, dtype, kv_dtype, name);

@@ -148,6 +148,12 @@ class LlamaAttention(nn.Module):
             attn_output = self.attn(q, k, v, kv_cache, attn_metadata, cache_written=True)
             return self._o(attn_output)
         qkv, _ = self.qkv_proj(hidden_states)
+        if self.fused_glue and qkv.is_cuda and qkv.dim() == 2:
+            # decode-only batch: rope + cache write + paged attention in one launch, from the finished row
+            attn_output = self.attn.decode_rope_partial(positions, qkv, self.rotary_emb, kv_cache,
+                                                        attn_metadata, qkv.dtype)
+            if attn_output is not None:
+                return self._o(attn_output)
         q, k, v = qkv.split([self.q_size, self.kv_size, self.kv_size], dim=-1)
         if self.fused_glue and q.is_cuda and self.attn.rope_and_cache(positions, q, k, v, self.rotary_emb,
                                                                       kv_cache, attn_metadata):

@@ -236,3 +236,19 @@ def test_paged_attention_rope_partial_matches_separate_launches(gpu_device, head
     assert torch.equal(kc.view(torch.uint8), ref_kc.view(torch.uint8))
     assert torch.equal(vc.view(torch.uint8), ref_vc.view(torch.uint8))
     assert torch.equal(got.view(torch.int16), ref.view(torch.int16))
+    # the same from the finished qkv row in the model dtype (W8A8 / unquantised projections)
+    row = slab.sum(0).to(dtype)        # any row will do: the reference below starts from the same bits
+    ref_kc2, ref_vc2 = caches()
+    rot = row.clone()
+    q2, k2, v2 = rot.split([heads * head_size, kv_heads * head_size, kv_heads * head_size], dim=-1)
+    ops.rotary_embedding_and_cache(pos_d, q2, k2, v2, head_size, cos_sin, True, ref_kc2, ref_vc2, slots_d,
+                                   kv_cache_dtype, kv_scale)
+    ref2 = PagedAttention.forward_decode(q2.reshape(num_seqs, heads, head_size), ref_kc2, ref_vc2, bt_d, sl_d,
+                                         max_ctx, kv_cache_dtype, kv_heads, scale, None, kv_scale)
+    kc2, vc2 = caches()
+    got2 = PagedAttention.forward_decode_rope_partial(row, pos_d, cos_sin, slots_d, kc2, vc2, bt_d, sl_d, max_ctx,
+                                                      kv_cache_dtype, heads, kv_heads, head_size, scale, kv_scale,
+                                                      dtype)
+    assert torch.equal(kc2.view(torch.uint8), ref_kc2.view(torch.uint8))
+    assert torch.equal(vc2.view(torch.uint8), ref_vc2.view(torch.uint8))
+    assert torch.equal(got2.view(torch.int16), ref2.view(torch.int16))
