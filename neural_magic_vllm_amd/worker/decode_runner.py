@@ -189,8 +189,14 @@ class DecodeRunner:
         """`batch` sequences that each already hold `context_len` tokens in the cache; block tables
         are a random permutation of the block ids."""
         bs = self.cache_config.block_size
+        # positions index the rotary cos/sin table: past max_position_embeddings the kernels would read
+        # beyond it (the reference's scheduler never lets a sequence grow that far, config.py max_model_len)
+        if context_len + max_new_tokens > self.arch.max_position_embeddings:
+            raise ValueError(f"context {context_len} + {max_new_tokens} new tokens exceeds the model's "
+                             f"max_position_embeddings = {self.arch.max_position_embeddings}")
         self.batch = batch
         self.max_seq_len = context_len + max_new_tokens
+        self._steps_left = max_new_tokens
         blocks_per_seq = (self.max_seq_len + bs - 1) // bs
         need = batch * blocks_per_seq
         if not self.kv_caches or self.num_blocks < need:
@@ -275,6 +281,11 @@ class DecodeRunner:
 
     @torch.inference_mode()
     def decode_step(self) -> torch.Tensor:
+        # the batch was set up with room for a fixed number of new tokens (block tables, rotary table):
+        # one step more would index past them on the device
+        self._steps_left -= 1
+        if self._steps_left < 0:
+            raise RuntimeError("decode_step: the batch has used up the max_new_tokens it was set up with")
         if self.graph is not None:
             self.graph.replay()
             return self._graph_out

@@ -177,3 +177,18 @@ def test_fused_glue_is_bit_identical(gpu_device, monkeypatch, quant, wide_mlp):
     assert torch.equal(outs[True][0], outs[False][0])
     for a, b in zip(outs[True][1], outs[False][1]):
         assert torch.equal(a.view(torch.int16), b.view(torch.int16))
+
+
+def test_runner_refuses_to_run_past_its_tables(gpu_device):
+    """positions index the rotary table and the block tables on the device: the runner must stop on the
+    host instead (a context beyond max_position_embeddings or a step beyond max_new_tokens would be an
+    out-of-bounds read in a kernel)"""
+    arch, _, runner = build(None, gpu_device)
+    with pytest.raises(ValueError, match="max_position_embeddings"):
+        runner.setup_batch(2, arch.max_position_embeddings - 2, 8)
+    runner.setup_batch(2, 20, 3)
+    runner.fill_context()
+    for _ in range(3):
+        runner.decode_step()
+    with pytest.raises(RuntimeError, match="max_new_tokens"):
+        runner.decode_step()
