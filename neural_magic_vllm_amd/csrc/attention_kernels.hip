@@ -600,6 +600,9 @@ static int pa_entry(PAArgs& a, nmv_dtype_t dtype, nmv_kv_dtype_t kv_dtype, const
   NMV_CHECK(a.block_size == 8 || a.block_size == 16 || a.block_size == 32,
             "%s: Unsupported block size: %d", name, a.block_size);
   NMV_CHECK(a.q_stride % 2 == 0, "%s: query row stride must be even", name);
+  NMV_CHECK((int64_t)a.max_num_blocks_per_seq * a.block_size >= a.max_seq_len,
+            "%s: block_tables hold %d blocks of %d tokens per sequence, max_seq_len is %d", name,
+            a.max_num_blocks_per_seq, a.block_size, a.max_seq_len);
   if (a.num_seqs == 0) return NMV_OK;
   int rc;
   switch (a.head_size) {
