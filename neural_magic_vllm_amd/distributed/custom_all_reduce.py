@@ -82,35 +82,43 @@ class CustomAllReduce:
         self._close()
 
     def _self_test(self) -> bool:
-        """bit-exact against the fp32 rank-order sum computed on the CPU, several sizes and rounds"""
-        try:
-            for rnd, numel in enumerate((8, 4096, 64 * 4096, 64 * 4096 + 8, 1 << 20)):
-                for dtype in (torch.bfloat16, torch.float16):
-                    g = torch.Generator().manual_seed(1000 * rnd + self.rank)
-                    x = torch.randn(numel, generator=g).to(dtype)
-                    parts: List = [None] * self.world
-                    dist.all_gather_object(parts, x, group=self.cpu_group)
+        """bit-exact against the fp32 rank-order sum computed on the CPU, several sizes and rounds.
+        Every rank walks the same sequence of CPU collectives whatever it finds (a rank that bailed
+        out early would pair its next collective with its peers' current one); a failure only clears
+        the flag that the caller then shares."""
+        good = True
+        for rnd, numel in enumerate((8, 4096, 64 * 4096, 64 * 4096 + 8, 1 << 20)):
+            for dtype in (torch.bfloat16, torch.float16):
+                g = torch.Generator().manual_seed(1000 * rnd + self.rank)
+                x = torch.randn(numel, generator=g).to(dtype)
+                parts: List = [None] * self.world
+                dist.all_gather_object(parts, x, group=self.cpu_group)
+                try:
                     ref = torch.zeros(numel, dtype=torch.float32)
                     for p in parts:
                         ref += p.float()
                     got = self.all_reduce(x.to(self.device))
                     torch.cuda.synchronize(self.device)
                     if not torch.equal(got.cpu().view(torch.int16), ref.to(dtype).view(torch.int16)):
-                        self.disabled_reason = f"self-test mismatch (numel={numel}, {dtype})"
-                        return False
+                        good = False
+                        self.disabled_reason = self.disabled_reason or f"self-test mismatch (numel={numel}, {dtype})"
+                except Exception as e:
+                    good = False
+                    self.disabled_reason = self.disabled_reason or f"self-test: {e}"
+        try:
             if not self._gather_ok():
-                self.disabled_reason = "self-test: all_gather mismatch"
-                return False
+                good = False
+                self.disabled_reason = self.disabled_reason or "self-test: all_gather mismatch"
             if not self._fused_ok():
-                self.disabled_reason = "self-test: fused all-reduce + norm mismatch"
-                return False
+                good = False
+                self.disabled_reason = self.disabled_reason or "self-test: fused all-reduce + norm mismatch"
             if _lib.load().nmv_ar_error(self.state):
-                self.disabled_reason = "self-test: a flag wait timed out"
-                return False
-            return True
+                good = False
+                self.disabled_reason = self.disabled_reason or "self-test: a flag wait timed out"
         except Exception as e:
-            self.disabled_reason = f"self-test: {e}"
-            return False
+            good = False
+            self.disabled_reason = self.disabled_reason or f"self-test: {e}"
+        return good
 
     # ------------------------------------------------------------------
     def should_use(self, t: torch.Tensor) -> bool:
@@ -172,6 +180,7 @@ class CustomAllReduce:
         """the slab-consuming and the norm-fusing variants against the (just verified) plain all-reduce
         followed by the stand-alone fused_add_rms_norm: bit for bit"""
         from .. import _custom_ops as ops
+        ok_all = True
         for rows, hidden in ((64, 4096), (3, 8192)):
             g = torch.Generator().manual_seed(99 + self.rank)
             x = torch.randn((rows, hidden), generator=g).to(torch.bfloat16).to(self.device)
@@ -180,17 +189,20 @@ class CustomAllReduce:
             w = (1 + 0.1 * torch.randn((hidden, ), generator=g2)).to(torch.bfloat16).to(self.device)
             ref = self.all_reduce(x)
             slabs = torch.stack([x.float() * 0.5, x.float() * 0.5])
+            good = True
             if not torch.equal(self.all_reduce_partial(slabs, torch.bfloat16), ref):
-                return False
+                good = False
             ref_res = res.clone()
             ops.fused_add_rms_norm(ref, ref_res, w, 1e-5)
-            for inp in (x, slabs):
+            for inp in (x, slabs):   # every rank issues every launch, whatever it has seen so far
                 got_res = res.clone()
                 got = self.all_reduce_add_rms_norm(inp, got_res, w, 1e-5)
                 if not (torch.equal(got, ref) and torch.equal(got_res, ref_res)):
-                    return False
+                    good = False
+            if not good:
+                ok_all = False
         torch.cuda.synchronize(self.device)
-        return True
+        return ok_all
 
 
 def maybe_create(cpu_group, rank_in_group: int, world_size: int, device: torch.device,
