@@ -325,6 +325,10 @@ extern "C" int nmv_ar_open(void* state, const void* handles) {
       hipIpcMemHandle_t h;
       std::memcpy(&h, (const uint8_t*)handles + (size_t)q * sizeof(h), sizeof(h));
       AR_HIP(hipIpcOpenMemHandle(&st->peer_base[q], h, hipIpcMemLazyEnablePeerAccess));
+      // touch the mapping through the runtime first: a copy that cannot reach the peer's memory
+      // returns an error here instead of a fault inside the first kernel
+      uint32_t probe[16];
+      AR_HIP(hipMemcpy(probe, st->peer_base[q], sizeof(probe), hipMemcpyDeviceToHost));
     }
     st->peers.comm[q] = (ArComm*)st->peer_base[q];
     st->peers.data[q] = (uint8_t*)st->peer_base[q] + sizeof(ArComm);

@@ -43,7 +43,7 @@ class CustomAllReduce:
         except Exception as e:  # allocation / IPC export refused
             ok, self.disabled_reason = False, f"create: {e}"
         gathered: List = [None] * world_size
-        dist.all_gather_object(gathered, (ok, handle, socket.gethostname()), group=cpu_group)
+        dist.all_gather_object(gathered, (ok, handle, socket.gethostname(), device.index), group=cpu_group)
         if not all(g[0] for g in gathered):
             self.disabled_reason = self.disabled_reason or "a peer could not create its buffer"
             return self._close()
@@ -51,6 +51,12 @@ class CustomAllReduce:
             self.disabled_reason = "ranks on different hosts"
             return self._close()
         try:
+            # the kernels read the peers' buffers directly: refuse unless the runtime reports peer access
+            # for every other device (ranks that share one device -- the rehearsal -- need none)
+            for g in gathered:
+                if g[3] is not None and device.index is not None and g[3] != device.index \
+                        and not torch.cuda.can_device_access_peer(device.index, g[3]):
+                    raise RuntimeError(f"device {device.index} cannot access peer device {g[3]}")
             with torch.cuda.device(device):
                 check(lib.nmv_ar_open(self.state, b"".join(g[1] for g in gathered)))
         except Exception as e:
