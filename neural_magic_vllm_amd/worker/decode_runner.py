@@ -296,6 +296,11 @@ class DecodeRunner:
         """capture one decode step into a hipGraph; returns False (and stays eager) on failure"""
         saved = [t.clone() for t in (self.input_ids, self.positions, self.seq_lens, self.slot_mapping)]
         prev_stream = torch.cuda.current_stream(self.device)
+        if self.tp_size > 1:
+            # the ranks enter the warm-up steps together: the P2P collectives wait for their peers
+            # with a bounded spin, and ranks may have taken different times to build their weights
+            torch.cuda.synchronize(self.device)
+            get_tp_group().barrier()
         try:
             s = torch.cuda.Stream(device=self.device)
             s.wait_stream(prev_stream)
