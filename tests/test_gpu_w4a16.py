@@ -278,7 +278,8 @@ def test_gemm_silu_mul_epilogue_matches_separate_ops(gpu_device, monkeypatch, m,
 
 
 @pytest.mark.parametrize("m", [1, 5, 16, 64, 200])
-@pytest.mark.parametrize("k,n", [(4096, 4096), (14336, 4096), (512, 512), (1024, 8192)])
+@pytest.mark.parametrize("k,n", [(4096, 4096), (14336, 4096), (512, 512), (1024, 8192),
+                                 (512, 4096), (1792, 4096)])   # the last two: o / down of Llama-3-8B at TP = 8
 @pytest.mark.parametrize("dtype", [torch.half, torch.bfloat16])
 def test_deferred_split_k_matches_gemm_then_norm(gpu_device, m, k, n, dtype):
     """gptq_marlin_gemm_partial (fp32 slabs, no ticket / last-arriver pass) + fused_add_rms_norm_partial
@@ -308,12 +309,13 @@ def test_deferred_split_k_matches_gemm_then_norm(gpu_device, m, k, n, dtype):
 @pytest.mark.parametrize("m", [1, 19, 64])
 @pytest.mark.parametrize("kv_cache_dtype", ["auto", "fp8"])
 @pytest.mark.parametrize("dtype", [torch.half, torch.bfloat16])
-def test_deferred_split_k_qkv_rope_cache(gpu_device, m, kv_cache_dtype, dtype):
+@pytest.mark.parametrize("heads,kv_heads", [(8, 2), (4, 1)])   # (4, 1): the TP = 8 shard of Llama-3-8B
+def test_deferred_split_k_qkv_rope_cache(gpu_device, m, kv_cache_dtype, dtype, heads, kv_heads):
     """qkv projection as fp32 slabs + rotary_embedding_and_cache_partial against gptq_marlin_gemm +
     rotary_embedding_and_cache: rotated qkv row and both caches, bit for bit"""
     from neural_magic_vllm_amd import _custom_ops as ops
     d = gpu_device
-    heads, kv_heads, hs, k = 8, 2, 128, 1024
+    hs, k = 128, 1024
     n = (heads + 2 * kv_heads) * hs
     pr = helpers.make_w4a16_problem(9, m, k, n, 4, 128, False, dtype)
     a, mq, ms = pr["a"].to(d), pr["marlin_q_w"].to(d), pr["marlin_s"].to(d)
