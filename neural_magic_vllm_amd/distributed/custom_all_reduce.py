@@ -221,4 +221,8 @@ def maybe_create(cpu_group, rank_in_group: int, world_size: int, device: torch.d
     if backend != "nccl" and mode != "force":
         return None
     car = CustomAllReduce(cpu_group, rank_in_group, world_size, device)
+    if not car.enabled and rank_in_group == 0:
+        import sys
+        print(f"[custom_all_reduce] not used ({car.disabled_reason}); collectives stay on the process group",
+              file=sys.stderr)
     return car if car.enabled else None

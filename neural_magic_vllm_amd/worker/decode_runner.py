@@ -16,6 +16,7 @@ There is no scheduler, block manager, tokenizer or checkpoint loader: those sit 
 drop-in boundary and stay the reference's own.
 """
 import os
+import sys
 import time
 from dataclasses import dataclass
 from typing import List, Optional
@@ -317,7 +318,9 @@ class DecodeRunner:
             self.graph, self._graph_out = graph, out
             ok = True
         except Exception as e:  # pragma: no cover - depends on the runtime
-            print(f"[decode_runner] hipGraph capture failed, staying eager: {str(e).splitlines()[0]}")
+            # stderr: bench.py's stdout carries exactly one JSON line
+            print(f"[decode_runner] hipGraph capture failed, staying eager: {str(e).splitlines()[0]}",
+                  file=sys.stderr)
             self.graph = None
             ok = False
             # torch.cuda.graph.__exit__ raises from capture_end() before it restores the stream, so
