@@ -279,6 +279,12 @@ def main():
                    "global_batch": args.batch, "context_len": args.context,
                    "parallelism": f"tp{world}", "hip_graph": graphed},
     }
+    if world > 1:
+        # which path carries the row-parallel all-reduces: the one-shot P2P kernel over HIP IPC (after its
+        # start-up self-test on these devices) or the process group (RCCL)
+        car = nd.get_tp_group().custom_ar
+        out["config"]["all_reduce"] = "p2p one-shot over HIP IPC (fused with residual-add + RMSNorm)" \
+            if car is not None else f"process group ({backend})"
     if rank == 0:
         wb = runner.weight_bytes_per_step()
         kv_elem = 1 if args.kv_cache_dtype.startswith("fp8") else 2
