@@ -133,9 +133,28 @@ def synthetic_llama_weights(arch: LlamaArch, dtype: torch.dtype, device, quant: 
 class DecodeRunner:
     """One model replica (or TP shard) + its KV cache + a captured decode step."""
 
+    @classmethod
+    def from_pretrained(cls, model_dir: str, device: torch.device, dtype: Optional[torch.dtype] = None,
+                        cache_config: Optional[CacheConfig] = None) -> "DecodeRunner":
+        """a runner on a local HF-layout Llama checkpoint: config.json -> architecture, the checkpoint's
+        quantisation config -> the reference's method (GPTQ -> gptq_marlin when the Marlin kernels can run
+        it), *.safetensors shards -> LlamaForCausalLM.load_weights (model_executor/model_loader.py)"""
+        from ..model_executor import model_loader as ml
+        cfg = ml.read_hf_config(model_dir)
+        arch = LlamaArch(cfg["hidden_size"], cfg["intermediate_size"], cfg["num_hidden_layers"],
+                         cfg["num_attention_heads"], cfg.get("num_key_value_heads", cfg["num_attention_heads"]),
+                         cfg["vocab_size"], cfg.get("rms_norm_eps", 1e-5), cfg.get("rope_theta", 10000.0),
+                         cfg.get("max_position_embeddings", 8192), cfg.get("hidden_act", "silu"),
+                         cfg.get("rope_scaling"))
+        if dtype is None:
+            dtype = {"bfloat16": torch.bfloat16, "float16": torch.float16}.get(str(cfg.get("torch_dtype")),
+                                                                               torch.bfloat16)
+        return cls(arch, device, dtype, None, cache_config, weights=ml.safetensors_weights_iterator(model_dir),
+                   quant_config=ml.build_quant_config(model_dir, cfg))
+
     def __init__(self, arch: LlamaArch, device: torch.device, dtype: torch.dtype = torch.bfloat16,
                  quant: Optional[dict] = None, cache_config: Optional[CacheConfig] = None,
-                 seed: int = 0, weights=None):
+                 seed: int = 0, weights=None, quant_config=None):
         self.arch = arch
         self.device = device
         self.dtype = dtype
@@ -143,8 +162,9 @@ class DecodeRunner:
         self.tp_size = get_tensor_model_parallel_world_size()
         self.fused_step_tail = os.environ.get("NMV_FUSED_GLUE", "1") != "0"
         self.tp_rank = get_tensor_model_parallel_rank()
-        quant_config = None
-        if quant is not None and quant.get("method") == "w8a8":
+        if quant_config is not None:
+            pass  # the checkpoint's own QuantizationConfig (from_pretrained)
+        elif quant is not None and quant.get("method") == "w8a8":
             # BASELINE.json configs[3]: int8 weights (per channel) x int8 activations (dynamic per token)
             quant_config = get_quantization_config("compressed-tensors").from_config({
                 "config_groups": {"group_0": {

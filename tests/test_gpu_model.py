@@ -192,3 +192,36 @@ def test_runner_refuses_to_run_past_its_tables(gpu_device):
         runner.decode_step()
     with pytest.raises(RuntimeError, match="max_new_tokens"):
         runner.decode_step()
+
+
+@pytest.mark.parametrize("quant", [dict(method="gptq_marlin", bits=4, group_size=128), None], ids=["gptq", "bf16"])
+def test_from_pretrained_safetensors_round_trip(gpu_device, tmp_path, quant):
+    """an HF-layout checkpoint on disk (two safetensors shards, config.json, AutoGPTQ's quantize_config.json)
+    through DecodeRunner.from_pretrained decodes the same tokens as the same tensors handed over directly"""
+    import json
+    from safetensors.torch import save_file
+    from neural_magic_vllm_amd.worker import decode_runner as dr
+    arch, weights, runner = build(quant, gpu_device)
+    names = list(weights)
+    half = len(names) // 2
+    save_file({n: weights[n].contiguous() for n in names[:half]}, str(tmp_path / "model-00001-of-00002.safetensors"))
+    save_file({n: weights[n].contiguous() for n in names[half:]}, str(tmp_path / "model-00002-of-00002.safetensors"))
+    (tmp_path / "config.json").write_text(json.dumps(dict(
+        architectures=["LlamaForCausalLM"], hidden_size=arch.hidden_size, intermediate_size=arch.intermediate_size,
+        num_hidden_layers=arch.num_hidden_layers, num_attention_heads=arch.num_attention_heads,
+        num_key_value_heads=arch.num_key_value_heads, vocab_size=arch.vocab_size, rms_norm_eps=arch.rms_norm_eps,
+        rope_theta=arch.rope_theta, max_position_embeddings=arch.max_position_embeddings, hidden_act="silu",
+        torch_dtype="bfloat16")))
+    if quant is not None:
+        (tmp_path / "quantize_config.json").write_text(json.dumps(dict(
+            bits=4, group_size=128, desc_act=False, sym=True, damp_percent=0.01, true_sequential=True)))
+    loaded = dr.DecodeRunner.from_pretrained(str(tmp_path), gpu_device, cache_config=dr.CacheConfig(16, "auto"))
+    if quant is not None:
+        from neural_magic_vllm_amd.model_executor.layers.quantization.gptq_marlin import GPTQMarlinConfig
+        assert isinstance(loaded.model.model.layers[0].self_attn.qkv_proj.quant_method.quant_config, GPTQMarlinConfig)
+    outs = []
+    for r in (runner, loaded):
+        r.setup_batch(3, 30, 8)
+        r.fill_context()
+        outs.append(torch.stack([r.decode_step().clone() for _ in range(4)]).cpu())
+    assert torch.equal(outs[0], outs[1])

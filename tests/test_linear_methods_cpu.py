@@ -69,3 +69,32 @@ def test_paged_attention_v1_v2_heuristic():
     for (msl, ns, nh), exp in cases.items():
         assert PagedAttention.use_v1(msl, ns, nh) == exp, (msl, ns, nh)
     assert PagedAttention.get_kv_cache_shape(10, 16, 8, 128) == (2, 10, 16 * 8 * 128)
+
+
+def test_checkpoint_iterator_and_quant_config(tmp_path):
+    """model_loader: every tensor of every safetensors shard comes back under its name; the quantisation
+    config is config.json's `quantization_config` when present, else quantize_config.json
+    (weight_utils.py get_quant_config)"""
+    import json
+
+    import torch
+    from safetensors.torch import save_file
+    from neural_magic_vllm_amd.model_executor import model_loader as ml
+    a = {"model.layers.0.self_attn.q_proj.qweight": torch.arange(12, dtype=torch.int32).view(3, 4),
+         "model.norm.weight": torch.ones(8, dtype=torch.bfloat16)}
+    b = {"lm_head.weight": torch.randn(4, 8).to(torch.bfloat16)}
+    save_file(a, str(tmp_path / "model-00001-of-00002.safetensors"))
+    save_file(b, str(tmp_path / "model-00002-of-00002.safetensors"))
+    got = dict(ml.safetensors_weights_iterator(str(tmp_path)))
+    assert set(got) == set(a) | set(b)
+    for k, v in {**a, **b}.items():
+        assert torch.equal(got[k], v) and got[k].dtype == v.dtype
+    (tmp_path / "config.json").write_text(json.dumps(dict(hidden_size=8)))
+    cfg = ml.read_hf_config(str(tmp_path))
+    assert ml.read_quant_config(str(tmp_path), cfg) is None
+    (tmp_path / "quantize_config.json").write_text(json.dumps(dict(bits=4, group_size=128, desc_act=False, sym=True)))
+    assert ml.read_quant_config(str(tmp_path), cfg)["bits"] == 4
+    cfg["quantization_config"] = dict(quant_method="fp8", activation_scheme="dynamic")
+    assert ml.read_quant_config(str(tmp_path), cfg)["quant_method"] == "fp8"      # config.json wins
+    with __import__("pytest").raises(FileNotFoundError):
+        list(ml.safetensors_weights_iterator(str(tmp_path / "nowhere")))
