@@ -1,8 +1,10 @@
 """bench.py -- decode tokens/s of Llama-3-8B w4a16 (GPTQ g128, marlin format) on MI355X.
 
 Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched
-through torch.distributed.run with one rank per GPU (tensor parallel over RCCL/xGMI).  Rank 0
-prints ONE JSON line.  A "step" is one decode step of the whole model for a batch of B
+through torch.distributed.run with one rank per GPU (tensor parallel over RCCL/xGMI) -- and when it
+is started directly (`python bench.py --gpus N`, no WORLD_SIZE in the environment) it starts those N
+ranks itself, as a child `python -m torch.distributed.run`, before anything touches the GPU.  Every
+rank checks WORLD_SIZE == --gpus and exits non-zero otherwise.  Rank 0 prints ONE JSON line.  A "step" is one decode step of the whole model for a batch of B
 sequences (embedding, 32 decoder layers through the HIP kernels, bf16 lm_head, greedy sample),
 replayed from a captured hipGraph; inputs (weights, KV cache with `context` tokens per
 sequence) are resident in HBM before the timed region.
@@ -12,9 +14,14 @@ Extra objects on the line:
                   the 4 GEMMs of a layer / mean device time of those 4 launches, measured live with
                   HIP events around a hipGraph replay of the same kernels (no host launch cost).
   ttft_ms_p50  -- p50 wall time of one 512-token prompt step (BASELINE metric's second half).
-  cpu_baseline -- the oracle (oracle/oracle.c, OpenMP) on the host cores: one decoder layer's
-                  dequant+GEMMs and paged attention for the same batch, scaled to a full step.
+  cpu_baseline -- what the reference's CPU executor would run for the same step, timed on this host's
+                  cores: weights dequantised once to bf16 + F.linear (oneDNN) for the 4 GEMMs of a layer,
+                  and the reference's own CPU paged-attention kernel (oracle/_ref) or its restatement
+                  (oracle.c), on a bounded sample scaled to the whole step.
+A P2P all-reduce whose flag wait timed out (a lost peer) makes the run exit non-zero without a JSON line.
 """
+import subprocess
+import socket
 import argparse
 import json
 import os
@@ -33,7 +40,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--steps", type=int, default=256)
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--batch", type=int, default=int(os.environ.get("NMV_BENCH_BATCH", 64)))
     ap.add_argument("--context", type=int, default=512)
@@ -157,56 +164,142 @@ def ttft(runner, dev, prompt_len, runs=5):
     return round(ts[len(ts) // 2], 3)
 
 
+def usable_cores() -> int:
+    """CPU cores this process may actually use: the affinity mask, capped by the cgroup CPU quota (a GPU
+    box hands a container a share of a 256-thread host; os.cpu_count() still says 256, and an OpenMP pool of
+    that size on a 16-core quota runs ~20x slower than a pool of 16)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(arch, batch, context, budget_s=12.0):
-    """the CPU oracle on the host cores: decoder-layer samples (4 dequant+GEMMs at M=batch and paged
-    attention over `context` tokens), repeated until ~`budget_s` seconds of CPU work have been timed,
-    extrapolated to the whole step (layers x; lm_head and glue not included)."""
+    """The CPU path the reference would run for this step, on this host's cores: its CPU
+    executor has no quantised GEMM, so a quantised model means weights dequantised ONCE to bf16 and
+    F.linear (vllm/model_executor/layers/linear.py:103-136; oneDNN bf16) per projection, and its CPU
+    paged-attention kernel (csrc/cpu/attention.cpp, compiled from the reference's sources into oracle/_ref
+    when that build travelled here; else the restatement in oracle.c).  One decoder layer (4 GEMMs at
+    M = batch + attention over batch x context tokens) is sampled until ~budget_s seconds of CPU work
+    have been timed and scaled to the layer count; lm_head and glue are not included.  oracle.c's own
+    (clarity-first) dequant-GEMM is timed once and reported separately."""
     import helpers
     import oracle
     from oracle import ref_math
-    cores = os.cpu_count() or 1
-    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    import torch.nn.functional as F
+    cores = usable_cores()
+    os.environ["OMP_NUM_THREADS"] = str(cores)
+    torch.set_num_threads(cores)
     oracle.build()
+    try:  # the OpenMP pools of oracle.c / oracle/_ref (libgomp reads OMP_NUM_THREADS once, at load)
+        import ctypes
+        ctypes.CDLL("libgomp.so.1").omp_set_num_threads(cores)
+    except OSError:
+        pass
     h, inter, hd = arch.hidden_size, arch.intermediate_size, arch.head_dim
     nq, nkv = arch.num_attention_heads, arch.num_key_value_heads
     shapes = [(h, (nq + 2 * nkv) * hd), (nq * hd, h), (h, 2 * inter), (inter, h)]
     g = torch.Generator().manual_seed(0)
-    probs = []
+    dense, t_deq = [], 0.0
+    port_prob = None
     for k, n in shapes:
         q_w = torch.randint(0, 16, (k, n), generator=g, dtype=torch.int32)
-        mq = ref_math.marlin_weights(q_w, k, n, 4)
         s = (torch.rand((k // 128, n), generator=g) * 0.01 + 0.001).to(torch.bfloat16)
-        ms = ref_math.marlin_permute_scales(s, k, n, 128)
         a = torch.randn((batch, k), generator=g).to(torch.bfloat16)
-        probs.append((a, mq, ms, n, k))
+        t0 = time.perf_counter()
+        # (q - 8) * s per group of 128, rounded to bf16: quantize_weights' w_ref (quant_utils.py:84-92)
+        w = ((q_w - 8).to(torch.bfloat16).view(k // 128, 128, n) * s.view(k // 128, 1, n)).view(k, n)
+        w_nk = w.t().contiguous()          # nn.Linear layout [out, in]
+        t_deq += time.perf_counter() - t0
+        dense.append((a, w_nk))
+        if port_prob is None:
+            port_prob = (a, ref_math.marlin_weights(q_w, k, n, 4), ref_math.marlin_permute_scales(s, k, n, 128), n, k)
     nblk = batch * ((context + 15) // 16) + 8
     inp = helpers.make_paged_attention_inputs(0, batch, (nq, nkv), hd, 16, torch.bfloat16,
                                               seq_lens=[context] * batch, num_blocks=nblk)
+    attn_kind, attn = "port", None
+    try:
+        from oracle import build_ref
+        if build_ref.load_ref():
+            out = torch.empty_like(inp["query"])
+
+            def attn():
+                torch.ops._C_ref.paged_attention_v1(out, inp["query"], inp["key_cache"], inp["value_cache"], nkv,
+                                                    inp["scale"], inp["block_tables"], inp["seq_lens"], 16,
+                                                    inp["max_seq_len"], None, "auto", 1.0, 0, 0, 0, 64, 0)
+            attn()
+            attn_kind = "reference"
+    except Exception:
+        attn = None
+    if attn is None:
+        def attn():
+            oracle.paged_attention(inp["query"], inp["key_cache"], inp["value_cache"], nkv, inp["scale"],
+                                   inp["block_tables"], inp["seq_lens"], 16)
+    for a, w_nk in dense:   # warm-up: oneDNN primitive creation, thread pool
+        F.linear(a, w_nk)
     t_gemm = t_attn = 0.0
     layers = 0
-    while layers == 0 or (t_gemm + t_attn < budget_s and layers < 64):
-        for a, mq, ms, n, k in probs:
-            t0 = time.perf_counter()
-            oracle.gptq_marlin_gemm(a, mq, ms, None, None, 4, batch, n, k)
-            t_gemm += time.perf_counter() - t0
+    while layers == 0 or (t_gemm + t_attn < budget_s and layers < 256):
         t0 = time.perf_counter()
-        oracle.paged_attention(inp["query"], inp["key_cache"], inp["value_cache"], nkv, inp["scale"],
-                               inp["block_tables"], inp["seq_lens"], 16)
+        for a, w_nk in dense:
+            F.linear(a, w_nk)
+        t_gemm += time.perf_counter() - t0
+        t0 = time.perf_counter()
+        attn()
         t_attn += time.perf_counter() - t0
         layers += 1
     step_s = (t_gemm + t_attn) / layers * arch.num_hidden_layers
-    return {"value": round(batch / step_s, 3), "unit": "tokens/s", "cores": cores, "kind": "port",
-            "sample": (f"oracle.c (OpenMP, {cores} threads) timed on {layers} decoder-layer samples: 4 "
-                       f"dequant+GEMMs at M={batch} and paged attention over {context} tokens x {batch} "
-                       f"seqs ({t_gemm:.2f}s + {t_attn:.2f}s of CPU work), scaled to "
-                       f"{arch.num_hidden_layers} layers; lm_head and glue not included")}
+    # the restatement's own GEMM, for the record (one qkv projection)
+    a, mq, ms, n, k = port_prob
+    t0 = time.perf_counter()
+    oracle.gptq_marlin_gemm(a, mq, ms, None, None, 4, batch, n, k)
+    t_port = time.perf_counter() - t0
+    return {"value": round(batch / step_s, 3), "unit": "tokens/s", "cores": cores, "kind": attn_kind,
+            "sample": (f"{layers} decoder-layer samples on {cores} threads: F.linear bf16 (oneDNN) on weights "
+                       f"dequantised once (4 GEMMs at M={batch}: {t_gemm / layers * 1e3:.2f} ms/layer; the one-time "
+                       f"dequantisation of a layer took {t_deq:.2f} s, not counted) + "
+                       f"{'the reference csrc/cpu paged_attention_v1 (oracle/_ref)' if attn_kind == 'reference' else 'oracle.c paged attention'}"
+                       f" over {context} tokens x {batch} seqs ({t_attn / layers * 1e3:.2f} ms/layer); "
+                       f"{t_gemm + t_attn:.1f} s of CPU work, scaled to {arch.num_hidden_layers} layers; lm_head and "
+                       f"glue not included"),
+            "oracle_c_gemm": {"qkv_proj_ms": round(t_port * 1e3, 1),
+                              "note": "oracle.c's clarity-first dequant+GEMM (the parity checker), one call"}}
+
+
+def _free_port():
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch_ranks(args) -> int:
+    """`python bench.py --gpus N` started by hand: run the N ranks as a child torch.distributed.run (the
+    command the driver itself uses) -- nothing in this process has touched the GPU yet, and it never
+    will.  The ranks inherit stdout, so rank 0's JSON line is this command's JSON line."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args))
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+              f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...), "
+              f"or run `python bench.py --gpus {args.gpus}` without WORLD_SIZE set", file=sys.stderr)
+        sys.exit(2)
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     # rehearsal knobs (tests/test_gpu_tp.py): all ranks on one GPU with gloo collectives, to exercise
     # this script's N > 1 path on a 1-GPU box; the measured configuration is one rank per GPU + RCCL
@@ -231,33 +324,34 @@ def main():
     runner = dr.DecodeRunner(arch, dev, torch.bfloat16, quant,
                              dr.CacheConfig(16, args.kv_cache_dtype))
 
+    def max_over_ranks(x: float) -> float:
+        if world == 1:
+            return x
+        vals = [None] * world
+        dist.all_gather_object(vals, float(x), group=nd.get_tp_group().cpu_group)
+        return max(vals)
+
     def measure(batch, steps, warmup):
         runner.setup_batch(batch, args.context, steps + warmup + 8)
         runner.fill_context()
+        # capture() decides graph-or-eager for the whole group (a step that holds collectives of a
+        # non-capturable backend is never offered to the graph) and checks the P2P error word
         graphed = False if args.no_graph else runner.capture()
-        if world > 1:  # every rank replays a graph, or none does
-            ok = torch.tensor([1 if graphed else 0], device=dev, dtype=torch.int32)
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            if graphed and int(ok.item()) == 0:
-                runner.graph = None
-                graphed = False
         for _ in range(warmup):
             runner.decode_step()
         torch.cuda.synchronize(dev)
         if world > 1:
-            dist.barrier()
+            nd.get_tp_group().barrier()
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
         for _ in range(steps):
             runner.decode_step()
         torch.cuda.synchronize(dev)
         if world > 1:
-            dist.barrier()
-        dt = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([dt], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
+            nd.get_tp_group().barrier()
+        dt = max_over_ranks(time.perf_counter() - t0)
+        # a P2P all-reduce that gave up waiting for a peer wrote NaN: no number from such a run
+        runner.check_collectives()
         return dt, graphed
 
     dt, graphed = measure(args.batch, args.steps, args.warmup)
@@ -269,7 +363,8 @@ def main():
                    "w8a8": "decode tokens/sec, Llama-3-8B w8a8 (int8 per-channel x dynamic per-token int8)",
                    "bf16": "decode tokens/sec, Llama-3-8B bf16 (unquantised)"}[args.quant],
         "value": round(value, 1), "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "timed_region_s": round(dt, 4),
+        "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "int8" if args.quant == "w8a8" else "bf16",
         "data": {"w4a16": "synthetic (random-init N(0,0.02) weights quantised to int4 g128, random KV context)",
                  "w8a8": "synthetic (random-init N(0,0.02) weights quantised to int8 per channel, random KV context)",
@@ -279,12 +374,35 @@ def main():
                    "global_batch": args.batch, "context_len": args.context,
                    "parallelism": f"tp{world}", "hip_graph": graphed},
     }
+    if dt < 0.5 and not args.no_sweep:
+        # the contract times exactly --steps steps; when that region is short, a longer one is measured
+        # as well and reported beside it (it never replaces `value`)
+        long_steps = 256
+        d2, _ = measure(args.batch, long_steps, 4)
+        out["sustained"] = {"steps": long_steps, "timed_region_s": round(d2, 4),
+                            "value": round(args.batch * long_steps / d2, 1),
+                            "ms_per_step": round(d2 / long_steps * 1e3, 4)}
     if world > 1:
-        # which path carries the row-parallel all-reduces: the one-shot P2P kernel over HIP IPC (after its
+        # which path carries the row-parallel all-reduces: the P2P kernels over HIP IPC (after their
         # start-up self-test on these devices) or the process group (RCCL)
-        car = nd.get_tp_group().custom_ar
-        out["config"]["all_reduce"] = "p2p one-shot over HIP IPC (fused with residual-add + RMSNorm)" \
-            if car is not None else f"process group ({backend})"
+        tp = nd.get_tp_group()
+        car = tp.custom_ar
+        if car is not None:
+            msg = args.batch * arch.hidden_size * 2
+            out["config"]["all_reduce"] = (f"p2p {'two-shot' if car.is_two_shot(msg) else 'one-shot'} over HIP IPC, "
+                                           f"fused with residual-add + RMSNorm ({msg} B per call)")
+            if os.environ.get("NMV_BENCH_COMPARE_RCCL", "1") != "0" and not args.no_sweep:
+                # the same step with the P2P communicator switched off: every all-reduce / gather goes
+                # through the process group (RCCL) -- so that the scaling curve can be read for both
+                tp.custom_ar = None
+                try:
+                    d3, g3 = measure(args.batch, args.steps, args.warmup)
+                    out["process_group_path"] = {"backend": backend, "value": round(args.batch * args.steps / d3, 1),
+                                                 "ms_per_step": round(d3 / args.steps * 1e3, 4), "hip_graph": g3}
+                finally:
+                    tp.custom_ar = car
+        else:
+            out["config"]["all_reduce"] = f"process group ({backend})"
     if rank == 0:
         wb = runner.weight_bytes_per_step()
         kv_elem = 1 if args.kv_cache_dtype.startswith("fp8") else 2
@@ -308,7 +426,7 @@ def main():
         try:
             out["cpu_baseline"] = cpu_baseline(arch, args.batch, args.context)
         except Exception as e:  # the baseline must never take the GPU number down with it
-            out["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": os.cpu_count(),
+            out["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": usable_cores(),
                                    "kind": "port", "sample": f"failed: {e!r}"}
     if rank == 0:
         print(json.dumps(out), flush=True)

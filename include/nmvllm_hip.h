@@ -406,13 +406,17 @@ int64_t nmv_get_device_attribute(int64_t attribute, int64_t device_id);
 int64_t nmv_get_max_shared_memory_per_block_device_attribute(int64_t device_id);
 
 /* ------------------------------------------------------------------------------------------
- * One-shot P2P all-reduce over HIP IPC (the analogue of csrc/custom_all_reduce.cuh:130-250 /
- * the `_C_custom_ar` ops of torch_bindings.cpp:262-294, which the reference compiles out on ROCm).
- * nmv_ar_create allocates this rank's staging block on the current device and exports its IPC
- * handle (nmv_ar_handle_bytes() bytes); nmv_ar_open maps the peers' blocks (handles: world
- * handles in rank order); nmv_ar_all_reduce sums `numel` fp16 / bf16 elements (bytes % 16 == 0,
- * <= max_bytes) across the ranks in fp32, rank order, one kernel launch, capturable into a
- * hipGraph.  Flag waits are bounded: nmv_ar_error reports (after a device sync) whether one ran out.
+ * One-shot / two-shot P2P all-reduce over HIP IPC (the analogue of csrc/custom_all_reduce.cuh:130-250
+ * and its dispatch rule :442-451; the `_C_custom_ar` ops of torch_bindings.cpp:262-294 are bound on top of
+ * these entry points -- the reference compiles all of it out on ROCm).
+ * nmv_ar_create allocates this rank's block (flags + 2 staging + 2 reduced-slice buffers) on the current
+ * device and exports its IPC handle (nmv_ar_handle_bytes() bytes); nmv_ar_open maps the peers' blocks
+ * (handles: world handles in rank order); nmv_ar_all_reduce sums `numel` fp16 / bf16 elements (bytes % 16
+ * == 0, <= max_bytes) across the ranks in fp32, rank order, one kernel launch, capturable into a hipGraph:
+ * one-shot (every rank reads all W buffers) or, by the reference's size rule, two-shot (reduce-scatter into
+ * the owner's slice + all-gather) -- the same bits either way.  Flag waits are bounded: a call whose wait
+ * ran out writes NaN and sets the error word that nmv_ar_error reports (after a device sync); the
+ * communicator must not be used after that.
  * ------------------------------------------------------------------------------------------ */
 int nmv_ar_handle_bytes(void);
 int nmv_ar_create(void** state_out, int rank, int world, int64_t max_bytes, void* handle_out);
@@ -433,6 +437,11 @@ int nmv_ar_all_reduce_add_rms_norm(void* state, const void* inp, const float* sl
  * protocol (bytes_per_rank % 16 == 0, <= max_bytes) */
 int nmv_ar_all_gather(void* state, const void* inp, void* out, int64_t bytes_per_rank, void* stream);
 int nmv_ar_error(void* state);
+/* algo: 0 = size rule of custom_all_reduce.cuh:442-451, 1 = one-shot, 2 = two-shot (same on all ranks) */
+int nmv_ar_set_algo(void* state, int algo);
+int nmv_ar_is_two_shot(void* state, int64_t bytes);
+/* bound of a flag wait in milliseconds (default 2000) */
+int nmv_ar_set_timeout_ms(void* state, int64_t ms);
 int nmv_ar_destroy(void* state);
 
 #ifdef __cplusplus

@@ -70,6 +70,9 @@ SIGNATURES = {
     "nmv_ar_all_reduce_add_rms_norm": (_I, [_P, _P, _P, _I, _P, _P, _P, _F, _I, _I, _I, _P]),
     "nmv_ar_all_gather": (_I, [_P, _P, _P, _L, _P]),
     "nmv_ar_error": (_I, [_P]),
+    "nmv_ar_set_algo": (_I, [_P, _I]),
+    "nmv_ar_is_two_shot": (_I, [_P, _L]),
+    "nmv_ar_set_timeout_ms": (_I, [_P, _L]),
     "nmv_greedy_record_elems": (_I, [_I]),
     "nmv_greedy_sample_shard": (_I, [_P, _P, _L, _I, _I, _I, _I, _P, _L, _P]),
     "nmv_greedy_sample_finish": (_I, [_P, _P, _I, _I, _P, _P, _P, _P, _P, _I, _I, _P]),

@@ -1,8 +1,8 @@
-// One-shot P2P all-reduce over HIP IPC for the tensor-parallel decode step: the gfx950 analogue of
-// the reference's csrc/custom_all_reduce.cuh:130-250 (cross_device_reduce_1stage), which the
-// reference compiles out on ROCm (torch_bindings.cpp:261).  Decode all-reduces a [B, hidden]
-// activation (8 KB .. 1 MB) twice per layer; at that size a ring collective is pure latency, while
-// xGMI lets every GPU read every peer's buffer directly (7 links x ~150 GB/s per GPU).
+// One-shot and two-shot P2P all-reduce over HIP IPC for the tensor-parallel decode step: the gfx950
+// analogue of the reference's csrc/custom_all_reduce.cuh:130-250 (cross_device_reduce_1stage / _2stage,
+// dispatch rule :442-451), which the reference compiles out on ROCm (torch_bindings.cpp:261).  Decode
+// all-reduces a [B, hidden] activation (8 KB .. 1 MB) twice per layer; at that size a ring collective is
+// pure latency, while xGMI lets every GPU read every peer's buffer directly (7 links x ~150 GB/s per GPU).
 //
 // Protocol (all ranks launch the same grid; block b of every rank owns slice b of the message):
 //   1. block b copies slice b of its input into its rank's IPC-mapped staging buffer (two buffers,
@@ -10,17 +10,20 @@
 //      after every peer has passed the flag wait of call n+1, i.e. has finished reading call n);
 //   2. system-scope release, then lanes 0..W-1 store the block's call number into slot
 //      [b][my_rank] of every rank's flag array and spin (bounded) until slots [b][0..W-1] of the
-//      own array carry it;
-//   3. system-scope acquire; every lane sums slice b of all W staging buffers in rank order (the
-//      same order on every rank => bit-identical results everywhere, deterministic) in fp32 and
-//      writes the output.
+//      own array carry it; system-scope acquire;
+//   3. one-shot: every lane sums slice b of all W staging buffers in rank order (the same order on
+//      every rank => bit-identical results everywhere, deterministic) in fp32 and writes the output;
+//      two-shot: rank r sums only sub-slice r of slice b into its `tmp` buffer (reduce-scatter), the
+//      ranks meet a second time (flags[1]), then every rank copies the W reduced sub-slices
+//      (all-gather): each rank pulls 2 x the message over xGMI instead of W x.
 // Call numbers live in device memory and are advanced by the kernel itself, so a captured launch
-// can be replayed.  The spin is bounded in time (2 s): a lost peer sets an error word instead of
-// hanging the GPU.
+// can be replayed.  The spin is bounded in time (default 2 s): a lost peer sets an error word and the
+// call writes NaN -- it neither hangs the GPU nor returns a sum of stale buffers.
 // Staging and flags are allocated uncached / fine-grained when the runtime allows it.
 #include "common.h"
 
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 // the fused residual-add + RMSNorm below reproduces glue_kernels.hip's roundings: no contraction
@@ -38,50 +41,93 @@ constexpr int AR_THREADS = 512;
 constexpr uint64_t AR_SPIN_TICKS = 200ull * 1000 * 1000;  // s_memrealtime runs at 100 MHz: give up after 2 s
 
 struct ArComm {
-  uint32_t flags[AR_MAX_BLOCKS][AR_MAX_RANKS];  // [block][source rank] = call number
+  // [phase][block][source rank] = call number; phase 1 is the second rendezvous of the two-shot form
+  uint32_t flags[2][AR_MAX_BLOCKS][AR_MAX_RANKS];
   uint32_t seq[AR_MAX_BLOCKS];                  // this rank's call number per block
   uint32_t error;                               // set when a spin ran out
-  uint32_t pad[63];
+  uint32_t pad[47];
 };
+static_assert(sizeof(ArComm) % 256 == 0, "staging stays 256-byte aligned");
 
 struct ArPeers {
   ArComm* comm[AR_MAX_RANKS];
-  uint8_t* data[AR_MAX_RANKS];  // staging: 2 x max_bytes each
+  uint8_t* data[AR_MAX_RANKS];  // staging: 2 x max_bytes each (alternating per call)
+  uint8_t* tmp[AR_MAX_RANKS];   // two-shot: the owner's reduced slices, 2 x max_bytes each
 };
 
 struct ArState {
   int rank, world;
   int64_t max_bytes;
-  void* base;        // one allocation: ArComm + 2 staging buffers
+  void* base;        // one allocation: ArComm + 2 staging buffers + 2 reduced-slice buffers
   size_t alloc_bytes;
   hipIpcMemHandle_t handle;
   void* peer_base[AR_MAX_RANKS];
   ArPeers peers;
   bool opened;
+  int force_algo;        // 0 = the reference's size rule, 1 = one-shot, 2 = two-shot
+  uint64_t spin_ticks;   // bounded flag wait, in 10 ns ticks
 };
 
-// GATHER: same protocol, but slice b of every rank's buffer is copied to out[q * n_vec + slice]
-// instead of summed (all-gather of small per-rank records, e.g. the per-shard argmax of the sampler)
-template <typename T, bool GATHER = false>
-__global__ __launch_bounds__(AR_THREADS) void one_shot_all_reduce_kernel(ArPeers peers, int rank, int world,
-                                                                         const uint16_t* __restrict__ inp,
-                                                                         uint16_t* __restrict__ out,
-                                                                         int64_t n_vec /* 16-byte vectors */,
-                                                                         int64_t buf_bytes,
-                                                                         const float* __restrict__ slab = nullptr,
-                                                                         int splits = 0, int64_t slab_stride = 0) {
-  const int b = blockIdx.x;
-  ArComm* mine = peers.comm[rank];
-  const uint32_t seq = mine->seq[b] + 1;  // only this block touches seq[b]
-  const int64_t parity_off = (seq & 1) ? buf_bytes : 0;
-  const int64_t per = (n_vec + gridDim.x - 1) / gridDim.x;
-  const int64_t v0 = (int64_t)b * per, v1 = min(v0 + per, n_vec);
-  // 1. my slice -> my staging buffer
-  uint4* stage = reinterpret_cast<uint4*>(peers.data[rank] + parity_off);
-  const uint4* src = reinterpret_cast<const uint4*>(inp);
+// Rendezvous `phase` of call `seq` for block b: everything this block has stored so far becomes
+// visible system-wide, lanes 0..W-1 signal every rank and wait (bounded) for every rank.  Returns
+// false when a wait ran out: the error word is set and *dead (LDS, zeroed at kernel start) says so
+// to the whole block -- the caller then poisons its output instead of reducing stale buffers.
+__device__ __forceinline__ bool ar_rendezvous(const ArPeers& peers, ArComm* mine, int rank, int world, int b,
+                                              uint32_t seq, int phase, uint64_t spin_ticks, int* dead) {
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x < world) {
+    const int q = threadIdx.x;
+    __hip_atomic_store(&peers.comm[q]->flags[phase][b][rank], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+    while ((int32_t)(__hip_atomic_load(&mine->flags[phase][b][q], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - seq) < 0) {
+      if (__builtin_amdgcn_s_memrealtime() - t0 > spin_ticks) {
+        __hip_atomic_store(&mine->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        *dead = 1;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+  }
+  __syncthreads();
+  // system-scope acquire on every lane: drop whatever the caches hold of the peers' buffers
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+  return *dead == 0;
+}
+
+template <typename T>
+__device__ __forceinline__ uint4 ar_nan16() {  // eight quiet NaNs of the model dtype
+  const uint32_t n = std::is_same<T, F16>::value ? 0x7E007E00u : 0x7FC07FC0u;
+  return make_uint4(n, n, n, n);
+}
+
+// fp32 sum of vector v of every rank's staging buffer, rank order, rounded to the model dtype
+template <typename T>
+__device__ __forceinline__ uint4 ar_sum_vec(const ArPeers& peers, int world, int64_t parity_off, int64_t v) {
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int q = 0; q < world; ++q) {
+    const uint4 x = reinterpret_cast<const uint4*>(peers.data[q] + parity_off)[v];
+    const uint32_t xs[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      acc[2 * j] += lo_f<T>(xs[j]);
+      acc[2 * j + 1] += hi_f<T>(xs[j]);
+    }
+  }
+  uint4 o = make_uint4(T::pack2(acc[0], acc[1]), T::pack2(acc[2], acc[3]), T::pack2(acc[4], acc[5]),
+                       T::pack2(acc[6], acc[7]));
+  // the rounding must survive when the caller keeps computing on the value (glue_kernels.hip: pin())
+  asm volatile("" : "+v"(o.x), "+v"(o.y), "+v"(o.z), "+v"(o.w));
+  return o;
+}
+
+// this block's slice [v0, v1) of the local input -> this rank's staging buffer.  slab != null: the
+// input is still the fp32 split-K slabs of the row-parallel GEMM (nmv_gptq_marlin_gemm_partial), summed
+// in split order from +0 and rounded to the model dtype, as that GEMM's own last pass would
+template <typename T>
+__device__ __forceinline__ void ar_stage_slice(uint4* stage, const uint16_t* inp, const float* slab, int splits,
+                                               int64_t slab_stride, int64_t v0, int64_t v1) {
   if (slab != nullptr) {
-    // the input is still the fp32 split-K slabs of the row-parallel GEMM (nmv_gptq_marlin_gemm_partial):
-    // summed in split order from +0 and rounded to the model dtype, as that GEMM's own last pass would
     for (int64_t v = v0 + threadIdx.x; v < v1; v += AR_THREADS) {
       f32x4_t lo4 = {0.f, 0.f, 0.f, 0.f}, hi4 = {0.f, 0.f, 0.f, 0.f};
       for (int sp = 0; sp < splits; ++sp) {
@@ -92,60 +138,82 @@ __global__ __launch_bounds__(AR_THREADS) void one_shot_all_reduce_kernel(ArPeers
                             T::pack2(hi4[2], hi4[3]));
     }
   } else {
+    const uint4* src = reinterpret_cast<const uint4*>(inp);
     for (int64_t v = v0 + threadIdx.x; v < v1; v += AR_THREADS) stage[v] = src[v];
   }
-  __threadfence_system();
-  __syncthreads();
-  // 2. signal every rank (myself included), wait for every rank
-  if (threadIdx.x < world) {
-    const int q = threadIdx.x;
-    __hip_atomic_store(&peers.comm[q]->flags[b][rank], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
-    while ((int32_t)(__hip_atomic_load(&mine->flags[b][q], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - seq) < 0) {
-      if (__builtin_amdgcn_s_memrealtime() - t0 > AR_SPIN_TICKS) {
-        __hip_atomic_store(&mine->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        break;
-      }
-      __builtin_amdgcn_s_sleep(1);
-    }
-  }
-  __syncthreads();
-  // system-scope acquire on every lane: drop whatever the caches hold of the peers' buffers
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
-  // 3. sum slice b of every rank's buffer, rank order, fp32
+}
+
+// MODE 0: one-shot all-reduce (every rank sums slice b of all W staging buffers: W x message read per
+//         rank) -- the analogue of cross_device_reduce_1stage, custom_all_reduce.cuh:130-196.
+// MODE 1: all-gather: slice b of every rank's buffer is copied to out[q * n_vec + slice] (small per-rank
+//         records, e.g. the per-shard argmax of the sampler).
+// MODE 2: two-shot all-reduce (cross_device_reduce_2stage, :203-250): rank r sums only sub-slice r of
+//         slice b (reduce-scatter into its own `tmp` buffer), second rendezvous, every rank copies the
+//         W reduced sub-slices (all-gather): 2 x message read per rank instead of W x.  The owner sums in
+//         the same rank order and rounds once, so the result has the bits of the one-shot form.
+template <typename T, int MODE>
+__global__ __launch_bounds__(AR_THREADS) void p2p_all_reduce_kernel(ArPeers peers, int rank, int world,
+                                                                    const uint16_t* __restrict__ inp,
+                                                                    uint16_t* __restrict__ out,
+                                                                    int64_t n_vec /* 16-byte vectors */,
+                                                                    int64_t buf_bytes, uint64_t spin_ticks,
+                                                                    const float* __restrict__ slab = nullptr,
+                                                                    int splits = 0, int64_t slab_stride = 0) {
+  __shared__ int dead;
+  if (threadIdx.x == 0) dead = 0;
+  const int b = blockIdx.x;
+  ArComm* mine = peers.comm[rank];
+  const uint32_t seq = mine->seq[b] + 1;  // only this block touches seq[b]
+  const int64_t parity_off = (seq & 1) ? buf_bytes : 0;
+  const int64_t per = (n_vec + gridDim.x - 1) / gridDim.x;
+  const int64_t v0 = min((int64_t)b * per, n_vec), v1 = min(v0 + per, n_vec);
   uint4* dst = reinterpret_cast<uint4*>(out);
-  if constexpr (GATHER) {
-    for (int q = 0; q < world; ++q)
-      for (int64_t v = v0 + threadIdx.x; v < v1; v += AR_THREADS)
-        dst[q * n_vec + v] = reinterpret_cast<const uint4*>(peers.data[q] + parity_off)[v];
+  // 1. my slice -> my staging buffer
+  ar_stage_slice<T>(reinterpret_cast<uint4*>(peers.data[rank] + parity_off), inp, slab, splits, slab_stride, v0, v1);
+  // 2. signal every rank (myself included), wait for every rank
+  bool ok = ar_rendezvous(peers, mine, rank, world, b, seq, 0, spin_ticks, &dead);
+  if constexpr (MODE == 1) {
+    if (ok)
+      for (int q = 0; q < world; ++q)
+        for (int64_t v = v0 + threadIdx.x; v < v1; v += AR_THREADS)
+          dst[q * n_vec + v] = reinterpret_cast<const uint4*>(peers.data[q] + parity_off)[v];
+    else
+      for (int q = 0; q < world; ++q)
+        for (int64_t v = v0 + threadIdx.x; v < v1; v += AR_THREADS) dst[q * n_vec + v] = make_uint4(~0u, ~0u, ~0u, ~0u);
     if (threadIdx.x == 0) mine->seq[b] = seq;
     return;
   }
-  for (int64_t v = v0 + threadIdx.x; v < v1; v += AR_THREADS) {
-    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int q = 0; q < world; ++q) {
-      const uint4 x = reinterpret_cast<const uint4*>(peers.data[q] + parity_off)[v];
-      const uint32_t xs[4] = {x.x, x.y, x.z, x.w};
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        acc[2 * j] += lo_f<T>(xs[j]);
-        acc[2 * j + 1] += hi_f<T>(xs[j]);
-      }
+  if constexpr (MODE == 0) {
+    // 3. sum slice b of every rank's buffer, rank order, fp32
+    if (ok)
+      for (int64_t v = v0 + threadIdx.x; v < v1; v += AR_THREADS) dst[v] = ar_sum_vec<T>(peers, world, parity_off, v);
+  } else {
+    const int64_t sub = (v1 - v0 + world - 1) / world;
+    if (ok) {
+      // 3a. reduce-scatter: my sub-slice of slice b -> my tmp buffer
+      uint4* tmine = reinterpret_cast<uint4*>(peers.tmp[rank] + parity_off);
+      const int64_t s0 = min(v0 + rank * sub, v1), s1 = min(s0 + sub, v1);
+      for (int64_t v = s0 + threadIdx.x; v < s1; v += AR_THREADS) tmine[v] = ar_sum_vec<T>(peers, world, parity_off, v);
+      ok = ar_rendezvous(peers, mine, rank, world, b, seq, 1, spin_ticks, &dead);
     }
-    dst[v] = make_uint4(T::pack2(acc[0], acc[1]), T::pack2(acc[2], acc[3]), T::pack2(acc[4], acc[5]),
-                        T::pack2(acc[6], acc[7]));
+    if (ok)  // 3b. all-gather of the reduced sub-slices
+      for (int64_t v = v0 + threadIdx.x; v < v1; v += AR_THREADS)
+        dst[v] = reinterpret_cast<const uint4*>(peers.tmp[(v - v0) / sub] + parity_off)[v];
   }
+  if (!ok)  // a peer never arrived: NaN, not a sum of stale buffers
+    for (int64_t v = v0 + threadIdx.x; v < v1; v += AR_THREADS) dst[v] = ar_nan16<T>();
   if (threadIdx.x == 0) mine->seq[b] = seq;
 }
 
 // ---------------------------------------------------------------------------------------------
 // all-reduce + residual-add + RMSNorm in one launch (tensor-parallel decode: o_proj / down_proj
 // -> all-reduce -> fused_add_rms_norm is three launches per projection otherwise).  Same protocol;
-// the slices are whole rows (block b owns rows [b R, (b+1) R)), so after the handshake a block holds
+// the slices are whole rows (block b owns rows [b R, (b+1) R)), so after the rendezvous a block holds
 // complete reduced rows and can finish them: sum over ranks (fp32, rank order) rounded to the model
 // dtype = what nmv_ar_all_reduce writes; + residual, rounded, stored back; variance with the per-lane
 // accumulation order of rms_norm_reg_kernel's 256-lane form (replayed through LDS, as its wide form
-// does); x * rsqrt rounded, times weight.  Bit-identical to the three launches.
+// does); x * rsqrt rounded, times weight.  Bit-identical to the three launches.  TWO: the two-shot
+// form -- the block's rows are reduced sub-slice by sub-slice by their owner ranks first.
 template <typename T>
 __device__ __forceinline__ float ar_rnd(float f) {
   uint32_t b = T::from_float(f);
@@ -153,54 +221,36 @@ __device__ __forceinline__ float ar_rnd(float f) {
   return T::to_float((uint16_t)b);
 }
 
-template <typename T>
-__global__ __launch_bounds__(AR_THREADS) void one_shot_all_reduce_norm_kernel(
+template <typename T, bool TWO>
+__global__ __launch_bounds__(AR_THREADS) void p2p_all_reduce_norm_kernel(
     ArPeers peers, int rank, int world, const uint16_t* __restrict__ inp, const float* __restrict__ slab,
     int splits, int64_t slab_stride, uint16_t* __restrict__ residual, const uint16_t* __restrict__ weight,
-    uint16_t* __restrict__ out, float epsilon, int rows, int hidden, int64_t buf_bytes) {
+    uint16_t* __restrict__ out, float epsilon, int rows, int hidden, int64_t buf_bytes, uint64_t spin_ticks) {
   __shared__ float fold[2 * AR_THREADS][4];
   __shared__ float red[AR_THREADS / 64];
+  __shared__ int dead;
+  if (threadIdx.x == 0) dead = 0;
   const int b = blockIdx.x;
   ArComm* mine = peers.comm[rank];
   const uint32_t seq = mine->seq[b] + 1;
   const int64_t parity_off = (seq & 1) ? buf_bytes : 0;
   const int hv = hidden / 8;                         // 16-byte vectors per row (<= 2 * AR_THREADS)
   const int per = (rows + gridDim.x - 1) / gridDim.x;
-  const int r0 = b * per, r1 = min(r0 + per, rows);
-  uint4* stage = reinterpret_cast<uint4*>(peers.data[rank] + parity_off);
+  const int r0 = min(b * per, rows), r1 = min(r0 + per, rows);
+  const int64_t v0 = (int64_t)r0 * hv, v1 = (int64_t)r1 * hv;
   // 1. my rows -> my staging buffer
-  for (int r = r0; r < r1; ++r)
-    for (int v = threadIdx.x; v < hv; v += AR_THREADS) {
-      const int64_t e = (int64_t)r * hv + v;
-      if (slab != nullptr) {
-        f32x4_t lo4 = {0.f, 0.f, 0.f, 0.f}, hi4 = {0.f, 0.f, 0.f, 0.f};
-        for (int sp = 0; sp < splits; ++sp) {
-          lo4 += *reinterpret_cast<const f32x4_t*>(slab + sp * slab_stride + e * 8);
-          hi4 += *reinterpret_cast<const f32x4_t*>(slab + sp * slab_stride + e * 8 + 4);
-        }
-        stage[e] = make_uint4(T::pack2(lo4[0], lo4[1]), T::pack2(lo4[2], lo4[3]), T::pack2(hi4[0], hi4[1]),
-                              T::pack2(hi4[2], hi4[3]));
-      } else {
-        stage[e] = reinterpret_cast<const uint4*>(inp)[e];
-      }
-    }
-  __threadfence_system();
-  __syncthreads();
-  // 2. handshake
-  if (threadIdx.x < world) {
-    const int q = threadIdx.x;
-    __hip_atomic_store(&peers.comm[q]->flags[b][rank], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
-    while ((int32_t)(__hip_atomic_load(&mine->flags[b][q], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - seq) < 0) {
-      if (__builtin_amdgcn_s_memrealtime() - t0 > AR_SPIN_TICKS) {
-        __hip_atomic_store(&mine->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        break;
-      }
-      __builtin_amdgcn_s_sleep(1);
+  ar_stage_slice<T>(reinterpret_cast<uint4*>(peers.data[rank] + parity_off), inp, slab, splits, slab_stride, v0, v1);
+  // 2. rendezvous (+ reduce-scatter and second rendezvous in the two-shot form)
+  bool ok = ar_rendezvous(peers, mine, rank, world, b, seq, 0, spin_ticks, &dead);
+  const int64_t sub = TWO ? max((v1 - v0 + world - 1) / world, (int64_t)1) : 1;
+  if constexpr (TWO) {
+    if (ok) {
+      uint4* tmine = reinterpret_cast<uint4*>(peers.tmp[rank] + parity_off);
+      const int64_t s0 = min(v0 + rank * sub, v1), s1 = min(s0 + sub, v1);
+      for (int64_t v = s0 + threadIdx.x; v < s1; v += AR_THREADS) tmine[v] = ar_sum_vec<T>(peers, world, parity_off, v);
+      ok = ar_rendezvous(peers, mine, rank, world, b, seq, 1, spin_ticks, &dead);
     }
   }
-  __syncthreads();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
   // 3. finish my rows
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int r = r0; r < r1; ++r) {
@@ -209,29 +259,25 @@ __global__ __launch_bounds__(AR_THREADS) void one_shot_all_reduce_norm_kernel(
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int v = threadIdx.x + i * AR_THREADS;
-      const bool ok = v < hv;
-      const int64_t e = (int64_t)r * hv + (ok ? v : 0);
-      float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      for (int q = 0; q < world; ++q) {
-        const uint4 x = reinterpret_cast<const uint4*>(peers.data[q] + parity_off)[e];
-        const uint32_t xs[4] = {x.x, x.y, x.z, x.w};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          acc[2 * j] += lo_f<T>(xs[j]);
-          acc[2 * j + 1] += hi_f<T>(xs[j]);
-        }
-      }
+      const bool in = v < hv;
+      const int64_t e = (int64_t)r * hv + (in ? v : 0);
+      // the all-reduce output of this vector, rounded to the model dtype
+      uint4 s4;
+      if (!ok) s4 = ar_nan16<T>();
+      else if constexpr (TWO) s4 = reinterpret_cast<const uint4*>(peers.tmp[(e - v0) / sub] + parity_off)[e];
+      else s4 = ar_sum_vec<T>(peers, world, parity_off, e);
+      const uint32_t ss[4] = {s4.x, s4.y, s4.z, s4.w};
       const uint4 rs4 = ld16(residual + e * 8);
       const uint32_t rs[4] = {rs4.x, rs4.y, rs4.z, rs4.w};
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        // all-reduce output rounded to the model dtype, then z = x + residual rounded (layernorm_kernels.cu:271-274)
-        const float lo = ar_rnd<T>(ar_rnd<T>(acc[2 * j]) + lo_f<T>(rs[j]));
-        const float hi = ar_rnd<T>(ar_rnd<T>(acc[2 * j + 1]) + hi_f<T>(rs[j]));
+        // z = x + residual rounded (layernorm_kernels.cu:271-274)
+        const float lo = ar_rnd<T>(lo_f<T>(ss[j]) + lo_f<T>(rs[j]));
+        const float hi = ar_rnd<T>(hi_f<T>(ss[j]) + hi_f<T>(rs[j]));
         z[i][j] = T::pack2(lo, hi);
-        terms[i][j] = ok ? lo * lo + hi * hi : 0.f;
+        terms[i][j] = in ? lo * lo + hi * hi : 0.f;
       }
-      if (ok) st16(residual + e * 8, make_uint4(z[i][0], z[i][1], z[i][2], z[i][3]));
+      if (in) st16(residual + e * 8, make_uint4(z[i][0], z[i][1], z[i][2], z[i][3]));
     }
     // variance in the 256-lane form's order: lane t adds the four addends of vector t, t + 256, ...
     __syncthreads();
@@ -273,6 +319,15 @@ __global__ __launch_bounds__(AR_THREADS) void one_shot_all_reduce_norm_kernel(
   if (threadIdx.x == 0) mine->seq[b] = seq;
 }
 
+// the reference's dispatch rule (custom_all_reduce.cuh:442-451): one-shot for two ranks and for small
+// messages (< 512 KB up to 4 ranks, < 256 KB up to 8), two-shot beyond
+static inline bool ar_two_shot(const ArState* st, int64_t bytes) {
+  if (st->force_algo) return st->force_algo == 2;
+  if (st->world == 2) return false;
+  if ((st->world <= 4 && bytes < 512 * 1024) || (st->world <= 8 && bytes < 256 * 1024)) return false;
+  return true;
+}
+
 }  // namespace nmv
 
 using namespace nmv;
@@ -288,14 +343,16 @@ using namespace nmv;
 
 extern "C" int nmv_ar_handle_bytes(void) { return (int)sizeof(hipIpcMemHandle_t); }
 
-/* allocate this rank's comm block + staging (2 x max_bytes) on the current device and export it */
+/* allocate this rank's comm block + staging (2 x max_bytes) + reduced-slice buffers (2 x max_bytes) on the
+ * current device and export it */
 extern "C" int nmv_ar_create(void** state_out, int rank, int world, int64_t max_bytes, void* handle_out) {
   NMV_CHECK(world >= 2 && world <= AR_MAX_RANKS && rank >= 0 && rank < world, "custom_all_reduce: bad rank / world");
-  NMV_CHECK(max_bytes > 0 && max_bytes % 16 == 0, "custom_all_reduce: max_bytes must be a multiple of 16");
+  NMV_CHECK(max_bytes > 0 && max_bytes % 256 == 0, "custom_all_reduce: max_bytes must be a multiple of 256");
   ArState* st = new ArState();
   std::memset(st, 0, sizeof(ArState));
   st->rank = rank; st->world = world; st->max_bytes = max_bytes;
-  st->alloc_bytes = sizeof(ArComm) + 2 * (size_t)max_bytes;
+  st->spin_ticks = AR_SPIN_TICKS;
+  st->alloc_bytes = sizeof(ArComm) + 4 * (size_t)max_bytes;
   hipError_t e = hipExtMallocWithFlags(&st->base, st->alloc_bytes, hipDeviceMallocUncached);
   if (e != hipSuccess) {
     (void)hipGetLastError();
@@ -332,9 +389,46 @@ extern "C" int nmv_ar_open(void* state, const void* handles) {
     }
     st->peers.comm[q] = (ArComm*)st->peer_base[q];
     st->peers.data[q] = (uint8_t*)st->peer_base[q] + sizeof(ArComm);
+    st->peers.tmp[q] = st->peers.data[q] + 2 * (size_t)st->max_bytes;
   }
   st->opened = true;
   return NMV_OK;
+}
+
+/* algo: 0 = the reference's size rule (custom_all_reduce.cuh:442-451), 1 = always one-shot, 2 = always
+ * two-shot (tests, measurements).  Every rank must use the same setting. */
+extern "C" int nmv_ar_set_algo(void* state, int algo) {
+  ArState* st = (ArState*)state;
+  NMV_CHECK(st != nullptr && algo >= 0 && algo <= 2, "custom_all_reduce: algo must be 0, 1 or 2");
+  st->force_algo = algo;
+  return NMV_OK;
+}
+
+/* how long a flag wait may last before the call gives up, sets the error word and writes NaN (default 2 s) */
+extern "C" int nmv_ar_set_timeout_ms(void* state, int64_t ms) {
+  ArState* st = (ArState*)state;
+  NMV_CHECK(st != nullptr && ms > 0, "custom_all_reduce: bad timeout");
+  st->spin_ticks = (uint64_t)ms * 100000ull;  // s_memrealtime: 100 MHz
+  return NMV_OK;
+}
+
+/* 1 when the call would take the two-shot form (reduce-scatter + all-gather), 0 for one-shot */
+extern "C" int nmv_ar_is_two_shot(void* state, int64_t bytes) {
+  ArState* st = (ArState*)state;
+  return (st != nullptr && ar_two_shot(st, bytes)) ? 1 : 0;
+}
+
+template <typename T>
+static void ar_launch(ArState* st, const void* inp, void* out, int64_t n_vec, const float* slab, int splits,
+                      int64_t slab_stride, hipStream_t s) {
+  if (ar_two_shot(st, n_vec * 16))
+    hipLaunchKernelGGL((p2p_all_reduce_kernel<T, 2>), dim3(AR_MAX_BLOCKS), dim3(AR_THREADS), 0, s, st->peers,
+                       st->rank, st->world, (const uint16_t*)inp, (uint16_t*)out, n_vec, st->max_bytes,
+                       st->spin_ticks, slab, splits, slab_stride);
+  else
+    hipLaunchKernelGGL((p2p_all_reduce_kernel<T, 0>), dim3(AR_MAX_BLOCKS), dim3(AR_THREADS), 0, s, st->peers,
+                       st->rank, st->world, (const uint16_t*)inp, (uint16_t*)out, n_vec, st->max_bytes,
+                       st->spin_ticks, slab, splits, slab_stride);
 }
 
 extern "C" int nmv_ar_all_reduce(void* state, const void* inp, void* out, int64_t numel, nmv_dtype_t dtype,
@@ -346,15 +440,8 @@ extern "C" int nmv_ar_all_reduce(void* state, const void* inp, void* out, int64_
   NMV_CHECK(bytes > 0 && bytes % 16 == 0 && bytes <= st->max_bytes,
             "custom_all_reduce: message must be a multiple of 16 bytes and <= %lld", (long long)st->max_bytes);
   NMV_CHECK((((uintptr_t)inp | (uintptr_t)out) & 15) == 0, "custom_all_reduce: 16-byte aligned tensors");
-  const int64_t n_vec = bytes / 16;
-  const int blocks = AR_MAX_BLOCKS;
-  hipStream_t s = (hipStream_t)stream;
-  if (dtype == NMV_F16)
-    hipLaunchKernelGGL((one_shot_all_reduce_kernel<F16>), dim3(blocks), dim3(AR_THREADS), 0, s, st->peers,
-                       st->rank, st->world, (const uint16_t*)inp, (uint16_t*)out, n_vec, st->max_bytes);
-  else
-    hipLaunchKernelGGL((one_shot_all_reduce_kernel<BF16>), dim3(blocks), dim3(AR_THREADS), 0, s, st->peers,
-                       st->rank, st->world, (const uint16_t*)inp, (uint16_t*)out, n_vec, st->max_bytes);
+  if (dtype == NMV_F16) ar_launch<F16>(st, inp, out, bytes / 16, nullptr, 0, 0, (hipStream_t)stream);
+  else ar_launch<BF16>(st, inp, out, bytes / 16, nullptr, 0, 0, (hipStream_t)stream);
   NMV_LAUNCH_CHECK();
   return NMV_OK;
 }
@@ -371,16 +458,8 @@ extern "C" int nmv_ar_all_reduce_partial(void* state, const float* slab, int spl
   NMV_CHECK(bytes > 0 && bytes % 16 == 0 && bytes <= st->max_bytes,
             "custom_all_reduce: message must be a multiple of 16 bytes and <= %lld", (long long)st->max_bytes);
   NMV_CHECK((((uintptr_t)slab | (uintptr_t)out) & 15) == 0, "custom_all_reduce: 16-byte aligned tensors");
-  const int64_t n_vec = bytes / 16;
-  hipStream_t s = (hipStream_t)stream;
-  if (dtype == NMV_F16)
-    hipLaunchKernelGGL((one_shot_all_reduce_kernel<F16>), dim3(AR_MAX_BLOCKS), dim3(AR_THREADS), 0, s, st->peers,
-                       st->rank, st->world, (const uint16_t*)nullptr, (uint16_t*)out, n_vec, st->max_bytes, slab,
-                       splits, numel);
-  else
-    hipLaunchKernelGGL((one_shot_all_reduce_kernel<BF16>), dim3(AR_MAX_BLOCKS), dim3(AR_THREADS), 0, s, st->peers,
-                       st->rank, st->world, (const uint16_t*)nullptr, (uint16_t*)out, n_vec, st->max_bytes, slab,
-                       splits, numel);
+  if (dtype == NMV_F16) ar_launch<F16>(st, nullptr, out, bytes / 16, slab, splits, numel, (hipStream_t)stream);
+  else ar_launch<BF16>(st, nullptr, out, bytes / 16, slab, splits, numel, (hipStream_t)stream);
   NMV_LAUNCH_CHECK();
   return NMV_OK;
 }
@@ -405,16 +484,15 @@ extern "C" int nmv_ar_all_reduce_add_rms_norm(void* state, const void* inp, cons
             "all_reduce_add_rms_norm: 16-byte aligned tensors");
   hipStream_t s = (hipStream_t)stream;
   const int64_t stride = (int64_t)rows * hidden;
-  if (dtype == NMV_F16)
-    hipLaunchKernelGGL((one_shot_all_reduce_norm_kernel<F16>), dim3(AR_MAX_BLOCKS), dim3(AR_THREADS), 0, s,
-                       st->peers, st->rank, st->world, (const uint16_t*)inp, slab, splits, stride,
-                       (uint16_t*)residual, (const uint16_t*)weight, (uint16_t*)out, epsilon, rows, hidden,
-                       st->max_bytes);
-  else
-    hipLaunchKernelGGL((one_shot_all_reduce_norm_kernel<BF16>), dim3(AR_MAX_BLOCKS), dim3(AR_THREADS), 0, s,
-                       st->peers, st->rank, st->world, (const uint16_t*)inp, slab, splits, stride,
-                       (uint16_t*)residual, (const uint16_t*)weight, (uint16_t*)out, epsilon, rows, hidden,
-                       st->max_bytes);
+  const bool two = ar_two_shot(st, stride * 2);
+#define NMV_AR_NORM(T_, TWO_)                                                                                   \
+  hipLaunchKernelGGL((p2p_all_reduce_norm_kernel<T_, TWO_>), dim3(AR_MAX_BLOCKS), dim3(AR_THREADS), 0, s,       \
+                     st->peers, st->rank, st->world, (const uint16_t*)inp, slab, splits, stride,                \
+                     (uint16_t*)residual, (const uint16_t*)weight, (uint16_t*)out, epsilon, rows, hidden,       \
+                     st->max_bytes, st->spin_ticks)
+  if (dtype == NMV_F16) { if (two) NMV_AR_NORM(F16, true); else NMV_AR_NORM(F16, false); }
+  else { if (two) NMV_AR_NORM(BF16, true); else NMV_AR_NORM(BF16, false); }
+#undef NMV_AR_NORM
   NMV_LAUNCH_CHECK();
   return NMV_OK;
 }
@@ -428,15 +506,16 @@ extern "C" int nmv_ar_all_gather(void* state, const void* inp, void* out, int64_
             "custom all_gather: record must be a multiple of 16 bytes and <= %lld", (long long)st->max_bytes);
   NMV_CHECK((((uintptr_t)inp | (uintptr_t)out) & 15) == 0, "custom all_gather: 16-byte aligned tensors");
   const int64_t n_vec = bytes_per_rank / 16;
-  const int blocks = AR_MAX_BLOCKS;
-  hipLaunchKernelGGL((one_shot_all_reduce_kernel<BF16, true>), dim3(blocks), dim3(AR_THREADS), 0,
+  hipLaunchKernelGGL((p2p_all_reduce_kernel<BF16, 1>), dim3(AR_MAX_BLOCKS), dim3(AR_THREADS), 0,
                      (hipStream_t)stream, st->peers, st->rank, st->world, (const uint16_t*)inp,
-                     (uint16_t*)out, n_vec, st->max_bytes);
+                     (uint16_t*)out, n_vec, st->max_bytes, st->spin_ticks);
   NMV_LAUNCH_CHECK();
   return NMV_OK;
 }
 
-/* 1 when a bounded spin ran out on this rank since creation (synchronises the device) */
+/* 1 when a bounded flag wait ran out on this rank since creation (synchronises the device): the call
+ * that timed out wrote NaN, the communicator's call counters are out of step with its peers' and it must
+ * not be used again */
 extern "C" int nmv_ar_error(void* state) {
   ArState* st = (ArState*)state;
   if (st == nullptr) return 1;

@@ -110,7 +110,14 @@ __global__ __launch_bounds__(64) void argmax_final_kernel(const float* __restric
   const int64_t pos = positions[row] + 1;
   positions[row] = pos;
   seq_lens[row] += 1;
-  const int64_t blk = block_tables[(int64_t)row * max_blocks_per_seq + pos / block_size];
+  // a sequence that has just filled its last block has no next slot: the block table ends there (its
+  // row would be read one entry past the end); -1 = "skip" for reshape_and_cache (cache_kernels.cu:164)
+  const int64_t bi = pos / block_size;
+  if (bi >= max_blocks_per_seq) {
+    slot_mapping[row] = -1;
+    return;
+  }
+  const int64_t blk = block_tables[(int64_t)row * max_blocks_per_seq + bi];
   slot_mapping[row] = blk * block_size + pos % block_size;
 }
 

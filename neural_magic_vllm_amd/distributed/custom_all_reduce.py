@@ -1,5 +1,5 @@
-"""One-shot P2P all-reduce over HIP IPC (csrc/custom_all_reduce.hip) -- the ROCm analogue of the
-reference's vllm/distributed/device_communicators/custom_all_reduce.py (CUDA only there; its
+"""One-shot / two-shot P2P all-reduce over HIP IPC (csrc/custom_all_reduce.hip) -- the ROCm analogue of
+the reference's vllm/distributed/device_communicators/custom_all_reduce.py (CUDA only there; its
 kernels are compiled out on ROCm, csrc/torch_bindings.cpp:261).
 
 Every rank allocates one staging block on its GPU, the IPC handles are exchanged over the gloo
@@ -7,7 +7,10 @@ twin of the tensor-parallel group, and `all_reduce` launches one kernel per call
 a hipGraph: the call counters live in device memory).  Before the communicator is used it runs a
 self-test against a CPU reference on the actual devices; any mismatch, a bounded-spin timeout or a
 failed IPC mapping on ANY rank disables it on ALL ranks and RCCL is used instead -- the custom
-path can make the decode step faster, never wrong."""
+path can make the decode step faster, never wrong.  After start-up a flag wait that runs out (a lost
+or lagging peer) makes the call write NaN and sets an error word on the device: `check_error` reads
+it at the points that synchronise anyway (after graph capture, after a timed loop, on destroy) and
+raises `CustomAllReduceError` on every rank."""
 import ctypes
 import os
 import socket
@@ -20,6 +23,10 @@ from .. import _lib
 from .._torch_bindings import check, dtype_code, ptr, stream_of
 
 MAX_BYTES = 8 << 20  # the reference's max_size (custom_all_reduce.py:43)
+
+
+class CustomAllReduceError(RuntimeError):
+    """a flag wait of the P2P all-reduce timed out on some rank: results since then are NaN"""
 
 
 class CustomAllReduce:
@@ -93,7 +100,12 @@ class CustomAllReduce:
         out early would pair its next collective with its peers' current one); a failure only clears
         the flag that the caller then shares."""
         good = True
-        for rnd, numel in enumerate((8, 4096, 64 * 4096, 64 * 4096 + 8, 1 << 20)):
+        lib = _lib.load()
+        # (message size, algorithm): 0 = the reference's size rule, 1 / 2 = one-shot / two-shot forced
+        cases = [(8, 0), (4096, 0), (64 * 4096, 0), (64 * 4096 + 8, 0), (1 << 20, 0),
+                 (8, 2), (64 * 4096 + 8, 2), (1 << 20, 1), (1 << 20, 2)]
+        for rnd, (numel, algo) in enumerate(cases):
+            lib.nmv_ar_set_algo(self.state, algo)
             for dtype in (torch.bfloat16, torch.float16):
                 g = torch.Generator().manual_seed(1000 * rnd + self.rank)
                 x = torch.randn(numel, generator=g).to(dtype)
@@ -107,17 +119,22 @@ class CustomAllReduce:
                     torch.cuda.synchronize(self.device)
                     if not torch.equal(got.cpu().view(torch.int16), ref.to(dtype).view(torch.int16)):
                         good = False
-                        self.disabled_reason = self.disabled_reason or f"self-test mismatch (numel={numel}, {dtype})"
+                        self.disabled_reason = self.disabled_reason or \
+                            f"self-test mismatch (numel={numel}, {dtype}, algo={algo})"
                 except Exception as e:
                     good = False
                     self.disabled_reason = self.disabled_reason or f"self-test: {e}"
         try:
+            lib.nmv_ar_set_algo(self.state, 0)
             if not self._gather_ok():
                 good = False
                 self.disabled_reason = self.disabled_reason or "self-test: all_gather mismatch"
-            if not self._fused_ok():
-                good = False
-                self.disabled_reason = self.disabled_reason or "self-test: fused all-reduce + norm mismatch"
+            for algo in (1, 2, 0):   # the fused variants in both forms; ends on the size rule
+                lib.nmv_ar_set_algo(self.state, algo)
+                if not self._fused_ok():
+                    good = False
+                    self.disabled_reason = self.disabled_reason or \
+                        f"self-test: fused all-reduce + norm mismatch (algo={algo})"
             if _lib.load().nmv_ar_error(self.state):
                 good = False
                 self.disabled_reason = self.disabled_reason or "self-test: a flag wait timed out"
@@ -127,6 +144,36 @@ class CustomAllReduce:
         return good
 
     # ------------------------------------------------------------------
+    def set_algo(self, algo: int) -> None:
+        """0 = the reference's size rule (custom_all_reduce.cuh:442-451), 1 = one-shot, 2 = two-shot;
+        every rank must make the same call"""
+        check(_lib.load().nmv_ar_set_algo(self.state, algo))
+
+    def set_timeout_ms(self, ms: int) -> None:
+        check(_lib.load().nmv_ar_set_timeout_ms(self.state, ms))
+
+    def is_two_shot(self, nbytes: int) -> bool:
+        return bool(_lib.load().nmv_ar_is_two_shot(self.state, nbytes))
+
+    def local_error(self) -> bool:
+        """True when a flag wait ran out on THIS rank (synchronises the device)"""
+        if self.state is None:
+            return False
+        with torch.cuda.device(self.device):
+            return bool(_lib.load().nmv_ar_error(self.state))
+
+    def check_error(self, collective: bool = True) -> None:
+        """raise CustomAllReduceError when a flag wait timed out -- on any rank of the group when
+        `collective` (every rank must then make this call), else on this rank only"""
+        bad = self.local_error()
+        if collective:
+            bad = not self._all_agree(not bad)
+        if bad:
+            self.enabled = False
+            raise CustomAllReduceError(
+                "custom all-reduce: a peer did not arrive within the flag-wait bound; the affected "
+                "outputs are NaN and the communicator is out of step -- results are invalid")
+
     def should_use(self, t: torch.Tensor) -> bool:
         nbytes = t.numel() * t.element_size()
         return (self.enabled and t.is_cuda and t.dtype in (torch.float16, torch.bfloat16) and t.is_contiguous()

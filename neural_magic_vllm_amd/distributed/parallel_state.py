@@ -148,10 +148,20 @@ class GroupCoordinator:
     def barrier(self):
         dist.barrier(group=self.cpu_group)
 
+    def check_custom_ar_error(self, collective: bool = True) -> None:
+        """raises CustomAllReduceError when a P2P all-reduce gave up waiting for a peer since the group
+        was created (its output is NaN then); a no-op without the P2P communicator.  Synchronises."""
+        if self.custom_ar is not None:
+            self.custom_ar.check_error(collective)
+
     def destroy(self):
         if getattr(self, "custom_ar", None) is not None:
-            self.custom_ar.close()
-            self.custom_ar = None
+            try:
+                # a timeout that nobody looked at must not pass silently; peers may already be gone
+                self.custom_ar.check_error(collective=False)
+            finally:
+                self.custom_ar.close()
+                self.custom_ar = None
         if self.device_group is not None:
             dist.destroy_process_group(self.device_group)
             self.device_group = None

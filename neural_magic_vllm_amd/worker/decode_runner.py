@@ -312,9 +312,38 @@ class DecodeRunner:
             return self._graph_out
         return self._step_body()
 
+    def step_is_capturable(self) -> bool:
+        """whether one decode step can be recorded into a hipGraph.  Without TP always; under TP when the
+        step holds no process-group collective at all (row-parallel all-reduces and the sampler's gather
+        on the P2P communicator) or when the device group is RCCL, whose collectives are captured by
+        torch like kernels.  Any other backend (gloo on GPU tensors: the one-GPU rehearsal) is NOT: its
+        collectives hand the tensor to a helper thread that synchronises a side stream, and a stream
+        synchronisation inside a capture invalidates it -- after which the runtime's stream state is
+        undefined (round 1: SIGSEGV in the first eager all_reduce that followed).  Such a step is never
+        offered to torch.cuda.graph; it runs eagerly."""
+        if self.tp_size == 1:
+            return True
+        tp = get_tp_group()
+        if tp.custom_ar is not None and self.fused_step_tail:
+            return True
+        return tp.backend == "nccl"
+
     @torch.inference_mode()
     def capture(self, warmup: int = 2) -> bool:
-        """capture one decode step into a hipGraph; returns False (and stays eager) on failure"""
+        """capture one decode step into a hipGraph; returns False (and stays eager) when the step is not
+        capturable (step_is_capturable) or the capture fails"""
+        self.graph = None
+        if not self.step_is_capturable():
+            if self.tp_rank == 0:
+                print(f"[decode_runner] decode step not captured: it contains '{get_tp_group().backend}' "
+                      "collectives, which cannot be recorded into a hipGraph; running eagerly", file=sys.stderr)
+            return False
+        # the capture runs warmup + 1 steps before the state is restored: they must fit into what the
+        # batch was set up with (block tables, rotary table)
+        if self._steps_left < warmup + 1:
+            warmup = max(0, self._steps_left - 1)
+            if self._steps_left < 1:
+                raise RuntimeError("capture: the batch has no decode step left (max_new_tokens used up)")
         saved = [t.clone() for t in (self.input_ids, self.positions, self.seq_lens, self.slot_mapping)]
         prev_stream = torch.cuda.current_stream(self.device)
         if self.tp_size > 1:
@@ -356,7 +385,23 @@ class DecodeRunner:
         for dst, src in zip((self.input_ids, self.positions, self.seq_lens, self.slot_mapping), saved):
             dst.copy_(src)
         torch.cuda.synchronize(self.device)
+        if self.tp_size > 1:
+            # every rank replays a graph, or none does (agreed over the CPU group: no device collective
+            # right after a capture), and a P2P flag wait that ran out during the warm-up is fatal
+            flags = [None] * self.tp_size
+            import torch.distributed as dist
+            dist.all_gather_object(flags, bool(ok), group=get_tp_group().cpu_group)
+            if not all(flags):
+                self.graph = None
+                ok = False
+            get_tp_group().check_custom_ar_error()
         return ok
+
+    def check_collectives(self) -> None:
+        """raise when a P2P all-reduce of this runner's group timed out since the last check (its
+        outputs, and every token since, are NaN / garbage); collective over the TP group"""
+        if self.tp_size > 1:
+            get_tp_group().check_custom_ar_error()
 
     @torch.inference_mode()
     def prefill(self, prompt_len: int, seed: int = 0) -> torch.Tensor:

@@ -139,3 +139,108 @@ def make_w4a16_problem(seed, size_m, size_k, size_n, num_bits, group_size, act_o
                                                                  act_order, g)
     return dict(a=a, w_ref=w_ref.to(dtype), marlin_q_w=mq, marlin_s=ms.to(dtype), g_idx=g_idx,
                 sort_indices=sort_idx)
+
+
+# ---------------------------------------------------------------------------------------------
+# Tiny models for the end-to-end fixtures (tools/make_golden_model.py runs the REFERENCE's model code
+# on these weights; tests/test_gpu_model_golden.py runs the HIP path on the same tensors).
+TINY_LLAMA = dict(hidden_size=512, intermediate_size=1024, num_hidden_layers=2, num_attention_heads=8,
+                  num_key_value_heads=2, vocab_size=2048, rms_norm_eps=1e-5, rope_theta=500000.0,
+                  max_position_embeddings=8192)
+# OPT-125m's head geometry (12 heads x 64, MHA; facebook/opt-125m config) with 2 layers, small vocabulary
+TINY_OPT = dict(hidden_size=768, ffn_dim=3072, num_hidden_layers=2, num_attention_heads=12,
+                vocab_size=2048, max_position_embeddings=2048)
+
+
+def is_quantised_linear(name: str) -> bool:
+    return name.endswith("_proj.weight")
+
+
+def tiny_llama_checkpoint(seed: int, dtype: torch.dtype):
+    """HF-layout tensors (name -> [out, in]) of a random TINY_LLAMA, CPU generator"""
+    a = TINY_LLAMA
+    g = torch.Generator().manual_seed(1000 + seed)
+    h, inter = a["hidden_size"], a["intermediate_size"]
+    hd = h // a["num_attention_heads"]
+    nq, nkv = a["num_attention_heads"], a["num_key_value_heads"]
+
+    def w(o, i, std=0.05):
+        return (torch.randn((o, i), generator=g) * std).to(dtype)
+
+    def norm(n):
+        return (1 + 0.1 * torch.randn(n, generator=g)).to(dtype)
+
+    ck = {"model.embed_tokens.weight": w(a["vocab_size"], h, 0.5)}
+    for i in range(a["num_hidden_layers"]):
+        p = f"model.layers.{i}."
+        ck[p + "self_attn.q_proj.weight"] = w(nq * hd, h)
+        ck[p + "self_attn.k_proj.weight"] = w(nkv * hd, h)
+        ck[p + "self_attn.v_proj.weight"] = w(nkv * hd, h)
+        ck[p + "self_attn.o_proj.weight"] = w(h, nq * hd)
+        ck[p + "mlp.gate_proj.weight"] = w(inter, h)
+        ck[p + "mlp.up_proj.weight"] = w(inter, h)
+        ck[p + "mlp.down_proj.weight"] = w(h, inter)
+        ck[p + "input_layernorm.weight"] = norm(h)
+        ck[p + "post_attention_layernorm.weight"] = norm(h)
+    ck["model.norm.weight"] = norm(h)
+    ck["lm_head.weight"] = w(a["vocab_size"], h)
+    return ck
+
+
+def quantize_like_reference(w_kn: torch.Tensor, num_bits: int, group_size: int):
+    """(q_w int32 [K, N], s [K/g, N]) of oracle.ref_math.quantize_weights -- pinned bit for bit to the
+    reference's quantize_weights by tests/golden/mq_*.npz and again by tools/make_golden_model.py"""
+    from oracle import ref_math
+    _, q_w, s, _, _ = ref_math.quantize_weights(w_kn, num_bits, group_size, False)
+    return q_w, s
+
+
+def gptq_checkpoint_from_dense(ckpt, num_bits: int = 4, group_size: int = 128):
+    """dense HF tensors -> GPTQ checkpoint tensors (qweight / scales / g_idx per quantised linear)"""
+    from oracle import ref_math
+    out = {}
+    for name, w in ckpt.items():
+        if not is_quantised_linear(name):
+            out[name] = w
+            continue
+        w_kn = w.t().contiguous()
+        k, n = w_kn.shape
+        q_w, s = quantize_like_reference(w_kn, num_bits, group_size)
+        base = name[:-len(".weight")]
+        out[base + ".qweight"] = ref_math.gptq_pack(q_w, num_bits, k, n)
+        out[base + ".scales"] = s.to(w.dtype)
+        out[base + ".g_idx"] = (torch.arange(k, dtype=torch.int32) // group_size)
+    return out
+
+
+def tiny_opt_checkpoint(seed: int, dtype: torch.dtype):
+    """HF-layout tensors of a random TINY_OPT (names of facebook/opt-*: model.decoder....)"""
+    a = TINY_OPT
+    g = torch.Generator().manual_seed(2000 + seed)
+    h, f = a["hidden_size"], a["ffn_dim"]
+
+    def w(o, i, std=0.05):
+        return (torch.randn((o, i), generator=g) * std).to(dtype)
+
+    def vec(n, mean=0.0, std=0.05):
+        return (mean + std * torch.randn(n, generator=g)).to(dtype)
+
+    d = "model.decoder."
+    ck = {d + "embed_tokens.weight": w(a["vocab_size"], h, 0.05),
+          d + "embed_positions.weight": w(a["max_position_embeddings"] + 2, h, 0.05)}
+    for i in range(a["num_hidden_layers"]):
+        p = f"{d}layers.{i}."
+        for nm in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            ck[p + f"self_attn.{nm}.weight"] = w(h, h)
+            ck[p + f"self_attn.{nm}.bias"] = vec(h)
+        ck[p + "self_attn_layer_norm.weight"] = vec(h, 1.0, 0.1)
+        ck[p + "self_attn_layer_norm.bias"] = vec(h)
+        ck[p + "fc1.weight"] = w(f, h)
+        ck[p + "fc1.bias"] = vec(f)
+        ck[p + "fc2.weight"] = w(h, f)
+        ck[p + "fc2.bias"] = vec(h)
+        ck[p + "final_layer_norm.weight"] = vec(h, 1.0, 0.1)
+        ck[p + "final_layer_norm.bias"] = vec(h)
+    ck[d + "final_layer_norm.weight"] = vec(h, 1.0, 0.1)
+    ck[d + "final_layer_norm.bias"] = vec(h)
+    return ck

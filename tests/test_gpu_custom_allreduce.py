@@ -1,4 +1,4 @@
-"""GPU: the one-shot P2P all-reduce over HIP IPC (csrc/custom_all_reduce.hip), rehearsed with 2 and 4
+"""GPU: the one-shot / two-shot P2P all-reduce over HIP IPC (csrc/custom_all_reduce.hip), rehearsed with 2 and 4
 processes that share the one GPU of the test box (IPC mapping, flag protocol, double buffering,
 graph replay, the self-test / fallback logic).  The cross-device part -- xGMI peer reads -- cannot be
 exercised here; on a multi-GPU node the communicator's own start-up self-test decides whether it is
@@ -27,7 +27,7 @@ def _expected(world, numel, dtype, it):
     return ref.to(dtype)
 
 
-def _worker(rank, world, port, q, run_model):
+def _worker(rank, world, port, q, run_model, algo=0):
     try:
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                           HSA_ENABLE_IPC_MODE_LEGACY="0", NMV_CUSTOM_ALLREDUCE="force")
@@ -42,6 +42,39 @@ def _worker(rank, world, port, q, run_model):
         car = tp.custom_ar
         assert car is not None and car.enabled, getattr(car, "disabled_reason", "custom all-reduce not created")
         out = {}
+        car.set_algo(algo)   # 0 = the reference's size rule, 2 = every call in the two-shot form
+        if run_model == "timeout":
+            # rank 1 skips a call: rank 0's flag wait must run out (bound lowered to 0.3 s), its output must
+            # be NaN -- not a sum of stale buffers -- and the error must surface on every rank
+            from neural_magic_vllm_amd.distributed.custom_all_reduce import CustomAllReduceError
+            car.set_timeout_ms(300)
+            x = torch.ones(4096, dtype=torch.bfloat16, device=dev)
+            y = car.all_reduce(x)
+            torch.cuda.synchronize()
+            assert float(y[0]) == world
+            tp.check_custom_ar_error()          # nothing yet
+            dist.barrier()
+            if rank == 0:
+                y = car.all_reduce(x)
+                torch.cuda.synchronize()
+                assert bool(torch.isnan(y.float()).all()), "a timed-out all-reduce must poison its output"
+                assert car.local_error()
+            else:
+                assert not car.local_error()
+            dist.barrier()
+            raised = False
+            try:
+                tp.check_custom_ar_error()      # collective: every rank learns about rank 0's timeout
+            except CustomAllReduceError:
+                raised = True
+            assert raised and not car.enabled
+            dist.barrier()
+            car.close()
+            tp.custom_ar = None
+            nd.destroy_model_parallel()
+            dist.destroy_process_group()
+            q.put(("ok", out))
+            return
         if run_model:
             from neural_magic_vllm_amd.worker import decode_runner as dr
             import test_gpu_tp
@@ -137,6 +170,22 @@ def _worker(rank, world, port, q, run_model):
             ref = torch.stack([(row == row.max()).nonzero()[0, 0] for row in full.float()])
             assert torch.equal(tok, ref), (tok, ref)
             assert int(tok[0]) == 5 and int(tok[1]) == world * shard - 1
+            # the two-shot form (reduce-scatter + all-gather) has the bits of the one-shot form
+            for numel in (8, 24, 3 * 4096 + 8, 64 * 4096):
+                g = torch.Generator().manual_seed(555 + numel + rank)
+                x = torch.randn(numel, generator=g).to(torch.bfloat16).to(dev)
+                car.set_algo(1)
+                one = car.all_reduce(x)
+                car.set_algo(2)
+                assert car.is_two_shot(numel * 2)
+                two = car.all_reduce(x)
+                assert torch.equal(one.view(torch.int16), two.view(torch.int16)), numel
+            car.set_algo(0)
+            # the reference's dispatch rule (custom_all_reduce.cuh:442-451)
+            if world == 2:
+                assert not car.is_two_shot(8 << 20)
+            else:
+                assert not car.is_two_shot(512 * 1024 - 16) and car.is_two_shot(512 * 1024)
             assert _lib.load().nmv_ar_error(car.state) == 0
         dist.barrier()
         nd.destroy_model_parallel()
@@ -147,11 +196,11 @@ def _worker(rank, world, port, q, run_model):
         q.put(("err", f"rank {rank}: {e!r}\n{traceback.format_exc()}"))
 
 
-def _spawn(world, run_model):
+def _spawn(world, run_model, algo=0):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q, run_model)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, run_model, algo)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=300) for _ in procs]
@@ -165,6 +214,18 @@ def _spawn(world, run_model):
 @pytest.mark.parametrize("world", [2, 4])
 def test_custom_all_reduce_bit_exact_and_graph_replay(gpu_device, world):
     _spawn(world, run_model=False)
+
+
+def test_custom_all_reduce_two_shot_everywhere(gpu_device):
+    """the whole protocol suite (plain, slabs, fused add + RMSNorm, graph replay) with every call forced
+    into the two-shot form (cross_device_reduce_2stage, custom_all_reduce.cuh:203-250)"""
+    _spawn(2, run_model=False, algo=2)
+
+
+def test_custom_all_reduce_timeout_poisons_and_surfaces(gpu_device):
+    """a peer that never arrives: the waiting rank's call ends after the bound with NaN output and the
+    error is raised on every rank at the next check"""
+    _spawn(2, run_model="timeout")
 
 
 def test_tp_model_over_custom_all_reduce(gpu_device):

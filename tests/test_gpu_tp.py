@@ -28,8 +28,11 @@ def _run(runner, try_capture=False):
     toks = [first.cpu()]
     runner.input_ids.copy_(first)
     if try_capture:
-        # gloo collectives cannot be captured into a hipGraph: capture() must fail cleanly, restore
-        # the step inputs and leave the runner usable (the eager fallback bench.py relies on)
+        # gloo collectives cannot be captured into a hipGraph: capture() must say so WITHOUT entering a
+        # capture (a stream synchronisation by gloo's helper thread inside one left the runtime in a
+        # state that segfaulted the next eager all_reduce in round 1), keep the step inputs and leave
+        # the runner usable
+        assert runner.step_is_capturable() is False
         assert runner.capture() is False
         runner.input_ids.copy_(first)
     for _ in range(STEPS):
@@ -89,22 +92,54 @@ def test_tp_matches_single_process(gpu_device, world):
     assert sum(a != b for a, b in zip(flat_got, flat_ref)) <= 1, (got, ref)
 
 
-def test_bench_py_multi_rank_rehearsal(gpu_device):
-    """bench.py's N > 1 path end to end (driver contract: torch.distributed.run, one JSON line from
-    rank 0) rehearsed with two ranks on this box's one GPU and gloo collectives, tiny model"""
+def _bench_cmd(root, extra):
+    return [os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--model", "tiny",
+            "--batch", "4", "--context", "40"] + extra
+
+
+def _one_json_line(res):
     import json
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("custom_ar", ["0", "force"])
+def test_bench_py_multi_rank_rehearsal(gpu_device, custom_ar):
+    """bench.py's N > 1 path end to end (driver contract: torch.distributed.run, one JSON line from
+    rank 0) rehearsed with two ranks on this box's one GPU and gloo collectives, tiny model, graph
+    capture left ON: with the collectives on gloo the runner decides for eager without entering a
+    capture; with the P2P all-reduce the step holds no process-group collective and is captured."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, NMV_BENCH_DIST_BACKEND="gloo", NMV_BENCH_SINGLE_DEVICE="1")
+    env = dict(os.environ, NMV_BENCH_DIST_BACKEND="gloo", NMV_BENCH_SINGLE_DEVICE="1",
+               NMV_CUSTOM_ALLREDUCE=custom_ar)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(root, "bench.py"),
-           "--gpus", "2", "--steps", "4", "--warmup", "2", "--model", "tiny", "--batch", "4", "--context", "40",
-           "--no-graph"]  # gloo collectives cannot be captured; the failed-capture fallback is tested above
-    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
-    assert res.returncode == 0, res.stderr[-2000:]
-    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, res.stdout[-2000:]
-    out = json.loads(lines[0])
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port())] + _bench_cmd(root, [])
+    out = _one_json_line(subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600))
     assert out["n_gpus"] == 2 and out["steps"] == 4 and out["value"] > 0 and out["scaling"] == "strong"
-    assert out["config"]["parallelism"] == "tp2" and out["config"]["hip_graph"] is False  # gloo: eager
+    assert out["config"]["parallelism"] == "tp2" and out["timed_region_s"] > 0
+    if custom_ar == "0":
+        assert out["config"]["hip_graph"] is False and "process group" in out["config"]["all_reduce"]
+    else:
+        assert out["config"]["hip_graph"] is True and "p2p" in out["config"]["all_reduce"]
+        # the same step over the process group, measured in the same run
+        assert out["process_group_path"]["value"] > 0 and out["process_group_path"]["hip_graph"] is False
+
+
+def test_bench_py_starts_its_own_ranks(gpu_device):
+    """`python bench.py --gpus 2` with no WORLD_SIZE: the script launches the two ranks itself (before it
+    touches the GPU) and relays rank 0's line; a world size that does not match --gpus is refused"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(NMV_BENCH_DIST_BACKEND="gloo", NMV_BENCH_SINGLE_DEVICE="1", NMV_CUSTOM_ALLREDUCE="force")
+    out = _one_json_line(subprocess.run([sys.executable] + _bench_cmd(root, ["--no-sweep"]), env=env,
+                                        capture_output=True, text=True, timeout=600))
+    assert out["n_gpus"] == 2 and out["config"]["parallelism"] == "tp2"
+    bad = subprocess.run([sys.executable] + _bench_cmd(root, []), env=dict(env, WORLD_SIZE="1", RANK="0"),
+                         capture_output=True, text=True, timeout=120)
+    assert bad.returncode != 0 and "WORLD_SIZE" in bad.stderr and not bad.stdout.strip()
