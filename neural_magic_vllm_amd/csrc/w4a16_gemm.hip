@@ -529,6 +529,137 @@ __global__ __launch_bounds__(GT) void w4a16_gemm_kernel(const GemmParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Epilogue shared by the tall and the direct kernel: a wave holds accm[j][t] = its 64-column chunk x
+// 16 MT rows over its k range (lane (r, g): columns chunk*64 + 16 j + 4 g + reg, rows m0 + 16 t + r).
+// Channelwise scales, the in-workgroup K reduction through LDS, then one of: model-dtype store, the
+// silu(gate) * up store, fp32 slabs + ticket + last-arriver sum, or slabs only (deferred reduction).
+template <typename T, int MT, int WN, int WK, int GS>
+__device__ __forceinline__ void w4_tall_epilogue(const GemmParams& p, f32x4_t (&accm)[4][MT], uint4* lds,
+                                                 int wn, int wk, int lane, int r, int g, int chunk,
+                                                 bool chunk_ok, int m0, int split) {
+  constexpr int MP = 16 * MT;
+  // ---- channelwise scales are applied once, on the fp32 result ----
+  if (GS == 0 && chunk_ok) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int c64 = j * 16 + 4 * g + reg;
+        const int c = c64 & 31;
+        const int pos = (c64 >> 5) * 32 + ((c & 7) >> 1) * 8 + 2 * (c >> 3) + (c & 1);
+        const float sv = T::to_float(p.s[(int64_t)chunk * 64 + pos]);
+#pragma unroll
+        for (int t = 0; t < MT; ++t) accm[j][t][reg] *= sv;
+      }
+    }
+  }
+
+  // ---- cross-wave (intra-workgroup) k reduction ----
+  if constexpr (WK > 1) {
+    float* red = reinterpret_cast<float*>(lds);
+    __syncthreads();  // nobody reads the operand images any more
+    if (wk > 0) {
+      float* dst = red + (int64_t)((wk - 1) * WN + wn) * (4 * MT * 4) * 64;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+          for (int reg = 0; reg < 4; ++reg) dst[((j * MT + t) * 4 + reg) * 64 + lane] = accm[j][t][reg];
+    }
+    __syncthreads();
+    if (wk == 0) {
+#pragma unroll
+      for (int kk = 1; kk < WK; ++kk) {
+        const float* src = red + (int64_t)((kk - 1) * WN + wn) * (4 * MT * 4) * 64;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) accm[j][t][reg] += src[((j * MT + t) * 4 + reg) * 64 + lane];
+      }
+    }
+  }
+  const bool writer = (wk == 0) && chunk_ok;
+
+  // ---- epilogue ----
+  if (p.splits == 1 && p.epi != 2) {
+    if (!writer) return;
+    if (p.epi) {
+      // gate_up with silu_and_mul folded in: the weight columns were interleaved at load time so
+      // that a chunk holds gate[32 c .. 32 c + 31] in tiles 0, 1 and up[32 c .. 32 c + 31] in tiles
+      // 2, 3 -- the lane that holds a gate element holds its up element.  Same roundings as the two
+      // ops it replaces: both GEMM outputs rounded to the model dtype, silu in fp32 rounded to the
+      // model dtype (activation_kernels.cu:14-26), product rounded.
+#pragma unroll
+      for (int t = 0; t < MT; ++t) {
+        const int m = m0 + t * 16 + r;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          float o[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float gb = round_trip<T>(accm[j][t][i]), ub = round_trip<T>(accm[j + 2][t][i]);
+            o[i] = round_trip<T>(gb / (1.0f + expf(-gb))) * ub;
+          }
+          uint2 pk;
+          pk.x = T::pack2(o[0], o[1]);
+          pk.y = T::pack2(o[2], o[3]);
+          *reinterpret_cast<uint2*>(p.c + (int64_t)m * (p.N >> 1) + chunk * 32 + j * 16 + 4 * g) = pk;
+        }
+      }
+      return;
+    }
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+      const int m = m0 + t * 16 + r;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int n = chunk * 64 + j * 16 + 4 * g;
+        const f32x4_t o = accm[j][t];
+        uint2 pk;
+        pk.x = T::pack2(o[0], o[1]);
+        pk.y = T::pack2(o[2], o[3]);
+        *reinterpret_cast<uint2*>(p.c + (int64_t)m * p.N + n) = pk;
+      }
+    }
+    return;
+  }
+  // split-K across workgroups: sc1 slabs, ticket, the last workgroup of the tile reduces (see above)
+  const int64_t slab_bytes = (int64_t)p.splits * p.M * p.N * 4;
+  __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p.slab, 0, (int)slab_bytes, 0x00020000);
+  if (writer) {
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+      const int m = m0 + t * 16 + r;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int n = chunk * 64 + j * 16 + 4 * g;
+        const int off = (int)((((int64_t)split * p.M + m) * p.N + n) * 4);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, accm[j][t]), rs, off, 0, 16);
+      }
+    }
+  }
+  if (p.epi == 2) return;  // deferred: the next kernel in the stream sums the slabs (kernel boundary = release)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __shared__ int ticket_s;
+  __syncthreads();
+  const int tile = blockIdx.z * gridDim.x + blockIdx.x;
+  if (threadIdx.x == 0)
+    ticket_s = __hip_atomic_fetch_add(p.tickets + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  if (ticket_s != p.splits - 1) return;
+  if (threadIdx.x == 0)
+    __hip_atomic_store(p.tickets + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  splitk_reduce_tile<T>(p, rs, m0, MP, blockIdx.x * (WN * 64), WN * 64, reinterpret_cast<f32x4_t*>(lds));
+}
+
+// ---------------------------------------------------------------------------------------------
 // The default kernel: "tall" register tile -- one wave = ONE 64-column chunk x 16 MT rows
 // (MT = 1 for M <= 16, 2 up to 64, 4 beyond).
 //
@@ -568,7 +699,9 @@ __global__ __launch_bounds__(GT) void w4a16_gemm_kernel(const GemmParams p) {
 // ZP: per-(group, column) zero points (asymmetric AWQ / GPTQ checkpoints repacked to the Marlin
 // layout): p.zp holds z in the model dtype in the layout of the scales; they travel through LDS
 // with the scales (threads 32..63 stage them) and replace the constant 8 in the correction term.
-template <typename T, int MT, int WN, int WK, int GS, bool PS = false, int BITS = 4, bool ZP = false>
+// DBG (development builds with -DNMV_W4_ABLATION only): timing ablations -- 1 = no expansion / MFMA, 2 = no
+// activation loads and LDS stores (barriers stay), 4 = no group flush, 8 = no stage barrier; results are garbage
+template <typename T, int MT, int WN, int WK, int GS, bool PS = false, int BITS = 4, bool ZP = false, int DBG = 0>
 __global__ __launch_bounds__(GT, 2) void w4a16_gemm_tall_kernel(const GemmParams p) {
   static_assert(!ZP || (BITS == 4 && GS == 128), "zero points: 4-bit, group 128");
   static_assert(WN * WK == 4, "4 waves per workgroup");
@@ -744,6 +877,7 @@ __global__ __launch_bounds__(GT, 2) void w4a16_gemm_tall_kernel(const GemmParams
   __syncthreads();
   const uint4 ones = make_uint4(W4<T>::ONES, W4<T>::ONES, W4<T>::ONES, W4<T>::ONES);
 
+  uint32_t dbg_fold = 0;
   // one stage (U = position in the ring: buffer parity and the scale-group schedule are static):
   // fetch the activations of stage st+1 and the weights of stage st+3 (into the slot stage st-1
   // just released), multiply stage st, park stage st+1's activations, barrier
@@ -753,7 +887,7 @@ __global__ __launch_bounds__(GT, 2) void w4a16_gemm_tall_kernel(const GemmParams
     constexpr bool closes = (U + 1) % SPG == 0;   // last stage of a scale group
     // scale buffer of this stage's group: static for 2 groups per ring, else by ring parity
     const int gbuf = SPG == 2 ? ((U >> 1) & 1) : ((st >> 2) & 1);
-    load_a(st + 1, ar);
+    if constexpr (!(DBG & 2)) load_a(st + 1, ar);
     if constexpr (closes) scr = load_sc(st + 1);  // the next stage opens a group
     load_w(st + 3, wfree);
     __builtin_amdgcn_sched_barrier(0);
@@ -775,6 +909,11 @@ __global__ __launch_bounds__(GT, 2) void w4a16_gemm_tall_kernel(const GemmParams
             ps_z[j] = -zc * ps_s[j];
           }
         }
+      }
+      if constexpr (DBG & 1) {
+#pragma unroll
+        for (int h = 0; h < WV; ++h) dbg_fold ^= wc[ks * WV + h].x ^ wc[ks * WV + h].y ^ wc[ks * WV + h].z ^ wc[ks * WV + h].w;
+        continue;
       }
       uint4 af[MT];
 #pragma unroll
@@ -835,13 +974,19 @@ __global__ __launch_bounds__(GT, 2) void w4a16_gemm_tall_kernel(const GemmParams
       if constexpr (!PS) {
 #pragma unroll
         for (int t = 0; t < GT_; ++t) accs[t] = W4<T>::mfma(ones, af[t], first ? zero4 : accs[t]);
-        if (kstep == 3) flush(gbuf);
+        if constexpr (!(DBG & 4)) { if (kstep == 3) flush(gbuf); }
+        else if (kstep == 3) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int t = 0; t < GT_; ++t) accm[j][t] += accg[j][t];
+        }
       }
     }
     __builtin_amdgcn_sched_barrier(0);
-    store_a(buf ^ 1, ar);
+    if constexpr (!(DBG & 2)) store_a(buf ^ 1, ar);
     if constexpr (closes) store_sc(gbuf ^ 1, scr);
-    __syncthreads();
+    if constexpr (!(DBG & 8)) __syncthreads();
   };
   for (int st = 0; st < n_stages; st += 4) {
     stage(std::integral_constant<int, 0>{}, st, w0, w3);
@@ -850,125 +995,203 @@ __global__ __launch_bounds__(GT, 2) void w4a16_gemm_tall_kernel(const GemmParams
     stage(std::integral_constant<int, 3>{}, st + 3, w3, w2);
   }
 
-  // ---- channelwise scales are applied once, on the fp32 result ----
-  if (GS == 0 && chunk_ok) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-#pragma unroll
-      for (int reg = 0; reg < 4; ++reg) {
-        const int c64 = j * 16 + 4 * g + reg;
-        const int c = c64 & 31;
-        const int pos = (c64 >> 5) * 32 + ((c & 7) >> 1) * 8 + 2 * (c >> 3) + (c & 1);
-        const float sv = T::to_float(p.s[(int64_t)chunk * 64 + pos]);
-#pragma unroll
-        for (int t = 0; t < MT; ++t) accm[j][t][reg] *= sv;
-      }
-    }
-  }
+  if constexpr (DBG & 1) accm[0][0][0] += __uint_as_float(dbg_fold);
+  w4_tall_epilogue<T, MT, WN, WK, GS>(p, accm, lds, wn, wk, lane, r, g, chunk, chunk_ok, m0, split);
+}
 
-  // ---- cross-wave (intra-workgroup) k reduction ----
-  if constexpr (WK > 1) {
-    float* red = reinterpret_cast<float*>(lds);
-    __syncthreads();  // nobody reads the operand images any more
-    if (wk > 0) {
-      float* dst = red + (int64_t)((wk - 1) * WN + wn) * (4 * MT * 4) * 64;
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int t = 0; t < MT; ++t)
-#pragma unroll
-          for (int reg = 0; reg < 4; ++reg) dst[((j * MT + t) * 4 + reg) * 64 + lane] = accm[j][t][reg];
-    }
-    __syncthreads();
-    if (wk == 0) {
-#pragma unroll
-      for (int kk = 1; kk < WK; ++kk) {
-        const float* src = red + (int64_t)((kk - 1) * WN + wn) * (4 * MT * 4) * 64;
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int t = 0; t < MT; ++t)
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) accm[j][t][reg] += src[((j * MT + t) * 4 + reg) * 64 + lane];
-      }
-    }
-  }
-  const bool writer = (wk == 0) && chunk_ok;
+// ---------------------------------------------------------------------------------------------
+// The decode kernel for M <= 32 ("direct"): the tall kernel's wave tile (one 64-column chunk x 16 MT rows,
+// weights as the MFMA A operand, DPP pair exchange, exponent-trick expansion, fp32 group scaling) with
+// NOTHING shared on the operand path -- no LDS staging of the activations, no barrier in the main loop.
+//
+// Why: at M <= 16 the tall kernel spends ~70 VALU + 5 MFMA instructions per 1 KiB of weights and parks
+// 47 % of its wave-cycles (rocprofv3 PMC, profiles/r01_gemm_tall_pmc.txt): its activations go global ->
+// registers -> LDS (four scattered ds_write_b32 per 16 bytes, because the MFMA contraction slots follow the
+// Marlin k order {2g, 2g+1, 2g+8, 2g+9} x 2) behind one workgroup barrier per 64 k, so every wave waits for
+// the slowest wave's loads twenty times per kilobyte-row.  Here each lane loads its B operand straight from
+// the activation row in NATURAL order -- 16 bytes = k 8g .. 8g+7 of row r, the fragment-shaped load of the
+// int8 kernel (scaled_mm.hip), which streams at 4.8 TB/s -- and the four lanes (g = 0..3) that hold one row
+// transpose their 4 x 4 dwords in registers with v_permlane32_swap + v_permlane16_swap (4 VALU ops per
+// operand): lane g then holds pairs {g, g+4, g+8, g+12} = k {2g, 2g+1, 2g+8, 2g+9, 2g+16, ...}, the slot
+// order of the expanded weights.  Waves are independent: weights and activations of the next 128-k group
+// are requested while the current group is multiplied (two register sets, ping-pong), the group's scale
+// rows for the workgroup's whole k range are parked in LDS once, before the loop (one barrier per
+// launch).  Fewer live registers than the tall kernel at the same tile => more waves per SIMD to cover
+// the loads.  Every wave re-reads its activation rows from L2 (MT x the weight bytes), which is why this
+// form ends at 32 rows; beyond, the workgroup-shared LDS image of the tall kernel is the cheaper side.
+// Same numerics as the tall kernel: identical MFMA operands in identical order => bit-identical output.
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
 
-  // ---- epilogue ----
-  if (p.splits == 1 && p.epi != 2) {
-    if (!writer) return;
-    if (p.epi) {
-      // gate_up with silu_and_mul folded in: the weight columns were interleaved at load time so
-      // that a chunk holds gate[32 c .. 32 c + 31] in tiles 0, 1 and up[32 c .. 32 c + 31] in tiles
-      // 2, 3 -- the lane that holds a gate element holds its up element.  Same roundings as the two
-      // ops it replaces: both GEMM outputs rounded to the model dtype, silu in fp32 rounded to the
-      // model dtype (activation_kernels.cu:14-26), product rounded.
+// DBG (only with -DNMV_W4_ABLATION, a development build): 1 = no expansion / MFMA (the weight words are
+// folded into one register so that the loads stay), 2 = no activation loads, 4 = no group flush -- timing
+// ablations, results are garbage
+template <typename T, int MT, int WN, int WK, int GS, int DBG = 0>
+__global__ __launch_bounds__(64 * WN * WK) void w4a16_gemm_direct_kernel(const GemmParams p) {
+  constexpr int NW = WN * WK;                  // waves per workgroup: 4, or 8 (one chunk, eight k groups)
+  constexpr int NT = 64 * NW;
+  static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
+  static_assert(MT == 1 || MT == 2, "16 or 32 rows");
+  static_assert(GS == 0 || GS == 128, "group 128 or channelwise");
+  constexpr int MAXG = 16;                     // 128-k groups per wave (k range of a wave <= 2048)
+  constexpr int SC_U4 = NW * MAXG * 8;         // [wave slot][group][8 x 16 B]
+  constexpr int RED_U4 = (WK > 1) ? (WK - 1) * WN * MT * 256 : 0;
+  constexpr int LDS_U4 = SC_U4 > RED_U4 ? SC_U4 : (RED_U4 > NT ? RED_U4 : NT);
+  __shared__ __attribute__((aligned(16))) uint4 lds[LDS_U4];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wn = wave % WN, wk = wave / WN;
+  const int r = lane & 15, g = lane >> 4;
+  const int blk = r >> 3, n_in = r & 7;
+  const int n_chunks = p.N >> 6;
+  const int chunk = blockIdx.x * WN + wn;
+  const bool chunk_ok = chunk < n_chunks;
+  const int m0 = blockIdx.z * (16 * MT);
+  const int split = blockIdx.y;
+  const int k_wg0 = split * p.k_per_wg;
+  const int k_wg1 = min(k_wg0 + p.k_per_wg, p.K);
+  const int k_per_wave = (k_wg1 - k_wg0) / WK;      // an even number of 128-k groups (make_plan)
+  const int k_w0 = k_wg0 + wk * k_per_wave;
+  const int gpw = __builtin_amdgcn_readfirstlane(k_per_wave >> 7);
+  const int g_last = gpw - 1;
+
+  // ---- weights: lane (blk, n_in, q = g) streams vector n_in*4+q of k-tile 2 ks + blk (as the tall kernel)
+  const int64_t row_u4 = (int64_t)(p.N >> 1);
+  const uint4* bp = p.b + ((int64_t)(chunk_ok ? chunk : 0) * 32 + (n_in * 4 + g)) +
+                    ((int64_t)(k_w0 >> 4) + blk) * row_u4;
+  // ---- activations: lane (r, g) reads k 8g .. 8g+7 of row m0 + 16 t + r (rows past M: clamped duplicates
+  // that only feed rows which are never stored)
+  const uint16_t* ap[MT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t)
+    ap[t] = p.a + (int64_t)min(m0 + 16 * t + r, p.M - 1) * p.K + k_w0 + 8 * g;
+
+  auto load_group = [&](int grp, uint4 (&w)[4], uint4 (&a)[4][MT]) {
+    const int gi = min(grp, g_last);           // the look-ahead past the end re-reads the last group
+    const uint4* q = bp + (int64_t)gi * (8 * row_u4);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) w[ks] = q[ks * 2 * row_u4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
       for (int t = 0; t < MT; ++t) {
-        const int m = m0 + t * 16 + r;
-        if (m >= p.M) continue;
+        if constexpr (DBG & 2) a[ks][t] = make_uint4(W4<T>::ONES, W4<T>::ONES, W4<T>::ONES, W4<T>::ONES);
+        else a[ks][t] = ld16(ap[t] + gi * 128 + ks * 32);
+      }
+  };
+  uint32_t dbg_fold = 0;
+
+  const uint32_t kmask = __builtin_amdgcn_readfirstlane(W4<T>::MASK);
+  uint32_t kmagic = W4<T>::MAGIC;
+  asm volatile("" : "+v"(kmagic));
+  const uint32_t rot_lo = blk ? W4<T>::ROT_LO1 : W4<T>::ROT_LO0;
+  const uint32_t rot_hi = blk ? W4<T>::ROT_HI1 : W4<T>::ROT_HI0;
+  const uint4 ones = make_uint4(W4<T>::ONES, W4<T>::ONES, W4<T>::ONES, W4<T>::ONES);
+
+  f32x4_t accm[4][MT], accg[4][MT], accs[MT];
+  const f32x4_t zero4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          float o[4];
+  for (int j = 0; j < 4; ++j)
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const float gb = round_trip<T>(accm[j][t][i]), ub = round_trip<T>(accm[j + 2][t][i]);
-            o[i] = round_trip<T>(gb / (1.0f + expf(-gb))) * ub;
-          }
-          uint2 pk;
-          pk.x = T::pack2(o[0], o[1]);
-          pk.y = T::pack2(o[2], o[3]);
-          *reinterpret_cast<uint2*>(p.c + (int64_t)m * (p.N >> 1) + chunk * 32 + j * 16 + 4 * g) = pk;
+    for (int t = 0; t < MT; ++t) { accm[j][t] = zero4; accg[j][t] = zero4; }
+#pragma unroll
+  for (int t = 0; t < MT; ++t) accs[t] = zero4;
+
+  // output fragment of this lane: columns chunk*64 + 16 j + 4 g + reg; grouped scale layout: element
+  // (4 (g&1) + reg) * 8 + 2 j + (g >> 1) of the chunk's 64 (marlin_permute_scales)
+  const uint32_t sc_shift = (g >> 1) * 16;
+  const uint4* sc_mine = lds + (wk * WN + wn) * (MAXG * 8) + (g & 1) * 4;
+  auto flush = [&](int grp) {
+    float zs[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) zs[t] = -W4_ZP * accs[t][0];
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      uint4 d4 = make_uint4(0, 0, 0, 0);
+      if constexpr (GS != 0) d4 = sc_mine[grp * 8 + reg];
+      const uint32_t d[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float scv = 1.f;
+        if constexpr (GS != 0) scv = T::to_float((uint16_t)(d[j] >> sc_shift));
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+          const float dlt = accg[j][t][reg] + zs[t];
+          if constexpr (GS != 0) accm[j][t][reg] = fmaf(scv, dlt, accm[j][t][reg]);
+          else accm[j][t][reg] += dlt;
         }
+      }
+    }
+  };
+
+  auto compute_group = [&](int grp, const uint4 (&w)[4], const uint4 (&a)[4][MT]) {
+    if constexpr (DBG & 1) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        dbg_fold ^= w[ks].x ^ w[ks].y ^ w[ks].z ^ w[ks].w;
+#pragma unroll
+        for (int t = 0; t < MT; ++t) dbg_fold ^= a[ks][t].x ^ a[ks][t].w;
       }
       return;
     }
 #pragma unroll
-    for (int t = 0; t < MT; ++t) {
-      const int m = m0 + t * 16 + r;
-      if (m >= p.M) continue;
+    for (int ks = 0; ks < 4; ++ks) {
+      // B operands: 4 x 4 dword transpose across the four lanes (g) of a row
+      uint4 af[MT];
+#pragma unroll
+      for (int t = 0; t < MT; ++t) {
+        u32x2_t s0 = __builtin_amdgcn_permlane32_swap(a[ks][t].x, a[ks][t].z, false, false);
+        u32x2_t s1 = __builtin_amdgcn_permlane32_swap(a[ks][t].y, a[ks][t].w, false, false);
+        u32x2_t t0 = __builtin_amdgcn_permlane16_swap(s0[0], s1[0], false, false);
+        u32x2_t t1 = __builtin_amdgcn_permlane16_swap(s0[1], s1[1], false, false);
+        af[t] = make_uint4(t0[0], t0[1], t1[0], t1[1]);
+      }
+      const uint32_t own[4] = {w[ks].x, w[ks].y, w[ks].z, w[ks].w};
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const int n = chunk * 64 + j * 16 + 4 * g;
-        const f32x4_t o = accm[j][t];
-        uint2 pk;
-        pk.x = T::pack2(o[0], o[1]);
-        pk.y = T::pack2(o[2], o[3]);
-        *reinterpret_cast<uint2*>(p.c + (int64_t)m * p.N + n) = pk;
-      }
-    }
-    return;
-  }
-  // split-K across workgroups: sc1 slabs, ticket, the last workgroup of the tile reduces (see above)
-  const int64_t slab_bytes = (int64_t)p.splits * p.M * p.N * 4;
-  __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p.slab, 0, (int)slab_bytes, 0x00020000);
-  if (writer) {
+        const uint32_t e = (uint32_t)__builtin_amdgcn_update_dpp((int)own[j], (int)own[j], 0x128, 0xf, 0xc, false);
+        const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp((int)own[j], (int)own[j], 0x128, 0xf, 0x3, false);
+        const uint4 wv = make_uint4(and_or(__builtin_amdgcn_alignbit(e, e, rot_lo), kmask, kmagic),
+                                    and_or(__builtin_amdgcn_alignbit(e, e, rot_hi), kmask, kmagic),
+                                    and_or(__builtin_amdgcn_alignbit(o, o, rot_lo), kmask, kmagic),
+                                    and_or(__builtin_amdgcn_alignbit(o, o, rot_hi), kmask, kmagic));
 #pragma unroll
-    for (int t = 0; t < MT; ++t) {
-      const int m = m0 + t * 16 + r;
-      if (m >= p.M) continue;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int n = chunk * 64 + j * 16 + 4 * g;
-        const int off = (int)((((int64_t)split * p.M + m) * p.N + n) * 4);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, accm[j][t]), rs, off, 0, 16);
+        for (int t = 0; t < MT; ++t) accg[j][t] = W4<T>::mfma(wv, af[t], ks == 0 ? zero4 : accg[j][t]);
       }
+#pragma unroll
+      for (int t = 0; t < MT; ++t) accs[t] = W4<T>::mfma(ones, af[t], ks == 0 ? zero4 : accs[t]);
+    }
+    if constexpr (!(DBG & 4)) flush(grp);
+    else
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int t = 0; t < MT; ++t) accm[j][t] += accg[j][t];
+  };
+
+  // ---- prologue: first group's operands, then the scale rows of the workgroup's k range -> LDS ----
+  uint4 wA[4], wB[4];
+  uint4 aA[4][MT], aB[4][MT];
+  load_group(0, wA, aA);
+  if constexpr (GS != 0) {
+    for (int id = threadIdx.x; id < NW * gpw * 8; id += NT) {
+      const int piece = id & 7, slot = (id >> 3) % NW, grp = id / (8 * NW);
+      const int s_chunk = min(blockIdx.x * WN + (slot % WN), n_chunks - 1);
+      const int k_abs = k_wg0 + (slot / WN) * k_per_wave + grp * 128;
+      lds[(slot * MAXG + grp) * 8 + piece] =
+          ld16(p.s + (int64_t)(k_abs >> 7) * p.N + (int64_t)s_chunk * 64 + piece * 8);
     }
   }
-  if (p.epi == 2) return;  // deferred: the next kernel in the stream sums the slabs (kernel boundary = release)
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __shared__ int ticket_s;
   __syncthreads();
-  const int tile = blockIdx.z * gridDim.x + blockIdx.x;
-  if (threadIdx.x == 0)
-    ticket_s = __hip_atomic_fetch_add(p.tickets + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __syncthreads();
-  if (ticket_s != p.splits - 1) return;
-  if (threadIdx.x == 0)
-    __hip_atomic_store(p.tickets + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __syncthreads();
-  splitk_reduce_tile<T>(p, rs, m0, MP, blockIdx.x * (WN * 64), WN * 64, reinterpret_cast<f32x4_t*>(lds));
+
+  for (int grp = 0; grp < gpw; grp += 2) {
+    load_group(grp + 1, wB, aB);
+    compute_group(grp, wA, aA);
+    load_group(grp + 2, wA, aA);
+    compute_group(grp + 1, wB, aB);
+  }
+  if constexpr (DBG & 1) accm[0][0][0] += __uint_as_float(dbg_fold);
+  w4_tall_epilogue<T, MT, WN, WK, GS>(p, accm, lds, wn, wk, lane, r, g, chunk, chunk_ok, m0, split);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1043,6 +1266,7 @@ struct GemmPlan {
   int mt, wn, wm, wk;  // kernel shape
   int splits, k_per_wg, m_blocks, n_blocks;
   int tall;      // 1: tall register tile (64 columns x 16 mt rows per wave); wn, wk, mt say which
+  int direct;    // 1 (with tall): the barrier-free decode form of the tall tile (M <= 32)
 };
 
 static int env_int(const char* name, int dflt) {
@@ -1054,10 +1278,43 @@ static int env_int(const char* name, int dflt) {
 // few microseconds at HBM speed, so the plan aims at >= ~2 workgroups per CU while keeping the
 // fp32 partial traffic (splits * M * N * 4 B) well below the weight bytes (K * N / 2).
 static GemmPlan make_plan(int M, int N, int K, int64_t tickets_len, bool allow_tall = false,
-                          int bits = 4, bool unsplit = false) {
+                          int bits = 4, bool unsplit = false, bool has_zp = false) {
   GemmPlan pl;
   const int n_chunks = N / 64;
   pl.tall = 0;
+  pl.direct = 0;
+  // M <= 32, 4-bit symmetric: the direct kernel (w4a16_gemm_direct_kernel) -- same tile, no LDS on the
+  // operand path.  A wave's k range is an even number of 128-k groups (ping-pong register sets) and at
+  // most 2048 (its scale rows live in LDS).
+  if (allow_tall && bits == 4 && !has_zp && M <= 32 && K % 256 == 0 && env_int("NMV_W4_DIRECT", 0)) {
+    int wk = env_int("NMV_W4_DIRECT_WK", 4);
+    while (wk > 1 && K % (256 * wk) != 0) wk >>= 1;
+    const int unit = 256 * wk;
+    const int k_units = K / unit;
+    pl.tall = 1;
+    pl.direct = 1;
+    pl.wm = 1;
+    pl.mt = M <= 16 ? 1 : 2;
+    pl.m_blocks = 1;
+    pl.wk = wk;
+    pl.wn = wk >= 4 ? 1 : 4 / wk;
+    pl.n_blocks = (n_chunks + pl.wn - 1) / pl.wn;
+    int splits = std::max(1, env_int("NMV_W4_DIRECT_WGS", 512) / pl.n_blocks);
+    splits = std::min(splits, env_int("NMV_W4_DIRECT_MAX_SPLITS", 8));
+    splits = env_int("NMV_W4_SPLITS", splits);
+    splits = std::max(1, std::min(splits, k_units));
+    if ((int64_t)pl.n_blocks > tickets_len || unsplit) splits = 1;
+    const int min_splits = (K + 2048 * wk - 1) / (2048 * wk);
+    if (min_splits > 1 && ((int64_t)pl.n_blocks > tickets_len || unsplit)) {
+      pl.direct = 0;  // a wave's k range would exceed the scale rows the kernel keeps in LDS
+    } else {
+      splits = std::max(splits, min_splits);
+      pl.k_per_wg = ((k_units + splits - 1) / splits) * unit;
+      pl.splits = (K + pl.k_per_wg - 1) / pl.k_per_wg;
+      return pl;
+    }
+    pl.tall = 0;
+  }
   // K in whole 256-k rings per wave, group 128 / channelwise, no act-order: the tall register
   // tile (measured faster than the kernels below at every M on the Llama-3-8B shapes)
   if (allow_tall && M >= env_int("NMV_W4_TALL_MIN_M", 1) && K % 256 == 0 && env_int("NMV_W4_TALL", 1)) {
@@ -1152,6 +1409,52 @@ static int launch_gemm_gs(const GemmPlan& pl, const GemmParams& p, hipStream_t s
         return -1;
       }
     }
+    if (pl.tall && pl.direct) {
+      // the last-arriver reduction of the shared epilogue is written for 256-thread workgroups: the
+      // 8-wave form runs unsplit or with deferred reduction only
+      if (pl.wn * pl.wk == 8 && pl.splits > 1 && p.epi != 2) return -1;
+#ifdef NMV_W4_ABLATION
+      if constexpr (GS == 128 && std::is_same<T, BF16>::value) {
+        const int dbg = env_int("NMV_W4_DBG", 0);
+#define NMV_W4_DBG_CASE(wk_, dbg_)                                                                               \
+  if (dbg == dbg_ && pl.mt == 1 && pl.wn == 1 && pl.wk == wk_) {                                                 \
+    hipLaunchKernelGGL((w4a16_gemm_direct_kernel<T, 1, 1, wk_, GS, dbg_>), grid, dim3(64 * wk_), 0, s, p);         \
+    return 0;                                                                                                    \
+  }
+        NMV_W4_DBG_CASE(4, 1) NMV_W4_DBG_CASE(4, 2) NMV_W4_DBG_CASE(4, 3) NMV_W4_DBG_CASE(4, 4) NMV_W4_DBG_CASE(4, 6)
+        NMV_W4_DBG_CASE(8, 1) NMV_W4_DBG_CASE(8, 2) NMV_W4_DBG_CASE(8, 3) NMV_W4_DBG_CASE(8, 4) NMV_W4_DBG_CASE(8, 6)
+#undef NMV_W4_DBG_CASE
+      }
+#endif
+#define NMV_W4_DIRECT_CASE(mt_, wn_, wk_)                                                        \
+  if (pl.mt == mt_ && pl.wn == wn_ && pl.wk == wk_) {                                            \
+    hipLaunchKernelGGL((w4a16_gemm_direct_kernel<T, mt_, wn_, wk_, GS>), grid, dim3(64 * wn_ * wk_), 0, s, p);  \
+    return 0;                                                                                    \
+  }
+      NMV_W4_DIRECT_CASE(1, 4, 1) NMV_W4_DIRECT_CASE(1, 2, 2) NMV_W4_DIRECT_CASE(1, 1, 4) NMV_W4_DIRECT_CASE(1, 1, 8)
+      NMV_W4_DIRECT_CASE(2, 4, 1) NMV_W4_DIRECT_CASE(2, 2, 2) NMV_W4_DIRECT_CASE(2, 1, 4) NMV_W4_DIRECT_CASE(2, 1, 8)
+#undef NMV_W4_DIRECT_CASE
+      return -1;
+    }
+#ifdef NMV_W4_ABLATION
+    if constexpr (GS == 128 && std::is_same<T, BF16>::value) {
+      const int dbg = env_int("NMV_W4_DBG", 0);
+      if (pl.tall && dbg && p.bits == 4 && p.zp == nullptr) {
+#define NMV_W4_TDBG_CASE(mt_, wn_, wk_, dbg_)                                                                    \
+  if (dbg == dbg_ && pl.mt == mt_ && pl.wn == wn_ && pl.wk == wk_) {                                             \
+    hipLaunchKernelGGL((w4a16_gemm_tall_kernel<T, mt_, wn_, wk_, GS, false, 4, false, dbg_>), grid, block, 0, s, p); \
+    return 0;                                                                                                    \
+  }
+#define NMV_W4_TDBG_ALL(mt_, wn_, wk_)                                                                           \
+  NMV_W4_TDBG_CASE(mt_, wn_, wk_, 1) NMV_W4_TDBG_CASE(mt_, wn_, wk_, 2) NMV_W4_TDBG_CASE(mt_, wn_, wk_, 4)        \
+  NMV_W4_TDBG_CASE(mt_, wn_, wk_, 6) NMV_W4_TDBG_CASE(mt_, wn_, wk_, 10) NMV_W4_TDBG_CASE(mt_, wn_, wk_, 14)     \
+  NMV_W4_TDBG_CASE(mt_, wn_, wk_, 15)
+        NMV_W4_TDBG_ALL(1, 1, 4) NMV_W4_TDBG_ALL(2, 2, 2) NMV_W4_TDBG_ALL(2, 1, 4) NMV_W4_TDBG_ALL(4, 2, 2) NMV_W4_TDBG_ALL(4, 1, 4)
+#undef NMV_W4_TDBG_ALL
+#undef NMV_W4_TDBG_CASE
+      }
+    }
+#endif
     if (pl.tall) {
 #define NMV_W4_TALL_CASE(mt_, wn_, wk_)                                                        \
   if (pl.mt == mt_ && pl.wn == wn_ && pl.wk == wk_) {                                          \
@@ -1291,7 +1594,7 @@ static int marlin_gemm_impl(void* c, const void* a, const int32_t* b_q_weight, c
   const bool allow_tall = !has_act_order && (group_size == 0 || group_size == 128);
   const GemmPlan pl = make_plan(size_m, size_n, size_k,
                                 epi == 2 ? INT64_MAX : (workspace ? workspace_len : 0), allow_tall,
-                                num_bits, epi == 1);
+                                num_bits, epi == 1, b_zeros != nullptr);
   NMV_CHECK(epi != 2 || (pl.tall && num_bits == 4 && b_zeros == nullptr),
             "gptq_marlin_gemm_partial: needs 4-bit symmetric codes, group 128 or channelwise, no "
             "act-order, K %% 256 == 0");

@@ -166,9 +166,12 @@ class CompressedTensorsConfig(QuantizationConfig):
     """Parses the `config_groups` of a compressed-tensors quantization_config for Linear targets
     (compressed_tensors.py:26-209)."""
 
-    def __init__(self, layer_quant_details: Dict[str, Any], ignore: List[str]):
+    def __init__(self, layer_quant_details: Dict[str, Any], ignore: List[str], quant_format: Optional[str] = None):
         self.ignore = ignore
         self.layer_quant_details = layer_quant_details
+        # the checkpoint's `format` selects the scheme family as in the reference (compressed_tensors.py
+        # :132-160): "int-quantized" -> W8A8, "pack-quantized" -> WNA16 ("marlin-24": 2:4 sparse, not built)
+        self.quant_format = quant_format
 
     def get_name(self) -> str:
         return "compressed_tensors"
@@ -195,17 +198,19 @@ class CompressedTensorsConfig(QuantizationConfig):
             for target in quant_config.get("targets"):
                 layer_quant_details[target] = {"weights": quant_config.get("weights"),
                                                "input_activations": quant_config.get("input_activations")}
-        return cls(layer_quant_details=layer_quant_details, ignore=ignore)
+        return cls(layer_quant_details=layer_quant_details, ignore=ignore, quant_format=config.get("format"))
 
     def _get_schema(self, weight_quant: Dict[str, Any], input_quant: Optional[Dict[str, Any]]):
         wbits, wtype = weight_quant.get("num_bits"), weight_quant.get("type", "int")
         wstrategy = weight_quant.get("strategy", "tensor")
         symmetric = weight_quant.get("symmetric", True)
         if input_quant is None:
-            if wtype == "int" and wbits in (4, 8) and symmetric and wstrategy in ("group", "channel"):
+            if self.quant_format == "pack-quantized" and wtype == "int" and wbits in (4, 8) and symmetric \
+                    and wstrategy in ("group", "channel") and not weight_quant.get("dynamic", False):
                 return CompressedTensorsWNA16(wstrategy, wbits, weight_quant.get("group_size"))
-            raise NotImplementedError("unsupported weight-only compressed-tensors scheme")
-        if wbits == 8 and input_quant.get("num_bits") == 8 and wtype == "int" and symmetric \
+            raise NotImplementedError("No compressed-tensors compatible scheme was found.")
+        if self.quant_format == "int-quantized" and wbits == 8 and input_quant.get("num_bits") == 8 \
+                and wtype == "int" and symmetric and input_quant.get("symmetric", True) \
                 and wstrategy in ("tensor", "channel"):
             dynamic = bool(input_quant.get("dynamic", False))
             if not dynamic and input_quant.get("strategy", "tensor") != "tensor":

@@ -264,6 +264,9 @@ class LlamaForCausalLM(nn.Module):
         # bf16 unless quant_config.lm_head_quantized (gptq_marlin.py:151-157)
         self.lm_head = ParallelLMHead(self.unpadded_vocab_size, config.hidden_size,
                                       org_num_embeddings=config.vocab_size)
+        self.tie_word_embeddings = bool(getattr(config, "tie_word_embeddings", False))
+        if self.tie_word_embeddings:
+            self.lm_head.weight = self.model.embed_tokens.weight   # llama.py:385-386
         self.logits_processor = LogitsProcessor(self.unpadded_vocab_size, config.vocab_size,
                                                 getattr(config, "logit_scale", 1.0))
 
@@ -277,26 +280,43 @@ class LlamaForCausalLM(nn.Module):
 
     def load_weights(self, weights: Iterable[Tuple[str, torch.Tensor]]):
         """stacked-parameter mapping of the reference (llama.py:391-460): q/k/v -> qkv_proj,
-        gate/up -> gate_up_proj; everything else by name."""
+        gate/up -> gate_up_proj; `.kv_scale` -> `.attn.kv_scale` (:470-481); everything else by name.
+        Unlike the reference this loader is strict: a parameter that no tensor of the checkpoint wrote
+        raises (a tied-embedding checkpoint without lm_head.weight is served by the tie below, :385-386)."""
         stacked = [(".qkv_proj", ".q_proj", "q"), (".qkv_proj", ".k_proj", "k"),
                    (".qkv_proj", ".v_proj", "v"), (".gate_up_proj", ".gate_proj", 0),
                    (".gate_up_proj", ".up_proj", 1)]
         params = dict(self.named_parameters())
+        written = {}
         for name, loaded in weights:
             if "rotary_emb.inv_freq" in name:
                 continue
+            if self.tie_word_embeddings and name == "lm_head.weight":
+                continue   # tied: the embedding's tensor is the head's
             for pname, wname, shard_id in stacked:
                 if wname not in name:
                     continue
                 name = name.replace(wname, pname)
+                if name.endswith(".bias") and name not in params:
+                    break  # extra bias of GPTQ exports (llama.py:453-455)
                 if name not in params:
-                    break
+                    raise ValueError(f"checkpoint tensor {name} has no parameter in the model")
                 param = params[name]
                 param.weight_loader(param, loaded, shard_id)
+                written.setdefault(name, set()).add(shard_id)
                 break
             else:
-                if name not in params:
+                if name.endswith(".bias") and name not in params:
                     continue
+                if name.endswith("kv_scale"):
+                    # fp8 checkpoints: the KV-cache scaling factor lives on the Attention layer
+                    remapped = name.replace(".kv_scale", ".attn.kv_scale")
+                    if remapped not in params:
+                        raise ValueError(f"checkpoint carries {name} but the model has no {remapped}: "
+                                         "load it with an fp8 quantisation config (Fp8KVCacheMethod)")
+                    name = remapped
+                if name not in params:
+                    raise ValueError(f"checkpoint tensor {name} has no parameter in the model")
                 param = params[name]
                 loader = getattr(param, "weight_loader", None)
                 if loader is not None:
@@ -304,3 +324,17 @@ class LlamaForCausalLM(nn.Module):
                 else:
                     assert param.shape == loaded.shape, name
                     param.data.copy_(loaded)
+                written.setdefault(name, set()).add(None)
+        need = {".qkv_proj": {"q", "k", "v"}, ".gate_up_proj": {0, 1}}
+        missing = []
+        for name, prm in params.items():
+            if prm.device.type == "meta" or (self.tie_word_embeddings and name == "lm_head.weight"):
+                continue
+            if name.endswith(("g_idx", "g_idx_sort_indices", "workspace", "qzeros", "kv_scale", "input_scale")):
+                continue   # optional in checkpoints / created by the method itself
+            want = next((v for k, v in need.items() if k in name), {None})
+            if not want <= written.get(name, set()):
+                missing.append(name)
+        if missing:
+            raise ValueError(f"checkpoint left {len(missing)} parameter(s) unwritten: {missing[:6]}"
+                             f"{' ...' if len(missing) > 6 else ''}")

@@ -44,6 +44,7 @@ class LlamaArch:
     max_position_embeddings: int = 8192
     hidden_act: str = "silu"
     rope_scaling: Optional[dict] = None
+    tie_word_embeddings: bool = False
 
     @property
     def head_dim(self):
@@ -145,10 +146,14 @@ class DecodeRunner:
                          cfg["num_attention_heads"], cfg.get("num_key_value_heads", cfg["num_attention_heads"]),
                          cfg["vocab_size"], cfg.get("rms_norm_eps", 1e-5), cfg.get("rope_theta", 10000.0),
                          cfg.get("max_position_embeddings", 8192), cfg.get("hidden_act", "silu"),
-                         cfg.get("rope_scaling"))
+                         cfg.get("rope_scaling"), bool(cfg.get("tie_word_embeddings", False)))
         if dtype is None:
-            dtype = {"bfloat16": torch.bfloat16, "float16": torch.float16}.get(str(cfg.get("torch_dtype")),
-                                                                               torch.bfloat16)
+            # config.py:_get_and_verify_dtype: fp32 checkpoints are served in fp16, fp16 / bf16 as they are
+            td = str(cfg.get("torch_dtype", "float16")).replace("torch.", "")
+            known = {"bfloat16": torch.bfloat16, "float16": torch.float16, "float32": torch.float16}
+            if td not in known:
+                raise ValueError(f"config.json: unsupported torch_dtype {td!r} (float16 / bfloat16 / float32)")
+            dtype = known[td]
         return cls(arch, device, dtype, None, cache_config, weights=ml.safetensors_weights_iterator(model_dir),
                    quant_config=ml.build_quant_config(model_dir, cfg))
 
@@ -167,6 +172,7 @@ class DecodeRunner:
         elif quant is not None and quant.get("method") == "w8a8":
             # BASELINE.json configs[3]: int8 weights (per channel) x int8 activations (dynamic per token)
             quant_config = get_quantization_config("compressed-tensors").from_config({
+                "format": "int-quantized",
                 "config_groups": {"group_0": {
                     "targets": ["Linear"],
                     "weights": dict(num_bits=8, type="int", strategy="channel", symmetric=True, dynamic=False),

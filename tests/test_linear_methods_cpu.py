@@ -10,12 +10,39 @@ import torch
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "linear_method_params.json")
 KEEP = ("input_dim", "output_dim", "packed_dim", "pack_factor", "marlin_tile_size",
         "needs_scalar_to_array")
+# the tables tools/make_golden_w8a8.py adds keep a few more attributes
+KEEP_W8A8 = KEEP + ("logical_widths", "ignore_warning", "shard_splitter", "use_bits_and_bytes")
+
+
+def _ct(weights, acts):
+    return {"config_groups": {"group_0": {"targets": ["Linear"], "weights": weights, "input_activations": acts}},
+            "format": "int-quantized" if acts is not None else "pack-quantized", "ignore": ["lm_head"]}
+
+
+_W8 = dict(num_bits=8, type="int", symmetric=True, strategy="tensor", dynamic=False)
+_W8C = dict(num_bits=8, type="int", symmetric=True, strategy="channel", dynamic=False)
 CFGS = {
     "gptq_marlin": ("gptq_marlin", dict(bits=4, group_size=128, desc_act=False, sym=True), torch.bfloat16),
     "gptq_marlin_act_order": ("gptq_marlin", dict(bits=4, group_size=128, desc_act=True, sym=True), torch.bfloat16),
     "gptq": ("gptq", dict(bits=4, group_size=128, desc_act=False), torch.float16),
     "awq": ("awq", dict(w_bit=4, q_group_size=128, zero_point=True), torch.bfloat16),
+    "fp8_static": ("fp8", dict(quant_method="fp8", activation_scheme="static"), torch.bfloat16),
+    "fp8_dynamic": ("fp8", dict(quant_method="fp8", activation_scheme="dynamic"), torch.bfloat16),
+    "marlin": ("marlin", dict(group_size=128), torch.float16),
+    "ct_w8a8_static": ("compressed-tensors",
+                       _ct(_W8, dict(num_bits=8, type="int", symmetric=True, strategy="tensor", dynamic=False)),
+                       torch.bfloat16),
+    "ct_w8a8_dynamic_token": ("compressed-tensors",
+                              _ct(_W8C, dict(num_bits=8, type="int", symmetric=True, strategy="token", dynamic=True)),
+                              torch.bfloat16),
+    "ct_w4a16_g128": ("compressed-tensors",
+                      _ct(dict(num_bits=4, type="int", symmetric=True, strategy="group", group_size=128,
+                               dynamic=False), None), torch.bfloat16),
+    "ct_w8a16_channel": ("compressed-tensors",
+                         _ct(dict(num_bits=8, type="int", symmetric=True, strategy="channel", dynamic=False), None),
+                         torch.bfloat16),
 }
+OLD_TABLES = ("gptq_marlin", "gptq_marlin_act_order", "gptq", "awq")
 
 
 @pytest.mark.parametrize("name", sorted(CFGS))
@@ -36,10 +63,27 @@ def test_parameter_tables_match_reference(name):
     lm.create_weights(layer, 4096, [4096, 1024, 1024], 4096, 6144, dtype, weight_loader=None)
     got = {}
     for pname, prm in layer.named_parameters():
-        attrs = {k: (str(getattr(prm, k)) if k == "pack_factor" else getattr(prm, k))
-                 for k in KEEP if hasattr(prm, k)}
+        attrs = {}
+        for k in (KEEP if name in OLD_TABLES else KEEP_W8A8):
+            if hasattr(prm, k):
+                v = getattr(prm, k)
+                attrs[k] = str(v) if k == "pack_factor" else (v if isinstance(v, (int, bool, list, type(None)))
+                                                              else type(v).__name__)
         got[pname] = dict(shape=list(prm.shape), dtype=str(prm.dtype), device=prm.device.type, attrs=attrs)
-    assert got == gold
+    assert got == gold, {k: (got.get(k), gold.get(k)) for k in set(got) | set(gold) if got.get(k) != gold.get(k)}
+
+
+def test_every_reference_table_is_checked():
+    assert sorted(json.load(open(GOLD))) == sorted(CFGS)
+
+
+def test_pack_fp8_to_int32_matches_reference():
+    """fp8.py's host-side packer (marlin_utils.py:227-247) against the reference's output"""
+    import numpy as np
+    from neural_magic_vllm_amd.model_executor.layers.quantization.fp8 import pack_fp8_to_int32
+    g = np.load(os.path.join(os.path.dirname(GOLD), "fp8_quant.npz"))
+    w = torch.from_numpy(g["pack_in"].copy()).view(torch.float8_e4m3fn)
+    assert torch.equal(pack_fp8_to_int32(w), torch.from_numpy(g["pack_out"]))
 
 
 def test_registry_and_configs():
@@ -54,6 +98,7 @@ def test_registry_and_configs():
     assert not gm.is_marlin_compatible(dict(bits=3, group_size=128, sym=True, desc_act=False))
     assert gm.override_quantization_method(dict(bits=4, group_size=128, sym=True, desc_act=True), None) == "gptq_marlin"
     ct = get_quantization_config("compressed-tensors").from_config({
+        "format": "int-quantized",
         "config_groups": {"g0": {"targets": ["Linear"],
                                  "weights": {"num_bits": 8, "type": "int", "symmetric": True, "strategy": "channel"},
                                  "input_activations": {"num_bits": 8, "type": "int", "dynamic": True, "strategy": "token"}}}})

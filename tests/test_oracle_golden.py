@@ -150,3 +150,34 @@ def test_gemm_oracle_matches_a_at_w_ref(name):
     c = oracle.gptq_marlin_gemm(a, torch.from_numpy(g["marlin_q_w"]), ms, None, None, bits, 13, n, k)
     ref = (a.float() @ w_ref.float())
     assert ref_math.compute_max_diff(c, ref) < 1e-3
+
+
+# ---------------------------------------------------------------------------------------------
+# tests/ref_llama.py (the fp32 torch model the GPU end-to-end tests compare with) pinned to the
+# REFERENCE's own LlamaForCausalLM run on CPU (tests/golden/tiny_llama_*.npz, tools/make_golden_model.py)
+@pytest.mark.parametrize("case", ["bf16", "w4a16"])
+def test_ref_llama_pinned_to_reference_model(case):
+    import types
+    from ref_llama import RefLlama
+    g = gold(f"tiny_llama_{case}")
+    ckpt = helpers.tiny_llama_checkpoint(int(g["seed"]), BF16)
+    assert helpers.tensor_sha(*[ckpt[k] for k in sorted(ckpt)]) == str(g["ckpt_sha"]), "checkpoint recipe drifted"
+    weights = helpers.gptq_checkpoint_from_dense(ckpt, 4, 128) if case == "w4a16" else ckpt
+    a = helpers.TINY_LLAMA
+    arch = types.SimpleNamespace(**a, head_dim=a["hidden_size"] // a["num_attention_heads"])
+    ref = RefLlama(arch, weights)
+    prompts = torch.from_numpy(g["prompts"])
+    tokens = torch.from_numpy(g["tokens"])
+    steps = int(g["steps"])
+    # the reference ran bf16 end to end, ref_llama keeps fp32 activations: bf16-level agreement (3e-2 of
+    # the mean |logit|, the tolerance the GPU end-to-end tests state)
+    for b in range(prompts.shape[0]):
+        seq = prompts[b].tolist()
+        for s in range(steps + 1):
+            logits = ref.forward(torch.tensor(seq))[-1]
+            want = torch.from_numpy(g["prompt_logits"][b] if s == 0 else g["step_logits"][s - 1][b])
+            rel = ((logits - want).abs().mean() / want.abs().mean()).item()
+            assert rel < 3e-2, (case, b, s, rel)
+            if float(g["top2_margin"][s][b]) > 4 * float((logits - want).abs().max()):
+                assert int(logits.argmax()) == int(tokens[s][b]), (case, b, s)
+            seq.append(int(tokens[s][b]))   # teacher forcing with the reference's tokens

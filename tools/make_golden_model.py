@@ -119,7 +119,14 @@ def gen_tiny_llama():
                       rms_norm_eps=a["rms_norm_eps"], rope_theta=a["rope_theta"],
                       max_position_embeddings=a["max_position_embeddings"], hidden_act="silu",
                       tie_word_embeddings=False)
-    cfg.rope_scaling = None   # transformers >= 4.4x fills in {"rope_type": "default"}; the 0.5.1 reader wants "type"
+    # newer transformers keep rope_theta / rope_scaling inside `rope_parameters`; the 0.5.1 reader wants
+    # the flat attributes (llama.py:183-189 reads them with getattr defaults: a missing rope_theta would
+    # silently become 10000)
+    cfg.rope_scaling = None
+    cfg.rope_theta = a["rope_theta"]
+    for k in ("hidden_size", "intermediate_size", "num_hidden_layers", "num_attention_heads",
+              "num_key_value_heads", "vocab_size", "rms_norm_eps", "rope_theta", "max_position_embeddings"):
+        assert getattr(cfg, k) == a[k], k
     dtype = torch.bfloat16
     hd = a["hidden_size"] // a["num_attention_heads"]
     block_size, num_blocks, b, plen, steps = 16, 64, 3, 21, 6
