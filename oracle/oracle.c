@@ -486,8 +486,12 @@ void orc_scaled_mm(uint16_t* out, const uint8_t* a, const uint8_t* bt, const flo
         for (int k = 0; k < K; ++k) acc += (int)(int8_t)a[(int64_t)m * K + k] * (int)(int8_t)bt[(int64_t)n * K + k];
         accf = (float)acc;
       }
-      float o = a_scales[a_per_row ? m : 0] * (b_scales[b_per_col ? n : 0] * accf);
-      if (bias) o += h_to_f(bias[n], dt);
+      /* epilogue in fp32, one rounding to the output type: without bias multiplies(a_scales,
+       * multiplies(b_scales, acc)) (scaled_mm_c2x.cu:117-131); with bias the outer node is
+       * cutlass::multiply_add(a_scales, tmp, bias) (:157-171), a fused multiply-add in device code */
+      const float tmp = b_scales[b_per_col ? n : 0] * accf;
+      const float as = a_scales[a_per_row ? m : 0];
+      const float o = bias ? fmaf(as, tmp, h_to_f(bias[n], dt)) : as * tmp;
       out[(int64_t)m * N + n] = f_to_h(o, dt);
     }
   free(af); free(bf);
