@@ -444,6 +444,23 @@ int nmv_ar_is_two_shot(void* state, int64_t bytes);
 int nmv_ar_set_timeout_ms(void* state, int64_t ms);
 int nmv_ar_destroy(void* state);
 
+/* The reference's registered-buffer protocol (`_C_custom_ar`: init_custom_ar, register_buffer, all_reduce_reg /
+ * _unreg, get_graph_buffer_ipc_meta, register_graph_buffers, dispose, meta_size -- csrc/custom_all_reduce.cu:12-160,
+ * csrc/torch_bindings.cpp:262-294).  The caller owns `meta` (nmv_car_meta_size() bytes of flags followed by the
+ * two-shot scratch, zeroed) and `rank_data` (device scratch for pointer tables) and exchanges the IPC handles of
+ * meta and of every input buffer; peers read the inputs in place.  One-shot / two-shot by the reference's rule. */
+int64_t nmv_car_meta_size(void);
+int nmv_car_init(void** state_out, void* meta, void* rank_data, int64_t rank_data_bytes, const void* handles,
+                 const int64_t* offsets, int world, int rank, int full_link);
+int nmv_car_register_buffer(void* state, const void* self, const void* handles, const int64_t* offsets);
+int nmv_car_all_reduce(void* state, const void* inp, void* out, int64_t numel, nmv_dtype_t dtype, void* stream);
+int nmv_car_graph_buffer_count(void* state);
+int nmv_car_get_graph_buffer_ipc_meta(void* state, void* handles_out, int64_t* offsets_out);
+int nmv_car_register_graph_buffers(void* state, const void* handles, const int64_t* offsets);
+int nmv_car_set_algo(void* state, int algo);
+int nmv_car_error(void* state);
+int nmv_car_dispose(void* state);
+
 #ifdef __cplusplus
 }
 #endif

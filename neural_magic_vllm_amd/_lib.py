@@ -73,6 +73,16 @@ SIGNATURES = {
     "nmv_ar_set_algo": (_I, [_P, _I]),
     "nmv_ar_is_two_shot": (_I, [_P, _L]),
     "nmv_ar_set_timeout_ms": (_I, [_P, _L]),
+    "nmv_car_meta_size": (_L, []),
+    "nmv_car_init": (_I, [_P, _P, _P, _L, _P, _P, _I, _I, _I]),
+    "nmv_car_register_buffer": (_I, [_P, _P, _P, _P]),
+    "nmv_car_all_reduce": (_I, [_P, _P, _P, _L, _I, _P]),
+    "nmv_car_graph_buffer_count": (_I, [_P]),
+    "nmv_car_get_graph_buffer_ipc_meta": (_I, [_P, _P, _P]),
+    "nmv_car_register_graph_buffers": (_I, [_P, _P, _P]),
+    "nmv_car_set_algo": (_I, [_P, _I]),
+    "nmv_car_error": (_I, [_P]),
+    "nmv_car_dispose": (_I, [_P]),
     "nmv_greedy_record_elems": (_I, [_I]),
     "nmv_greedy_sample_shard": (_I, [_P, _P, _L, _I, _I, _I, _I, _P, _L, _P]),
     "nmv_greedy_sample_finish": (_I, [_P, _P, _I, _I, _P, _P, _P, _P, _P, _I, _I, _P]),

@@ -360,11 +360,10 @@ def fp8_marlin_gemm(a, b_q_weight, b_scales, workspace, num_bits, size_m, size_n
 def gptq_gemm(a, b_q_weight, b_gptq_qzeros, b_gptq_scales, b_g_idx, use_exllama, bit) -> torch.Tensor:
     """csrc/quantization/gptq/q_gemm.cu:1823-1846"""
     _req(bit in (2, 3, 4, 8), f"unsupported bit width {bit}")
-    _req(bit != 3, "3-bit GPTQ is not supported on gfx950 (2, 4 and 8 bit are)")
-    pack = 32 // bit
     size_m, size_k = a.shape[0], a.shape[1]
     size_n = b_q_weight.shape[1]
-    _req(b_q_weight.shape[0] * pack == size_k, "b_q_weight rows do not match a's K")
+    # 3-bit: 32 codes per three int32 rows (qweight is [K * 3 / 32, N])
+    _req(b_q_weight.shape[0] * 32 == size_k * bit, "b_q_weight rows do not match a's K")
     _req(a.is_contiguous() and b_q_weight.is_contiguous() and b_gptq_scales.is_contiguous()
          and b_gptq_qzeros.is_contiguous(), "gptq_gemm: tensors must be contiguous")
     _req(b_gptq_scales.dtype == a.dtype, "scales must have the activation dtype")
@@ -386,17 +385,15 @@ def gptq_gemm(a, b_q_weight, b_gptq_qzeros, b_gptq_scales, b_g_idx, use_exllama,
 
 def gptq_shuffle(q_weight, q_perm, bit) -> None:
     """csrc/quantization/gptq/q_gemm.cu:1848-1856 (in place)"""
-    _req(bit in (2, 4, 8), f"gptq_shuffle: {bit}-bit weights are not supported on gfx950")
+    _req(bit in (2, 3, 4, 8), f"gptq_shuffle: {bit}-bit weights are not supported")
     has_perm = q_perm is not None and q_perm.numel() > 0 and q_perm.device.type != "meta"
     if not has_perm:
         return
-    pack = 32 // bit
-    _req(q_perm.dtype == torch.int32 and q_perm.numel() == q_weight.shape[0] * pack,
-         "q_perm must be int32 [K]")
+    size_k = q_weight.shape[0] * 32 // bit
+    _req(q_perm.dtype == torch.int32 and q_perm.numel() == size_k, "q_perm must be int32 [K]")
     tmp = torch.empty_like(q_weight)
     with device_guard(q_weight):
-        check(_lib.load().nmv_gptq_shuffle(ptr(q_weight), ptr(q_perm), ptr(tmp),
-                                           q_weight.shape[0] * pack, q_weight.shape[1], bit,
+        check(_lib.load().nmv_gptq_shuffle(ptr(q_weight), ptr(q_perm), ptr(tmp), size_k, q_weight.shape[1], bit,
                                            stream_of(q_weight)))
 
 
@@ -930,6 +927,138 @@ _UTIL_OPS = [
 ]
 
 
+# ---------------------------------------------------------------------------------------------
+# _C_custom_ar: the registered-buffer all-reduce protocol (csrc/custom_all_reduce.cu:12-160; the reference
+# compiles it out on ROCm, torch_bindings.cpp:261).  `fa` is the C-side state pointer as an int, IPC handles
+# travel as latin-1 strings of nmv_ar_handle_bytes() bytes (the schema's `str[]`).
+def _hbytes(h) -> bytes:
+    return h if isinstance(h, (bytes, bytearray)) else h.encode("latin-1")
+
+
+def _raw_handle(b: bytes, hb: int) -> bytes:
+    """the runtime's hipIpcMemHandle_t inside what the caller passed: either the bare handle, or torch's
+    shareable-handle string (`storage._share_cuda_()`[1] since torch 2.5: a version byte, a type byte -- 'c' for
+    a plain device allocation -- and then the handle; c10/cuda/CUDACachingAllocator.cpp shareIpcHandle)"""
+    if len(b) == hb:
+        return b
+    _req(len(b) == hb + 2 and b[1:2] == b"c",
+         "IPC handle: expected the runtime's handle or torch's shareable handle of a plain device allocation "
+         f"(got {len(b)} bytes; expandable segments cannot be shared this way)")
+    return b[2:]
+
+
+def _handle_block(handles) -> bytes:
+    hb = _lib.load().nmv_ar_handle_bytes()
+    return b"".join(_raw_handle(_hbytes(h), hb) for h in handles)
+
+
+def car_init_custom_ar(meta, rank_data, handles, offsets, rank, full_nvlink) -> int:
+    import ctypes
+    world = len(offsets)
+    _req(world <= 8, "world size > 8 is not supported")
+    _req(world % 2 == 0, "Odd num gpus is not supported for now")
+    _req(world == len(handles), "handles length should equal to offsets length")
+    _req(0 <= rank < world, "invalid rank passed in")
+    st = ctypes.c_void_p()
+    offs = (ctypes.c_int64 * world)(*[int(o) for o in offsets])
+    with device_guard(meta):
+        check(_lib.load().nmv_car_init(ctypes.byref(st), ptr(meta), ptr(rank_data),
+                                       rank_data.numel() * rank_data.element_size(), _handle_block(handles), offs,
+                                       world, int(rank), int(bool(full_nvlink))))
+    return int(st.value)
+
+
+def _is_weak_contiguous(t: torch.Tensor) -> bool:
+    """custom_all_reduce.cu:36-59"""
+    return t.is_contiguous() or (t.untyped_storage().nbytes() - t.storage_offset() * t.element_size()
+                                 == t.numel() * t.element_size())
+
+
+def car_should_custom_ar(inp, max_size, world_size, full_nvlink) -> bool:
+    """custom_all_reduce.cu:61-71"""
+    inp_size = inp.numel() * inp.element_size()
+    if inp_size % 16 != 0 or not _is_weak_contiguous(inp):
+        return False
+    if world_size == 2 or full_nvlink:
+        return inp_size <= max_size
+    return False
+
+
+def car_all_reduce_reg(fa, inp, out) -> None:
+    _req(inp.dtype == out.dtype, "all_reduce_reg: inp / out dtypes differ")
+    _req(inp.numel() == out.numel(), "all_reduce_reg: inp / out sizes differ")
+    _req(_is_weak_contiguous(out), "all_reduce_reg: out must be (weakly) contiguous")
+    with device_guard(inp):
+        check(_lib.load().nmv_car_all_reduce(fa, ptr(inp), ptr(out), out.numel(), dtype_code(out.dtype),
+                                             stream_of(inp)))
+
+
+def car_all_reduce_unreg(fa, inp, reg_buffer, out) -> None:
+    nbytes = inp.numel() * inp.element_size()
+    _req(inp.dtype == out.dtype and inp.numel() == out.numel(), "all_reduce_unreg: inp / out mismatch")
+    _req(nbytes <= reg_buffer.numel() * reg_buffer.element_size(),
+         "registered buffer is too small to contain the input")
+    # stream-ordered device copy into the registered buffer (cudaMemcpyAsync, custom_all_reduce.cu:121-123)
+    reg_buffer.view(torch.uint8).reshape(-1)[:nbytes].copy_(inp.contiguous().view(torch.uint8).reshape(-1))
+    staged = reg_buffer.view(torch.uint8).reshape(-1)[:nbytes].view(inp.dtype)
+    car_all_reduce_reg(fa, staged, out)
+
+
+def car_dispose(fa) -> None:
+    check(_lib.load().nmv_car_dispose(fa))
+
+
+def car_meta_size() -> int:
+    return int(_lib.load().nmv_car_meta_size())
+
+
+def car_register_buffer(fa, t, handles, offsets) -> None:
+    import ctypes
+    offs = (ctypes.c_int64 * len(offsets))(*[int(o) for o in offsets])
+    with device_guard(t):
+        check(_lib.load().nmv_car_register_buffer(fa, ptr(t), _handle_block(handles), offs))
+
+
+def car_get_graph_buffer_ipc_meta(fa):
+    import ctypes
+    L = _lib.load()
+    n = L.nmv_car_graph_buffer_count(fa)
+    hb = L.nmv_ar_handle_bytes()
+    buf = ctypes.create_string_buffer(max(n * hb, 1))
+    offs = (ctypes.c_int64 * max(n, 1))()
+    check(L.nmv_car_get_graph_buffer_ipc_meta(fa, buf, offs))
+    handles = torch.frombuffer(bytearray(buf.raw[:n * hb]), dtype=torch.uint8).clone() if n else \
+        torch.empty(0, dtype=torch.uint8)
+    return handles, [int(offs[i]) for i in range(n)]
+
+
+def car_register_graph_buffers(fa, handles, offsets) -> None:
+    import ctypes
+    L = _lib.load()
+    n = L.nmv_car_graph_buffer_count(fa)
+    hb = L.nmv_ar_handle_bytes()
+    blobs = [_hbytes(h) for h in handles]
+    _req(all(len(b) == n * hb for b in blobs) and all(len(o) == n for o in offsets),
+         "register_graph_buffers: every rank must send one handle and one offset per recorded buffer")
+    flat = (ctypes.c_int64 * max(len(offsets) * n, 1))(*[int(v) for o in offsets for v in o])
+    check(L.nmv_car_register_graph_buffers(fa, b"".join(b[:n * hb] for b in blobs), flat))
+
+
+_CUSTOM_AR_OPS = [
+    ("init_custom_ar(Tensor meta, Tensor rank_data, str[] handles, int[] offsets, int rank, bool full_nvlink) -> int",
+     car_init_custom_ar, "CUDA"),
+    ("should_custom_ar(Tensor inp, int max_size, int world_size, bool full_nvlink) -> bool", car_should_custom_ar, "CUDA"),
+    ("all_reduce_reg(int fa, Tensor inp, Tensor! out) -> ()", car_all_reduce_reg, "CUDA"),
+    ("all_reduce_unreg(int fa, Tensor inp, Tensor reg_buffer, Tensor! out) -> ()", car_all_reduce_unreg, "CUDA"),
+    ("dispose(int _fa) -> ()", car_dispose, "CompositeExplicitAutograd"),
+    ("meta_size() -> int", car_meta_size, "CompositeExplicitAutograd"),
+    ("register_buffer(int _fa, Tensor t, str[] handles, int[] offsets) -> ()", car_register_buffer, "CUDA"),
+    ("get_graph_buffer_ipc_meta(int _fa) -> (Tensor, int[])", car_get_graph_buffer_ipc_meta, "CompositeExplicitAutograd"),
+    ("register_graph_buffers(int _fa, str[] handles, int[][] offsets) -> ()", car_register_graph_buffers,
+     "CompositeExplicitAutograd"),
+]
+
+
 def _op_name(schema: str) -> str:
     return schema.split("(", 1)[0]
 
@@ -957,9 +1086,14 @@ def register() -> None:
         # dispatched without a tensor key, so give them the catch-all key.
         lib.impl(_op_name(schema), fn, "CompositeExplicitAutograd")
     _libs.append(lib)
+    lib = torch.library.Library("_C_custom_ar", "DEF")
+    for schema, fn, key in _CUSTOM_AR_OPS:
+        lib.define(schema)
+        lib.impl(_op_name(schema), fn, key)
+    _libs.append(lib)
     _registered = True
 
 
 def all_schemas():
     return {"_C": [s for s, _ in _C_OPS] + [s for s, _ in _C_NOTENSOR_OPS], "_C_cache_ops": [s for s, _ in _CACHE_OPS],
-            "_C_cuda_utils": [s for s, _ in _UTIL_OPS]}
+            "_C_cuda_utils": [s for s, _ in _UTIL_OPS], "_C_custom_ar": [s for s, _, _ in _CUSTOM_AR_OPS]}

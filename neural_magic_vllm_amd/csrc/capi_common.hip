@@ -1,5 +1,6 @@
 // Error plumbing, ABI version and device-attribute queries of the C ABI.
 // Reference for the attribute ops: /root/reference/csrc/cuda_utils_kernels.cu:1-29.
+#include <cstring>
 #include "common.h"
 
 #include <stdarg.h>
@@ -11,6 +12,13 @@ void set_error(const char* fmt, ...) {
   va_list ap;
   va_start(ap, fmt);
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+void append_error(const char* fmt, ...) {
+  const size_t n = strlen(g_err);
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err + n, sizeof(g_err) - n, fmt, ap);
   va_end(ap);
 }
 }  // namespace nmv

@@ -21,6 +21,7 @@ typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
 
 // ---- error plumbing for the C ABI -------------------------------------------------
 void set_error(const char* fmt, ...);
+void append_error(const char* fmt, ...);
 #define NMV_CHECK(cond, ...)              \
   do {                                    \
     if (!(cond)) {                        \

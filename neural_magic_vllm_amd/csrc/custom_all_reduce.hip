@@ -23,7 +23,10 @@
 #include "common.h"
 
 #include <cstring>
+#include <map>
+#include <array>
 #include <type_traits>
+#include <unordered_map>
 #include <vector>
 
 // the fused residual-add + RMSNorm below reproduces glue_kernels.hip's roundings: no contraction
@@ -41,8 +44,10 @@ constexpr int AR_THREADS = 512;
 constexpr uint64_t AR_SPIN_TICKS = 200ull * 1000 * 1000;  // s_memrealtime runs at 100 MHz: give up after 2 s
 
 struct ArComm {
-  // [phase][block][source rank] = call number; phase 1 is the second rendezvous of the two-shot form
-  uint32_t flags[2][AR_MAX_BLOCKS][AR_MAX_RANKS];
+  // [phase][block][source rank] = call number; phase 1 is the second rendezvous of the two-shot form,
+  // phase 2 the closing one of the registered-buffer calls (peers read the caller's own tensor there, which
+  // must not be overwritten before every peer is done: end_sync, custom_all_reduce.cuh:167-196)
+  uint32_t flags[3][AR_MAX_BLOCKS][AR_MAX_RANKS];
   uint32_t seq[AR_MAX_BLOCKS];                  // this rank's call number per block
   uint32_t error;                               // set when a spin ran out
   uint32_t pad[47];
@@ -319,6 +324,113 @@ __global__ __launch_bounds__(AR_THREADS) void p2p_all_reduce_norm_kernel(
   if (threadIdx.x == 0) mine->seq[b] = seq;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Registered-buffer form: the `_C_custom_ar` protocol of the reference (torch_bindings.cpp:262-294,
+// custom_all_reduce.cuh:253-470, vllm/distributed/device_communicators/custom_all_reduce.py).  The caller owns
+// every byte: `meta` (this rank's flag block, followed by the two-shot scratch) and the input tensors, whose
+// IPC handles the ranks exchange (register_buffer / register_graph_buffers); peers sum the caller's tensors in
+// place -- no staging copy -- so every call ends with a closing rendezvous.  RegPtrs is one entry of the
+// caller's `rank_data` tensor: the address of one registered buffer on every rank.
+struct RegPtrs {
+  const void* p[AR_MAX_RANKS];
+};
+
+template <typename T>
+__device__ __forceinline__ uint4 reg_sum_vec(const RegPtrs* __restrict__ ptrs, int world, int64_t v) {
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int q = 0; q < world; ++q) {
+    const uint4 x = reinterpret_cast<const uint4*>(ptrs->p[q])[v];
+    const uint32_t xs[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      acc[2 * j] += lo_f<T>(xs[j]);
+      acc[2 * j + 1] += hi_f<T>(xs[j]);
+    }
+  }
+  return make_uint4(T::pack2(acc[0], acc[1]), T::pack2(acc[2], acc[3]), T::pack2(acc[4], acc[5]),
+                    T::pack2(acc[6], acc[7]));
+}
+template <>
+__device__ __forceinline__ uint4 reg_sum_vec<float>(const RegPtrs* __restrict__ ptrs, int world, int64_t v) {
+  f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+  for (int q = 0; q < world; ++q) acc += reinterpret_cast<const f32x4_t*>(ptrs->p[q])[v];
+  return __builtin_bit_cast(uint4, acc);
+}
+
+template <typename T, bool TWO>
+__global__ __launch_bounds__(AR_THREADS) void reg_all_reduce_kernel(ArPeers peers, const RegPtrs* __restrict__ ptrs,
+                                                                    int rank, int world, void* __restrict__ out,
+                                                                    int64_t n_vec, uint64_t spin_ticks) {
+  __shared__ int dead;
+  if (threadIdx.x == 0) dead = 0;
+  const int b = blockIdx.x;
+  ArComm* mine = peers.comm[rank];
+  const uint32_t seq = mine->seq[b] + 1;
+  const int64_t per = (n_vec + gridDim.x - 1) / gridDim.x;
+  const int64_t v0 = min((int64_t)b * per, n_vec), v1 = min(v0 + per, n_vec);
+  uint4* dst = reinterpret_cast<uint4*>(out);
+  // opening rendezvous: every rank has reached this call, so its input (written earlier in its stream) is complete
+  bool ok = ar_rendezvous(peers, mine, rank, world, b, seq, 0, spin_ticks, &dead);
+  if constexpr (!TWO) {
+    if (ok)
+      for (int64_t v = v0 + threadIdx.x; v < v1; v += AR_THREADS) dst[v] = reg_sum_vec<T>(ptrs, world, v);
+  } else {
+    const int64_t sub = max((v1 - v0 + world - 1) / world, (int64_t)1);
+    if (ok) {
+      uint4* tmine = reinterpret_cast<uint4*>(peers.tmp[rank]);
+      const int64_t s0 = min(v0 + rank * sub, v1), s1 = min(s0 + sub, v1);
+      for (int64_t v = s0 + threadIdx.x; v < s1; v += AR_THREADS) tmine[v] = reg_sum_vec<T>(ptrs, world, v);
+      ok = ar_rendezvous(peers, mine, rank, world, b, seq, 1, spin_ticks, &dead);
+    }
+    if (ok)
+      for (int64_t v = v0 + threadIdx.x; v < v1; v += AR_THREADS)
+        dst[v] = reinterpret_cast<const uint4*>(peers.tmp[(v - v0) / sub])[v];
+  }
+  if (!ok) {
+    const uint4 nan = std::is_same<T, float>::value ? make_uint4(0x7FC00000u, 0x7FC00000u, 0x7FC00000u, 0x7FC00000u)
+                                                    : ar_nan16<typename std::conditional<std::is_same<T, float>::value, BF16, T>::type>();
+    for (int64_t v = v0 + threadIdx.x; v < v1; v += AR_THREADS) dst[v] = nan;
+  } else {
+    // closing rendezvous: inputs and scratch may be rewritten only after every peer has read them
+    ar_rendezvous(peers, mine, rank, world, b, seq, 2, spin_ticks, &dead);
+  }
+  if (threadIdx.x == 0) mine->seq[b] = seq;
+}
+
+using IpcKey = std::array<uint8_t, sizeof(hipIpcMemHandle_t)>;
+
+struct RegState {
+  int rank, world, full_link;
+  ArPeers peers;                               // comm[q] = rank q's meta, tmp[q] = the scratch behind it
+  RegPtrs* rd_next;                            // next free entry of the caller's rank_data tensor (device)
+  RegPtrs* rd_end;
+  std::unordered_map<const void*, RegPtrs*> buffers;   // registered input -> its entry
+  std::vector<void*> graph_unreg;              // inputs seen during graph capture, registered afterwards
+  std::map<IpcKey, char*> opened;              // IPC handle -> mapped base (one mapping per allocation)
+  uint64_t spin_ticks;
+  int force_algo;
+};
+
+static bool reg_open(RegState* st, const void* handle, char** base) {
+  IpcKey key;
+  std::memcpy(key.data(), handle, key.size());
+  auto it = st->opened.find(key);
+  if (it == st->opened.end()) {
+    void* ptr = nullptr;
+    hipIpcMemHandle_t h;
+    std::memcpy(&h, handle, sizeof(h));
+    const hipError_t e = hipIpcOpenMemHandle(&ptr, h, hipIpcMemLazyEnablePeerAccess);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      ::nmv::set_error("hipIpcOpenMemHandle: %s", hipGetErrorString(e));
+      return false;
+    }
+    it = st->opened.emplace(key, (char*)ptr).first;
+  }
+  *base = it->second;
+  return true;
+}
+
 // the reference's dispatch rule (custom_all_reduce.cuh:442-451): one-shot for two ranks and for small
 // messages (< 512 KB up to 4 ranks, < 256 KB up to 8), two-shot beyond
 static inline bool ar_two_shot(const ArState* st, int64_t bytes) {
@@ -533,6 +645,186 @@ extern "C" int nmv_ar_destroy(void* state) {
     for (int q = 0; q < st->world; ++q)
       if (q != st->rank && st->peer_base[q]) (void)hipIpcCloseMemHandle(st->peer_base[q]);
   if (st->base) (void)hipFree(st->base);
+  delete st;
+  return NMV_OK;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * `_C_custom_ar` (torch_bindings.cpp:262-294): the registered-buffer protocol.  The Python side
+ * (neural_magic_vllm_amd/_torch_bindings.py) binds the reference's op names to these entry points. */
+extern "C" int64_t nmv_car_meta_size(void) { return (int64_t)sizeof(ArComm); }
+
+/* meta: this rank's tensor of nmv_car_meta_size() + max_size bytes (zeroed); rank_data: device scratch for the
+ * pointer tables; handles: world x nmv_ar_handle_bytes() (IPC handles of every rank's meta allocation), offsets:
+ * byte offset of meta inside that allocation.  custom_all_reduce.cu:12-34 */
+extern "C" int nmv_car_init(void** state_out, void* meta, void* rank_data, int64_t rank_data_bytes,
+                            const void* handles, const int64_t* offsets, int world, int rank, int full_link) {
+  NMV_CHECK(world <= 8, "world size > 8 is not supported");
+  NMV_CHECK(world % 2 == 0, "Odd num gpus is not supported for now");
+  NMV_CHECK(rank >= 0 && rank < world, "invalid rank passed in");
+  NMV_CHECK(meta != nullptr && rank_data != nullptr && rank_data_bytes >= (int64_t)sizeof(RegPtrs),
+            "init_custom_ar: meta / rank_data missing");
+  RegState* st = new RegState();
+  st->rank = rank; st->world = world; st->full_link = full_link;
+  st->spin_ticks = AR_SPIN_TICKS;
+  st->force_algo = 0;
+  st->rd_next = (RegPtrs*)rank_data;
+  st->rd_end = st->rd_next + rank_data_bytes / (int64_t)sizeof(RegPtrs);
+  std::memset(&st->peers, 0, sizeof(st->peers));
+  for (int q = 0; q < world; ++q) {
+    char* base = (char*)meta;
+    if (q != rank) {
+      if (!reg_open(st, (const uint8_t*)handles + (size_t)q * sizeof(hipIpcMemHandle_t), &base)) {
+        delete st;
+        ::nmv::append_error(" (init_custom_ar: rank %d's meta buffer)", q);
+        return NMV_ERR_HIP;
+      }
+      base += offsets[q];
+    }
+    st->peers.comm[q] = (ArComm*)base;
+    st->peers.tmp[q] = (uint8_t*)base + sizeof(ArComm);
+  }
+  *state_out = st;
+  return NMV_OK;
+}
+
+/* custom_all_reduce.cuh:337-355 */
+extern "C" int nmv_car_register_buffer(void* state, const void* self, const void* handles, const int64_t* offsets) {
+  RegState* st = (RegState*)state;
+  NMV_CHECK(st != nullptr, "register_buffer: bad handle");
+  NMV_CHECK(st->rd_next + 1 <= st->rd_end, "Rank data buffer is overflowed by 1");
+  RegPtrs d;
+  std::memset(&d, 0, sizeof(d));
+  for (int q = 0; q < st->world; ++q) {
+    if (q == st->rank) { d.p[q] = self; continue; }
+    char* base;
+    NMV_CHECK(reg_open(st, (const uint8_t*)handles + (size_t)q * sizeof(hipIpcMemHandle_t), &base),
+              "register_buffer: cannot map rank %d's buffer", q);
+    d.p[q] = base + offsets[q];
+  }
+  AR_HIP(hipMemcpy(st->rd_next, &d, sizeof(d), hipMemcpyHostToDevice));
+  st->buffers[self] = st->rd_next++;
+  return NMV_OK;
+}
+
+/* all_reduce_reg: inp is a registered buffer, or -- while the stream is capturing -- a graph-private tensor
+ * that is recorded and registered after the capture (custom_all_reduce.cuh:402-432).  elem_size 2 (fp16 / bf16
+ * by dtype) or 4 (fp32). */
+extern "C" int nmv_car_all_reduce(void* state, const void* inp, void* out, int64_t numel, nmv_dtype_t dtype,
+                                  void* stream) {
+  RegState* st = (RegState*)state;
+  NMV_CHECK(st != nullptr, "all_reduce: bad handle");
+  NMV_CHECK(dtype == NMV_F16 || dtype == NMV_BF16 || dtype == NMV_F32,
+            "custom allreduce only supports float32, float16 and bfloat16");
+  const int64_t bytes = numel * (dtype == NMV_F32 ? 4 : 2);
+  NMV_CHECK(bytes > 0 && bytes % 16 == 0, "custom allreduce currently requires input length to be multiple of %d",
+            dtype == NMV_F32 ? 4 : 8);
+  NMV_CHECK((((uintptr_t)inp | (uintptr_t)out) & 15) == 0, "custom allreduce: 16-byte aligned tensors");
+  hipStream_t s = (hipStream_t)stream;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  AR_HIP(hipStreamIsCapturing(s, &cap));
+  const RegPtrs* ptrs;
+  if (cap == hipStreamCaptureStatusActive) {
+    NMV_CHECK(st->rd_next + st->graph_unreg.size() + 1 <= st->rd_end, "Rank data buffer is overflowed by 1");
+    ptrs = st->rd_next + st->graph_unreg.size();      // filled in by register_graph_buffers
+    st->graph_unreg.push_back(const_cast<void*>(inp));
+  } else {
+    auto it = st->buffers.find(inp);
+    NMV_CHECK(it != st->buffers.end(), "buffer address %llu is not registered!", (unsigned long long)(uintptr_t)inp);
+    ptrs = it->second;
+  }
+  const int64_t n_vec = bytes / 16;
+  bool two;
+  if (st->force_algo) two = st->force_algo == 2;
+  else if (st->world == 2) two = false;
+  else if (st->full_link) two = !((st->world <= 4 && bytes < 512 * 1024) || (st->world <= 8 && bytes < 256 * 1024));
+  else two = false;   // the reference launches nothing here (:442-451); should_custom_ar never lets such a call in
+#define NMV_REG_AR(T_)                                                                                          \
+  do {                                                                                                          \
+    if (two)                                                                                                    \
+      hipLaunchKernelGGL((reg_all_reduce_kernel<T_, true>), dim3(AR_MAX_BLOCKS), dim3(AR_THREADS), 0, s,        \
+                         st->peers, ptrs, st->rank, st->world, out, n_vec, st->spin_ticks);                     \
+    else                                                                                                        \
+      hipLaunchKernelGGL((reg_all_reduce_kernel<T_, false>), dim3(AR_MAX_BLOCKS), dim3(AR_THREADS), 0, s,       \
+                         st->peers, ptrs, st->rank, st->world, out, n_vec, st->spin_ticks);                     \
+  } while (0)
+  if (dtype == NMV_F16) NMV_REG_AR(F16);
+  else if (dtype == NMV_BF16) NMV_REG_AR(BF16);
+  else NMV_REG_AR(float);
+#undef NMV_REG_AR
+  NMV_LAUNCH_CHECK();
+  return NMV_OK;
+}
+
+extern "C" int nmv_car_graph_buffer_count(void* state) {
+  RegState* st = (RegState*)state;
+  return st ? (int)st->graph_unreg.size() : 0;
+}
+
+/* handles_out: count x nmv_ar_handle_bytes(), offsets_out: count entries (custom_all_reduce.cuh:308-328: the
+ * handle of the allocation's base address + the tensor's offset in it) */
+extern "C" int nmv_car_get_graph_buffer_ipc_meta(void* state, void* handles_out, int64_t* offsets_out) {
+  RegState* st = (RegState*)state;
+  NMV_CHECK(st != nullptr, "get_graph_buffer_ipc_meta: bad handle");
+  for (size_t i = 0; i < st->graph_unreg.size(); ++i) {
+    void* ptr = st->graph_unreg[i];
+    hipDeviceptr_t base = nullptr;
+    size_t size = 0;
+    AR_HIP(hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)ptr));
+    hipIpcMemHandle_t h;
+    AR_HIP(hipIpcGetMemHandle(&h, (void*)base));
+    std::memcpy((uint8_t*)handles_out + i * sizeof(h), &h, sizeof(h));
+    offsets_out[i] = (int64_t)((char*)ptr - (char*)base);
+  }
+  return NMV_OK;
+}
+
+/* handles: [world][count] handles, offsets: [world][count] (custom_all_reduce.cuh:364-391) */
+extern "C" int nmv_car_register_graph_buffers(void* state, const void* handles, const int64_t* offsets) {
+  RegState* st = (RegState*)state;
+  NMV_CHECK(st != nullptr, "register_graph_buffers: bad handle");
+  const size_t n = st->graph_unreg.size();
+  NMV_CHECK(st->rd_next + n <= st->rd_end, "Rank data buffer is overflowed by %d", (int)n);
+  if (n == 0) return NMV_OK;
+  std::vector<RegPtrs> rd(n);
+  for (size_t i = 0; i < n; ++i) {
+    std::memset(&rd[i], 0, sizeof(RegPtrs));
+    for (int q = 0; q < st->world; ++q) {
+      if (q == st->rank) { rd[i].p[q] = st->graph_unreg[i]; continue; }
+      char* base;
+      NMV_CHECK(reg_open(st, (const uint8_t*)handles + ((size_t)q * n + i) * sizeof(hipIpcMemHandle_t), &base),
+                "register_graph_buffers: cannot map rank %d's buffer %d", q, (int)i);
+      rd[i].p[q] = base + offsets[(size_t)q * n + i];
+    }
+  }
+  AR_HIP(hipMemcpy(st->rd_next, rd.data(), sizeof(RegPtrs) * n, hipMemcpyHostToDevice));
+  st->rd_next += n;
+  st->graph_unreg.clear();
+  return NMV_OK;
+}
+
+extern "C" int nmv_car_set_algo(void* state, int algo) {
+  RegState* st = (RegState*)state;
+  NMV_CHECK(st != nullptr && algo >= 0 && algo <= 2, "custom_all_reduce: algo must be 0, 1 or 2");
+  st->force_algo = algo;
+  return NMV_OK;
+}
+
+/* 1 when a flag wait ran out on this rank (synchronises the device) */
+extern "C" int nmv_car_error(void* state) {
+  RegState* st = (RegState*)state;
+  if (st == nullptr) return 1;
+  uint32_t err = 1;
+  if (hipDeviceSynchronize() != hipSuccess) return 1;
+  if (hipMemcpy(&err, &st->peers.comm[st->rank]->error, 4, hipMemcpyDeviceToHost) != hipSuccess) return 1;
+  return (int)err;
+}
+
+extern "C" int nmv_car_dispose(void* state) {
+  RegState* st = (RegState*)state;
+  if (st == nullptr) return NMV_OK;
+  (void)hipDeviceSynchronize();
+  for (auto& kv : st->opened) (void)hipIpcCloseMemHandle(kv.second);
   delete st;
   return NMV_OK;
 }

@@ -179,7 +179,10 @@ __global__ __launch_bounds__(MM_THREADS) void scaled_mm_kernel(const MMParams p)
         elem_t v = acc[j][t][i];
 #pragma unroll
         for (int ww = 0; ww < 3; ++ww) v += redt[ww][j][t][i][lane];
-        o[i] = fmaf(as, bs[i] * (float)v, bv[i]);
+        // multiplies(a_scales, multiplies(b_scales, acc)); with a bias the outer node is multiply_add
+        // (scaled_mm_c2x.cu:117-131, :157-171) -- no "+ 0" without one: it would turn -0 into +0
+        const float tmp = bs[i] * (float)v;
+        o[i] = p.bias ? fmaf(as, tmp, bv[i]) : as * tmp;
       }
       uint16_t* dst = reinterpret_cast<uint16_t*>(p.out) + (int64_t)m * p.ldc + nb;
       if (nb + 3 < p.N && (reinterpret_cast<uintptr_t>(dst) & 7) == 0) {
@@ -216,7 +219,8 @@ __global__ __launch_bounds__(256) void scaled_mm_reduce_kernel(const MMParams p)
     for (int s = 0; s < p.splits; ++s) v += src[s * slab_stride + i];
     const float bs = p.b_scales[p.b_per_col ? nb + i : 0];
     const float bv = p.bias ? T::to_float(reinterpret_cast<const uint16_t*>(p.bias)[nb + i]) : 0.f;
-    dst[i] = T::from_float(fmaf(as, bs * (float)v, bv));
+    const float tmp = bs * (float)v;
+    dst[i] = T::from_float(p.bias ? fmaf(as, tmp, bv) : as * tmp);
   }
 }
 

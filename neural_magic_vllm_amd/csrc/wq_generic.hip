@@ -39,6 +39,15 @@ __device__ __forceinline__ uint32_t wq_code(const WqParams& p, int k, int n) {
   const int bits = p.bits;
   const uint32_t mask = (1u << bits) - 1;
   if constexpr (FMT == WQ_GPTQ) {
+    if (bits == 3) {
+      // 32 consecutive k of a column are a 96-bit little-endian stream over three int32 rows: code i sits at
+      // bits [3 i, 3 i + 3), codes 10 and 21 straddle a word (q_gemm.cu:1438-1459)
+      const int bit0 = (k & 31) * 3, w = bit0 >> 5, sh = bit0 & 31;
+      const uint32_t* col = p.qweight + (int64_t)((k >> 5) * 3) * p.N + n;
+      const uint64_t lo = col[(int64_t)w * p.N];
+      const uint64_t hi = (sh > 29) ? col[(int64_t)(w + 1) * p.N] : 0;
+      return (uint32_t)(((hi << 32) | lo) >> sh) & 7u;
+    }
     // qweight [K/pack, N]: `pack` consecutive k share one int32, low bits first (quant_utils.py:125-146)
     const int pack = 32 / bits;
     return (p.qweight[(int64_t)(k / pack) * p.N + n] >> (bits * (k % pack))) & mask;
@@ -79,6 +88,14 @@ template <int FMT>
 __device__ __forceinline__ float wq_zero(const WqParams& p, int g, int n) {
   if constexpr (FMT == WQ_GPTQ) {
     if (p.qzeros == nullptr) return (float)(1 << (p.bits - 1));
+    if (p.bits == 3) {
+      // the same 3-bit stream along N: 32 columns per three int32 (matrix_view.cuh:204-232)
+      const int bit0 = (n & 31) * 3, w = bit0 >> 5, sh = bit0 & 31;
+      const uint32_t* row = p.qzeros + (int64_t)g * (p.N * 3 / 32) + (n >> 5) * 3;
+      const uint64_t lo = row[w];
+      const uint64_t hi = (sh > 29) ? row[w + 1] : 0;
+      return (float)(((uint32_t)(((hi << 32) | lo) >> sh) & 7u) + 1);
+    }
     const int pack = 32 / p.bits;
     const uint32_t z = (p.qzeros[(int64_t)g * (p.N / pack) + n / pack] >> (p.bits * (n % pack))) & ((1u << p.bits) - 1);
     return (float)(z + 1);  // GPTQ stores zero - 1 (q_gemm.cu:1410-1417)
@@ -379,16 +396,47 @@ static WqStreamPlan wq_stream_plan(int M, int N, int K) {
   pl.splits = (K + pl.k_per_wg - 1) / pl.k_per_wg;
   return pl;
 }
-// the streaming kernel's domain: 4 bits, no act-order, whole stages and tiles
+// the streaming kernel's domain: 4 bits, whole stages and tiles, groups that are whole k-steps.  Act-order in
+// the exllama form is inside it: gptq_shuffle has sorted the weight rows by group, so the groups are contiguous
+// again and only the activation columns have to be gathered -- once per call, by permute_cols_kernel, instead
+// of per weight tile (the reference's Marlin path does the same, gptq_marlin.cu:345-394)
 static bool wq_stream_ok(const WqParams& p) {
-  return p.bits == 4 && p.g_idx == nullptr && p.perm == nullptr && p.K % WS_K == 0 && p.N % 64 == 0 &&
+  return p.bits == 4 && p.g_idx == nullptr && p.K % WS_K == 0 && p.N % 64 == 0 &&
          p.group_size % 32 == 0 && p.group_size > 0;
 }
 
+// out[m, k] = a[m, perm[k]]: one thread per 8 consecutive output elements (16-byte store)
+__global__ void permute_cols_kernel(const uint16_t* __restrict__ a, const int* __restrict__ perm,
+                                    uint16_t* __restrict__ out, int M, int K) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int per_row = K / 8;
+  if (idx >= (int64_t)M * per_row) return;
+  const int m = idx / per_row, k0 = (idx % per_row) * 8;
+  const uint16_t* row = a + (int64_t)m * K;
+  uint16_t e[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) e[j] = row[perm[k0 + j]];
+  st16(out + (int64_t)m * K + k0, make_uint4(e[0] | ((uint32_t)e[1] << 16), e[2] | ((uint32_t)e[3] << 16),
+                                             e[4] | ((uint32_t)e[5] << 16), e[6] | ((uint32_t)e[7] << 16)));
+}
+
 template <typename T, int FMT>
-static int launch_wq_stream(const WqParams& p, float* slab, int64_t slab_bytes, hipStream_t s) {
+static int launch_wq_stream(const WqParams& p_in, float* slab, int64_t slab_bytes, hipStream_t s) {
+  WqParams p = p_in;
   const WqStreamPlan pl = wq_stream_plan(p.M, p.N, p.K);
-  if (pl.splits > 1 && (slab == nullptr || slab_bytes < (int64_t)pl.splits * p.M * p.N * 4)) return -2;
+  // scratch = [gathered activations (act-order only)] [split-K slabs]
+  const int64_t a_bytes = p.perm ? (((int64_t)p.M * p.K * 2 + 255) & ~(int64_t)255) : 0;
+  const int64_t need = a_bytes + (pl.splits > 1 ? (int64_t)pl.splits * p.M * p.N * 4 : 0);
+  if (need > 0 && (slab == nullptr || slab_bytes < need)) return -2;
+  if (p.perm) {
+    uint16_t* a_perm = reinterpret_cast<uint16_t*>(slab);
+    const int64_t cells = (int64_t)p.M * (p.K / 8);
+    hipLaunchKernelGGL(permute_cols_kernel, dim3((unsigned)cdiv64(cells, 256)), dim3(256), 0, s, p.a, p.perm, a_perm,
+                       p.M, p.K);
+    p.a = a_perm;
+    p.perm = nullptr;
+    slab = reinterpret_cast<float*>(reinterpret_cast<uint8_t*>(slab) + a_bytes);
+  }
   dim3 grid(p.N / 64, pl.splits, (p.M + 16 * pl.mt - 1) / (16 * pl.mt));
   if (pl.mt == 1) hipLaunchKernelGGL((wq_stream_kernel<T, FMT, 1>), grid, dim3(256), 0, s, p, slab, pl.k_per_wg);
   else if (pl.mt == 2) hipLaunchKernelGGL((wq_stream_kernel<T, FMT, 2>), grid, dim3(256), 0, s, p, slab, pl.k_per_wg);
@@ -426,6 +474,31 @@ __global__ void gptq_permute_rows_kernel(const uint32_t* __restrict__ src, uint3
     res |= ((src[(int64_t)(ks / pack) * N + n] >> (bits * (ks % pack))) & mask) << (bits * e);
   }
   dst[idx] = res;
+}
+
+// 3-bit: a thread owns one column of one 32-row group of the OUTPUT (three words) and gathers its 32 codes
+__global__ void gptq_permute_rows_3bit_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst,
+                                              const int* __restrict__ perm, int K, int N) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)(K / 32) * N) return;
+  const int grp = idx / N, n = idx % N;
+  uint64_t acc = 0;   // bit stream under construction
+  int filled = 0, w = 0;
+  for (int e = 0; e < 32; ++e) {
+    const int ks = perm[grp * 32 + e];
+    const int bit0 = (ks & 31) * 3, sw = bit0 >> 5, sh = bit0 & 31;
+    const uint32_t* col = src + (int64_t)((ks >> 5) * 3) * N + n;
+    const uint64_t lo = col[(int64_t)sw * N];
+    const uint64_t hi = (sh > 29) ? col[(int64_t)(sw + 1) * N] : 0;
+    acc |= (uint64_t)((uint32_t)(((hi << 32) | lo) >> sh) & 7u) << filled;
+    filled += 3;
+    if (filled >= 32) {
+      dst[(int64_t)(grp * 3 + w) * N + n] = (uint32_t)acc;
+      acc >>= 32;
+      filled -= 32;
+      ++w;
+    }
+  }
 }
 
 template <typename T, int FMT>
@@ -470,7 +543,9 @@ using namespace nmv;
 extern "C" int64_t nmv_wq_gemm_scratch_bytes(int size_m, int size_n, int size_k) {
   if (size_m <= 0 || size_n <= 0 || size_k <= 0 || size_k % WS_K != 0 || size_n % 64 != 0) return 0;
   const WqStreamPlan pl = wq_stream_plan(size_m, size_n, size_k);
-  return pl.splits > 1 ? (int64_t)pl.splits * size_m * size_n * 4 : 0;
+  // the gathered activations of an act-order call (the caller does not say whether it is one) + the slabs
+  const int64_t a_bytes = ((int64_t)size_m * size_k * 2 + 255) & ~(int64_t)255;
+  return a_bytes + (pl.splits > 1 ? (int64_t)pl.splits * size_m * size_n * 4 : 0);
 }
 
 extern "C" int nmv_gptq_gemm(void* c, const void* a, const int32_t* b_q_weight,
@@ -479,9 +554,9 @@ extern "C" int nmv_gptq_gemm(void* c, const void* a, const int32_t* b_q_weight,
                              int size_n, int size_k, int num_groups, nmv_dtype_t dtype,
                              void* scratch, int64_t scratch_bytes, void* stream) {
   NMV_CHECK(dtype == NMV_F16 || dtype == NMV_BF16, "gptq_gemm: unsupported dtype %d", (int)dtype);
-  NMV_CHECK(bit == 2 || bit == 4 || bit == 8, "gptq_gemm: %d-bit weights are not supported on gfx950 (2, 4, 8 are)", bit);
+  NMV_CHECK(bit == 2 || bit == 3 || bit == 4 || bit == 8, "gptq_gemm: %d-bit weights are not supported", bit);
   NMV_CHECK(size_k % 32 == 0 && num_groups >= 1 && size_k % num_groups == 0, "gptq_gemm: bad K / groups");
-  NMV_CHECK(size_n % (32 / bit) == 0, "gptq_gemm: N must be a multiple of the pack factor");
+  NMV_CHECK(size_n % (bit == 3 ? 32 : 32 / bit) == 0, "gptq_gemm: N must be a multiple of the pack factor");
   if (size_m == 0) return NMV_OK;
   // exllama: weights were row-permuted by gptq_shuffle, b_g_idx is that permutation (gathers A);
   // otherwise b_g_idx is the per-row group index of the unshuffled weights (q_gemm.cu:1823-1846)
@@ -506,15 +581,19 @@ extern "C" int nmv_gptq_gemm(void* c, const void* a, const int32_t* b_q_weight,
 
 extern "C" int nmv_gptq_shuffle(int32_t* q_weight, const int32_t* q_perm, int32_t* tmp, int size_k,
                                 int size_n, int bit, void* stream) {
-  NMV_CHECK(bit == 2 || bit == 4 || bit == 8, "gptq_shuffle: %d-bit weights are not supported on gfx950", bit);
+  NMV_CHECK(bit == 2 || bit == 3 || bit == 4 || bit == 8, "gptq_shuffle: %d-bit weights are not supported", bit);
   if (q_perm == nullptr) return NMV_OK;  // nothing observable to do without act-order
   NMV_CHECK(tmp != nullptr, "gptq_shuffle: scratch required with a permutation");
-  const int pack = 32 / bit;
-  const int64_t total = (int64_t)(size_k / pack) * size_n;
+  NMV_CHECK(bit != 3 || size_k % 32 == 0, "gptq_shuffle: 3-bit rows come in groups of 32");
+  const int64_t total = bit == 3 ? (int64_t)(size_k / 32) * 3 * size_n : (int64_t)(size_k / (32 / bit)) * size_n;
   if (total == 0) return NMV_OK;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(gptq_permute_rows_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, s,
-                     (const uint32_t*)q_weight, (uint32_t*)tmp, q_perm, size_k, size_n, bit);
+  if (bit == 3)
+    hipLaunchKernelGGL(gptq_permute_rows_3bit_kernel, dim3((unsigned)cdiv64((int64_t)(size_k / 32) * size_n, 256)),
+                       dim3(256), 0, s, (const uint32_t*)q_weight, (uint32_t*)tmp, q_perm, size_k, size_n);
+  else
+    hipLaunchKernelGGL(gptq_permute_rows_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, s,
+                       (const uint32_t*)q_weight, (uint32_t*)tmp, q_perm, size_k, size_n, bit);
   hipError_t e = hipMemcpyAsync(q_weight, tmp, total * 4, hipMemcpyDeviceToDevice, s);
   if (e != hipSuccess) { set_error("gptq_shuffle: copy failed: %s", hipGetErrorString(e)); return NMV_ERR_HIP; }
   NMV_LAUNCH_CHECK();

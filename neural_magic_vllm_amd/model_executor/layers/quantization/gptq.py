@@ -28,8 +28,6 @@ class GPTQConfig(QuantizationConfig):
         if self.weight_bits not in [2, 3, 4, 8]:
             raise ValueError("Currently, only 2/3/4/8-bit weight quantization is supported for "
                              f"GPTQ, but got {self.weight_bits} bits.")
-        if self.weight_bits == 3:
-            raise ValueError("3-bit GPTQ is not supported by the gfx950 kernels")
 
     def __repr__(self) -> str:
         return (f"GPTQConfig(weight_bits={self.weight_bits}, group_size={self.group_size}, "
@@ -101,15 +99,15 @@ class GPTQLinearMethod(LinearMethodBase):
             else:
                 scale_and_zero_size = input_size_per_partition // group_size
                 scale_and_zero_input_dim = 0
-        pf = int(cfg.pack_factor)
-        qweight = Parameter(torch.empty(input_size_per_partition // pf, output_size_per_partition,
+        pf = cfg.pack_factor   # a Fraction: 32/3 for 3-bit codes (gptq.py:34, :137-160)
+        qweight = Parameter(torch.empty(int(input_size_per_partition // pf), output_size_per_partition,
                                         dtype=torch.int32), requires_grad=False)
         set_weight_attrs(qweight, {"input_dim": 0, "output_dim": 1, "packed_dim": 0,
                                    "pack_factor": cfg.pack_factor})
         g_idx = Parameter(torch.tensor([i // cfg.group_size for i in range(input_size_per_partition)],
                                        dtype=torch.int32), requires_grad=False)
         set_weight_attrs(g_idx, {"input_dim": 0, "ignore_warning": True})
-        qzeros = Parameter(torch.empty(scale_and_zero_size, output_size_per_partition // pf,
+        qzeros = Parameter(torch.empty(scale_and_zero_size, int(output_size_per_partition // pf),
                                        dtype=torch.int32), requires_grad=False)
         set_weight_attrs(qzeros, {"input_dim": scale_and_zero_input_dim, "output_dim": 1,
                                   "packed_dim": 1, "pack_factor": cfg.pack_factor})

@@ -17,7 +17,7 @@ def rel_err(out, ref):
     return ref_math.compute_max_diff(out, ref).item()
 
 
-@pytest.mark.parametrize("bits", [4, 8, 2])
+@pytest.mark.parametrize("bits", [4, 8, 2, 3])
 @pytest.mark.parametrize("group_size", [128, 32, -1])
 @pytest.mark.parametrize("m", [1, 13, 67])
 @pytest.mark.parametrize("dtype", [torch.half, torch.bfloat16])
@@ -37,8 +37,12 @@ def test_gptq_gemm(gpu_device, bits, group_size, m, dtype, mode):
     w_ref = ref_math.gptq_reference_weight(q, z, s, g_idx, dtype)
     ref = (a.float() @ w_ref.float()).to(dtype)
     d = gpu_device
-    qweight = ref_math.gptq_pack(q, bits, k, n).to(d)
-    qzeros = ref_math.pack_cols(z - 1, bits).to(d)  # stored as zero - 1
+    if bits == 3:   # 32 codes per three words, along K for the weights and along N for the zero points
+        qweight = ref_math.pack_3bit_stream(q, 0).to(d)
+        qzeros = ref_math.pack_3bit_stream(z - 1, 1).to(d)
+    else:
+        qweight = ref_math.gptq_pack(q, bits, k, n).to(d)
+        qzeros = ref_math.pack_cols(z - 1, bits).to(d)  # stored as zero - 1
     scales = s.to(d)
     if mode == "exllama_act_order":
         # GPTQLinearMethod.apply (gptq.py:211-225): g_idx <- argsort(g_idx); gptq_shuffle; gemm
