@@ -406,6 +406,21 @@ int64_t nmv_get_device_attribute(int64_t attribute, int64_t device_id);
 int64_t nmv_get_max_shared_memory_per_block_device_attribute(int64_t device_id);
 
 /* ------------------------------------------------------------------------------------------
+ * MFMA-native W4 tensors (not ops of nm-vllm 0.5.1; what GPTQMarlinLinearMethod keeps beside the Marlin tensor
+ * for decode-sized calls).  nmv_w4_native_repack: GPTQ qweight int32 [K/8, N] (+ optional act-order row gather
+ * perm[K]) -> native int32 [K/8 * N] (csrc/w4a16_gemm.hip).  nmv_w4_native_gemm: C = A . ((q - 8) * s), s the
+ * natural [groups, N] scales; mode 0 = [M, N] in the model dtype (workspace = zeroed split-K tickets, scratch =
+ * fp32 slabs, nmv_gptq_marlin_gemm_scratch_bytes), 1 = silu(gate) * up -> [M, N/2] on column-interleaved
+ * gate_up weights, 2 = deferred reduction: fp32 slabs [nmv_w4_native_gemm_splits][M][N] in scratch.
+ * Same arithmetic as nmv_gptq_marlin_gemm (fp32 group scaling), M tiles <= 64 rows. */
+int nmv_w4_native_repack(const int32_t* qweight, const int32_t* perm, int32_t* out, int size_k, int size_n,
+                         void* stream);
+int nmv_w4_native_gemm_splits(int size_m, int size_n, int size_k);
+int nmv_w4_native_gemm(void* c, const void* a, const int32_t* b_native, const void* b_scales, int32_t* workspace,
+                       int64_t workspace_len, void* scratch, int64_t scratch_bytes, int size_m, int size_n,
+                       int size_k, int num_groups, nmv_dtype_t dtype, int mode, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * One-shot / two-shot P2P all-reduce over HIP IPC (the analogue of csrc/custom_all_reduce.cuh:130-250
  * and its dispatch rule :442-451; the `_C_custom_ar` ops of torch_bindings.cpp:262-294 are bound on top of
  * these entry points -- the reference compiles all of it out on ROCm).

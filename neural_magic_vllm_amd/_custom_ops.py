@@ -380,6 +380,23 @@ def greedy_sample_advance(logits: torch.Tensor, input_ids: Optional[torch.Tensor
 
 
 # deferred split-K: the GEMM leaves fp32 slabs, the following fused_add_rms_norm sums them
+def w4_native_repack(qweight: torch.Tensor, perm: Optional[torch.Tensor], size_k: int, size_n: int) -> torch.Tensor:
+    """GPTQ qweight -> the MFMA-native W4 tensor (csrc/w4a16_gemm.hip; not an op of the reference)"""
+    from neural_magic_vllm_amd import _torch_bindings as tb
+    return tb.w4_native_repack(qweight, perm, size_k, size_n)
+
+
+def w4_native_gemm_splits(size_m: int, size_n: int, size_k: int) -> int:
+    from neural_magic_vllm_amd import _torch_bindings as tb
+    return tb.w4_native_gemm_splits(size_m, size_n, size_k)
+
+
+def w4_native_gemm(a: torch.Tensor, b_native: torch.Tensor, scales: torch.Tensor, workspace: Optional[torch.Tensor],
+                   size_m: int, size_n: int, size_k: int, mode: int = 0) -> torch.Tensor:
+    from neural_magic_vllm_amd import _torch_bindings as tb
+    return tb.w4_native_gemm(a, b_native, scales, workspace, size_m, size_n, size_k, mode)
+
+
 def gptq_marlin_gemm_partial_splits(size_m: int, size_n: int, size_k: int) -> int:
     from neural_magic_vllm_amd import _torch_bindings as tb
     return tb.gptq_marlin_gemm_partial_splits(size_m, size_n, size_k)

@@ -73,6 +73,9 @@ SIGNATURES = {
     "nmv_ar_set_algo": (_I, [_P, _I]),
     "nmv_ar_is_two_shot": (_I, [_P, _L]),
     "nmv_ar_set_timeout_ms": (_I, [_P, _L]),
+    "nmv_w4_native_repack": (_I, [_P, _P, _P, _I, _I, _P]),
+    "nmv_w4_native_gemm_splits": (_I, [_I, _I, _I]),
+    "nmv_w4_native_gemm": (_I, [_P, _P, _P, _P, _P, _L, _P, _L, _I, _I, _I, _I, _I, _I, _P]),
     "nmv_car_meta_size": (_L, []),
     "nmv_car_init": (_I, [_P, _P, _P, _L, _P, _P, _I, _I, _I]),
     "nmv_car_register_buffer": (_I, [_P, _P, _P, _P]),

@@ -654,6 +654,52 @@ def greedy_sample_advance(logits, input_ids=None, positions=None, seq_lens=None,
     return out
 
 
+# ---- MFMA-native W4 tensors (include/nmvllm_hip.h: nmv_w4_native_*; not ops of the reference) ----
+def w4_native_repack(qweight, perm, size_k, size_n) -> torch.Tensor:
+    """GPTQ qweight int32 [K/8, N] (+ optional act-order row gather) -> native int32 [K/8 * N]"""
+    _req(qweight.dtype == torch.int32 and qweight.is_contiguous() and tuple(qweight.shape) == (size_k // 8, size_n),
+         "w4_native_repack: qweight must be contiguous int32 [K/8, N]")
+    has_perm = perm is not None and perm.numel() > 0
+    if has_perm:
+        _req(perm.dtype == torch.int32 and perm.numel() == size_k, "w4_native_repack: perm must be int32 [K]")
+    out = torch.empty((size_k // 8 * size_n, ), dtype=torch.int32, device=qweight.device)
+    with device_guard(qweight):
+        check(_lib.load().nmv_w4_native_repack(ptr(qweight), ptr(perm) if has_perm else None, ptr(out), size_k, size_n,
+                                               stream_of(qweight)))
+    return out
+
+
+def w4_native_gemm_splits(size_m, size_n, size_k) -> int:
+    return int(_lib.load().nmv_w4_native_gemm_splits(size_m, size_n, size_k))
+
+
+def w4_native_gemm(a, b_native, scales, workspace, size_m, size_n, size_k, mode=0) -> torch.Tensor:
+    """mode 0: [M, N]; 1: silu(gate) * up -> [M, N/2]; 2: fp32 split-K slabs [splits, M, N] (deferred reduction)"""
+    _req(a.is_contiguous() and a.shape == (size_m, size_k) and a.dtype in (torch.float16, torch.bfloat16),
+         "w4_native_gemm: a must be contiguous fp16 / bf16 [M, K]")
+    _req(b_native.dtype == torch.int32 and b_native.numel() == size_k // 8 * size_n, "w4_native_gemm: b is not a native tensor")
+    _req(scales.is_contiguous() and scales.dtype == a.dtype and scales.shape[1] == size_n,
+         "w4_native_gemm: scales must be the natural [groups, N] tensor in A's dtype")
+    L = _lib.load()
+    dev = a.device
+    if mode == 2:
+        splits = L.nmv_w4_native_gemm_splits(size_m, size_n, size_k)
+        _req(splits >= 1, "w4_native_gemm: shape not supported")
+        out = torch.empty((splits, size_m, size_n), dtype=torch.float32, device=dev)
+        scratch, nbytes, c = out, out.numel() * 4, None
+    else:
+        c = torch.empty((size_m, size_n // 2 if mode == 1 else size_n), dtype=a.dtype, device=dev)
+        nbytes = 0 if mode == 1 else int(L.nmv_gptq_marlin_gemm_scratch_bytes(size_m, size_n, size_k, 0))
+        scratch = torch.empty((max(nbytes, 16), ), dtype=torch.uint8, device=dev)
+        out = c
+    with device_guard(a):
+        check(L.nmv_w4_native_gemm(ptr(c) if c is not None else None, ptr(a), ptr(b_native), ptr(scales),
+                                   ptr(workspace) if workspace is not None else None,
+                                   workspace.numel() if workspace is not None else 0, ptr(scratch), nbytes, size_m, size_n,
+                                   size_k, scales.shape[0], dtype_code(a.dtype), mode, stream_of(a)))
+    return out
+
+
 def gptq_marlin_gemm_partial_splits(size_m, size_n, size_k) -> int:
     return int(_lib.load().nmv_gptq_marlin_gemm_partial_splits(size_m, size_n, size_k))
 

@@ -62,6 +62,18 @@ __device__ __forceinline__ uint32_t and_or(uint32_t x, uint32_t mask_sgpr, uint3
   return (x & mask_sgpr) | magic_vgpr;
 }
 
+// Weight vectors that a launch reads once (a single block of rows: M <= 16 mt) are streamed with the
+// non-temporal policy so that they do not displace the activation tile and the scales in the XCD's L2
+// (measured: -2..4 % at M <= 16); with two row blocks the second one finds them in L2 and nt costs 10 %.
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 ld_stream(const uint4* ptr, bool nt) {
+  if (nt) {
+    const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(ptr));
+    return make_uint4(v.x, v.y, v.z, v.w);
+  }
+  return *ptr;
+}
+
 template <typename T> struct W4;
 template <> struct W4<BF16> {
   static constexpr uint32_t MASK = 0x00780078u, MAGIC = 0x41804180u, ONES = 0x3F803F80u;
@@ -107,6 +119,7 @@ struct GemmParams {
   int group_size;         // 32/64/128, or 0 = channelwise (one scale row)
   int k_per_wg;           // k range of one workgroup (multiple of WK*STAGE_K)
   int splits;
+  int native;             // b is the MFMA-native tensor of nmv_w4_native_repack, s / zp are natural [groups, N]
   int epi;                // 1: silu(gate) * up epilogue on column-interleaved gate_up weights (tall
                           //    kernel, splits == 1): c is [M, N/2]
                           // 2: deferred reduction: every workgroup stores its fp32 partial tile in
@@ -533,7 +546,7 @@ __global__ __launch_bounds__(GT) void w4a16_gemm_kernel(const GemmParams p) {
 // 16 MT rows over its k range (lane (r, g): columns chunk*64 + 16 j + 4 g + reg, rows m0 + 16 t + r).
 // Channelwise scales, the in-workgroup K reduction through LDS, then one of: model-dtype store, the
 // silu(gate) * up store, fp32 slabs + ticket + last-arriver sum, or slabs only (deferred reduction).
-template <typename T, int MT, int WN, int WK, int GS>
+template <typename T, int MT, int WN, int WK, int GS, bool NAT = false>
 __device__ __forceinline__ void w4_tall_epilogue(const GemmParams& p, f32x4_t (&accm)[4][MT], uint4* lds,
                                                  int wn, int wk, int lane, int r, int g, int chunk,
                                                  bool chunk_ok, int m0, int split) {
@@ -546,7 +559,8 @@ __device__ __forceinline__ void w4_tall_epilogue(const GemmParams& p, f32x4_t (&
       for (int reg = 0; reg < 4; ++reg) {
         const int c64 = j * 16 + 4 * g + reg;
         const int c = c64 & 31;
-        const int pos = (c64 >> 5) * 32 + ((c & 7) >> 1) * 8 + 2 * (c >> 3) + (c & 1);
+        // Marlin tensors carry channelwise scales in scale_perm_single order, native ones in column order
+        const int pos = NAT ? c64 : (c64 >> 5) * 32 + ((c & 7) >> 1) * 8 + 2 * (c >> 3) + (c & 1);
         const float sv = T::to_float(p.s[(int64_t)chunk * 64 + pos]);
 #pragma unroll
         for (int t = 0; t < MT; ++t) accm[j][t][reg] *= sv;
@@ -748,12 +762,13 @@ __global__ __launch_bounds__(GT, 2) void w4a16_gemm_tall_kernel(const GemmParams
   const int64_t row_u4 = (int64_t)(p.N >> 1) * WV;
   const uint4* bp = p.b + ((int64_t)(chunk_ok ? chunk : 0) * 32 + (n_in * 4 + g)) * WV +
                     ((int64_t)(k_w0 >> 4) + blk) * row_u4;
+  const bool w_nt = gridDim.z == 1;
   auto load_w = [&](int st, uint4 (&w)[KSS * WV]) {
     const uint4* q = bp + (int64_t)min(st, st_last) * (2 * KSS * row_u4);
 #pragma unroll
     for (int ks = 0; ks < KSS; ++ks)
 #pragma unroll
-      for (int h = 0; h < WV; ++h) w[ks * WV + h] = q[ks * 2 * row_u4 + h];
+      for (int h = 0; h < WV; ++h) w[ks * WV + h] = ld_stream(q + ks * 2 * row_u4 + h, w_nt);
   };
   const uint32_t kmask = __builtin_amdgcn_readfirstlane(W4<T>::MASK);
   uint32_t kmagic = W4<T>::MAGIC;
@@ -1000,6 +1015,271 @@ __global__ __launch_bounds__(GT, 2) void w4a16_gemm_tall_kernel(const GemmParams
 }
 
 // ---------------------------------------------------------------------------------------------
+// The MFMA-native weight layout and its kernel (M <= 64, 4-bit, group 128 / channelwise).
+//
+// rocprofv3 PMC and the ablations of the tall kernel put decode at ~70 VALU instructions per
+// KiB of weights, issued by ~1.75 waves per SIMD: the wave program's own instruction issue, not HBM, sets the
+// time.  Three parts of that count are owed to the Marlin tensor being an NVIDIA fragment order: the DPP pair
+// exchange (8 per k-step), per-lane rotate amounts instead of plain shifts (16), and activations that must be
+// re-ordered to the Marlin k order on their way through LDS (four ds_write_b32 per 16 bytes).  The op
+// gptq_marlin_gemm has to take that tensor; the LinearMethod does not: at load time it also builds
+//     native[kstep][chunk][lane] (uint4),  lane = r + 16 g:
+//       dword j  <->  column n = 64 chunk + 16 j + r   (the MFMA A-operand row of tile j)
+//       nibble (s >> 1) + 4 (s & 1) of that dword  <->  k = 32 kstep + 8 g + s,  s = 0..7
+// i.e. exactly one MFMA operand per lane, k in NATURAL order (slot s of lane group g is k 8g + s: the B
+// operand is the activation row's own 16 bytes), pairs (2p, 2p+1) 16 bits apart so that one v_and_or_b32 of
+// x >> 4p makes two numbers, and a wave's k-step is 1 KiB contiguous; a k-step of all chunks is one
+// contiguous band of N * 16 bytes, so the waves of a launch, which advance through k together, sweep memory
+// front to back as they do on the Marlin tensor (the chunk-major order, every wave in a stream of its own
+// 128 KiB apart, measured 10-15 % slower).  bf16 keeps the nibble where it is (128 + q, exponent 2^7: 3 shifts + 4 and_or per dword), fp16
+// moves it up to the top mantissa bits (16 + q, as in the Marlin kernels) to spare its 10-bit sum of
+// activations three more bits of cancellation.  Scales stay the checkpoint's natural [groups, N] tensor and are
+// parked in LDS as fp32 in output-fragment order; zero point and group scale are applied in fp32 on the group
+// accumulators exactly as in the tall kernel.  Everything around the operand path -- 4 waves = WN chunks x WK
+// k groups, 4-slot register ring three stages ahead, one barrier per stage, LDS K reduction, slabs / ticket /
+// deferred / silu epilogues -- is the tall kernel's.
+template <typename T> struct W4N;
+template <> struct W4N<BF16> {   // nibble stays in mantissa bits [3:0]: 128 + q
+  static constexpr uint32_t MASK = 0x000F000Fu, MAGIC = 0x43004300u, ONES = 0x3F803F80u;
+  static constexpr int POS = 0;
+  static constexpr float ZPC = 136.0f;
+};
+template <> struct W4N<F16> {    // nibble in mantissa bits [9:6]: 16 + q
+  static constexpr uint32_t MASK = 0x03C003C0u, MAGIC = 0x4C004C00u, ONES = 0x3C003C00u;
+  static constexpr int POS = 6;
+  static constexpr float ZPC = 24.0f;
+};
+
+template <typename T, int MT, int WN, int WK, int GS>
+__global__ __launch_bounds__(GT, 2) void w4n_gemm_kernel(const GemmParams p) {
+  static_assert(WN * WK == 4, "4 waves per workgroup");
+  static_assert(MT == 1 || MT == 2 || MT == 4, "16, 32 or 64 rows");
+  static_assert(GS == 0 || GS == 128, "group 128 or channelwise");
+  using N4 = W4N<T>;
+  constexpr int MP = 16 * MT;
+  constexpr int KSS = MT >= 4 ? 1 : 2;         // MFMA k-steps per stage
+  constexpr int TS_K = 32 * KSS;
+  constexpr int SPG = 4 / KSS;                 // stages per 128-k scale group
+  constexpr int PPR = 4 * KSS;                 // 16-byte activation pieces per row and stage
+  constexpr int A_U4 = KSS * 4 * MP;           // uint4 per (stage, k-group): [k-step][g][row]
+  constexpr int SC_ROW_U4 = 16;                // one chunk's 64 scales as fp32, [g][reg][j]
+  constexpr int SC_U4 = 4 * SC_ROW_U4;
+  constexpr int MAIN_U4 = 2 * WK * A_U4 + 2 * SC_U4;
+  constexpr int RED_U4 = (WK > 1) ? (WK - 1) * WN * MT * 256 : 0;
+  constexpr int LDS_U4 = MAIN_U4 > RED_U4 ? (MAIN_U4 > GT ? MAIN_U4 : GT) : (RED_U4 > GT ? RED_U4 : GT);
+  __shared__ __attribute__((aligned(16))) uint4 lds[LDS_U4];
+  uint4* a_s = lds;
+  uint4* sc_s = lds + 2 * WK * A_U4;
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wn = wave % WN, wk = wave / WN;
+  const int r = lane & 15, g = lane >> 4;
+  const int n_chunks = p.N >> 6;
+  const int chunk = blockIdx.x * WN + wn;
+  const bool chunk_ok = chunk < n_chunks;
+  const int m0 = blockIdx.z * MP;
+  const int split = blockIdx.y;
+  const int k_wg0 = split * p.k_per_wg;
+  const int k_wg1 = min(k_wg0 + p.k_per_wg, p.K);
+  const int k_per_wave = (k_wg1 - k_wg0) / WK;      // multiple of 4 stages (make_plan)
+  const int k_w0 = k_wg0 + wk * k_per_wave;
+  const int n_stages = k_per_wave / TS_K;
+  const int st_last = __builtin_amdgcn_readfirstlane(n_stages - 1);
+
+  // ---- weights: one 16-byte load per lane and k-step, a wave reads 1 KiB contiguous ----
+  const int64_t kstep_u4 = (int64_t)n_chunks * 64;     // one k-step of every chunk: N * 16 bytes, contiguous
+  const uint4* bp = p.b + ((int64_t)(k_w0 >> 5) * n_chunks + (chunk_ok ? chunk : 0)) * 64 + lane;
+  const bool w_nt = gridDim.z == 1;
+  auto load_w = [&](int st, uint4 (&w)[KSS]) {
+    const uint4* q = bp + (int64_t)min(st, st_last) * (KSS * kstep_u4);
+#pragma unroll
+    for (int ks = 0; ks < KSS; ++ks) w[ks] = ld_stream(q + ks * kstep_u4, w_nt);
+  };
+  const uint32_t kmask = __builtin_amdgcn_readfirstlane(N4::MASK);
+  uint32_t kmagic = N4::MAGIC;
+  asm volatile("" : "+v"(kmagic));
+
+  // ---- activations -> registers -> LDS: a 16-byte piece (row, 8 k) IS the B operand of lane (row, g) ----
+  constexpr int A_CHUNKS = WK * MP * PPR;
+  constexpr int APT = (A_CHUNKS + GT - 1) / GT;
+  static_assert(A_CHUNKS % GT == 0 || A_CHUNKS < GT, "no ragged tail");
+  const uint16_t* ap[APT];
+  int a_dst[APT];
+#pragma unroll
+  for (int i = 0; i < APT; ++i) {
+    const int id = (threadIdx.x + i * GT) % A_CHUNKS;
+    const int c8 = id % PPR, row = (id / PPR) % MP, kg = (id / PPR) / MP;
+    ap[i] = p.a + (int64_t)min(m0 + row, p.M - 1) * p.K + (k_wg0 + kg * k_per_wave) + c8 * 8;
+    // c8 = 4 kstep + g.  The eight pieces of a row go to eight [kstep][g] planes MP * 16 bytes apart -- the same
+    // LDS banks -- so the row index is XOR-swizzled with the plane: a store wave-instruction's groups of 8 lanes
+    // (one row, c8 = 0..7) then cover 8 different bank quads, and a plane read back by 16 lanes (r = 0..15) is
+    // still a permutation of 16 consecutive vectors
+    a_dst[i] = kg * A_U4 + c8 * MP + (row ^ (c8 & 7));
+  }
+  auto load_a = [&](int st, uint4 (&av)[APT]) {
+    const int off = min(st, st_last) * TS_K;
+#pragma unroll
+    for (int i = 0; i < APT; ++i) av[i] = ld16(ap[i] + off);
+  };
+  auto store_a = [&](int buf, const uint4 (&av)[APT]) {
+#pragma unroll
+    for (int i = 0; i < APT; ++i) a_s[buf * WK * A_U4 + a_dst[i]] = av[i];
+  };
+  // scale rows: threads 0..31 = (k-group*WN + wn') x 8 pieces of 16 B (64 columns x 2 B, natural order)
+  const int s_combo = (threadIdx.x >> 3) & 3, s_piece = threadIdx.x & 7;
+  const int s_chunk = min(blockIdx.x * WN + (s_combo % WN), n_chunks - 1);
+  const uint16_t* s_src = p.s + (int64_t)s_chunk * 64 + s_piece * 8;
+  const int s_k0 = k_wg0 + (s_combo / WN) * k_per_wave;
+  auto load_sc = [&](int st) -> uint4 {
+    if constexpr (GS == 0) return make_uint4(0, 0, 0, 0);
+    const int k_abs = min(s_k0 + st * TS_K, p.K - 1);
+    return ld16(s_src + (int64_t)(k_abs / 128) * p.N);
+  };
+  auto store_sc = [&](int gbuf, uint4 v) {
+    if constexpr (GS != 0) {
+      if (threadIdx.x < 32) {
+        // piece pc holds columns 8 pc .. 8 pc + 7 = tile j = pc / 2, lane group g = 2 (pc & 1) + (i >> 2),
+        // reg = i & 3: fp32 destination index (g * 4 + reg) * 4 + j
+        const int slot = threadIdx.x >> 3, pc = threadIdx.x & 7;
+        const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+        float* dst = reinterpret_cast<float*>(sc_s + gbuf * SC_U4 + slot * SC_ROW_U4);
+        const int j = pc >> 1, g0 = 2 * (pc & 1);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float f = (i & 1) ? hi_f<T>(d[i >> 1]) : lo_f<T>(d[i >> 1]);
+          dst[((g0 + (i >> 2)) * 4 + (i & 3)) * 4 + j] = f;
+        }
+      }
+    }
+  };
+
+  f32x4_t accm[4][MT], accg[4][MT], accs[MT];
+  const f32x4_t zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int t = 0; t < MT; ++t) { accm[j][t] = zero4; accg[j][t] = zero4; }
+#pragma unroll
+  for (int t = 0; t < MT; ++t) accs[t] = zero4;
+
+  auto flush = [&](int gbuf) {
+    float zs[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) zs[t] = -N4::ZPC * accs[t][0];
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      f32x4_t d4 = {1.f, 1.f, 1.f, 1.f};
+      if constexpr (GS != 0)
+        d4 = reinterpret_cast<const f32x4_t*>(sc_s + gbuf * SC_U4 + (wk * WN + wn) * SC_ROW_U4)[g * 4 + reg];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+          const float dlt = accg[j][t][reg] + zs[t];
+          if constexpr (GS != 0) accm[j][t][reg] = fmaf(d4[j], dlt, accm[j][t][reg]);
+          else accm[j][t][reg] += dlt;
+        }
+    }
+  };
+
+  // ---- prologue ----
+  uint4 w0[KSS], w1[KSS], w2[KSS], w3[KSS];
+  uint4 ar[APT];
+  uint4 scr = make_uint4(0, 0, 0, 0);
+  load_a(0, ar);
+  scr = load_sc(0);
+  load_w(0, w0);
+  load_w(1, w1);
+  load_w(2, w2);
+  store_a(0, ar);
+  store_sc(0, scr);
+  __syncthreads();
+  const uint4 ones = make_uint4(N4::ONES, N4::ONES, N4::ONES, N4::ONES);
+
+  auto stage = [&](auto u_tag, int st, const uint4 (&wc)[KSS], uint4 (&wfree)[KSS]) {
+    constexpr int U = decltype(u_tag)::value;
+    constexpr int buf = U & 1;
+    constexpr bool closes = (U + 1) % SPG == 0;
+    const int gbuf = SPG == 2 ? ((U >> 1) & 1) : ((st >> 2) & 1);
+    load_a(st + 1, ar);
+    if constexpr (closes) scr = load_sc(st + 1);
+    load_w(st + 3, wfree);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < KSS; ++ks) {
+      const int kstep = (U % SPG) * KSS + ks;
+      const bool first = kstep == 0;
+      uint4 af[MT];
+#pragma unroll
+      for (int t = 0; t < MT; ++t)
+        af[t] = a_s[(buf * WK + wk) * A_U4 + (ks * 4 + g) * MP + ((t * 16 + r) ^ ((ks * 4 + g) & 7))];
+      const uint32_t x4[4] = {wc[ks].x, wc[ks].y, wc[ks].z, wc[ks].w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const uint32_t x = x4[j];
+        // pair p = nibbles p and p + 4: bring nibble p to bit POS of the low half (p + 4 follows in the high half)
+        auto pair = [&](int pz) -> uint32_t {
+          constexpr int dummy = 0; (void)dummy;
+          const int sh = 4 * pz - N4::POS;
+          const uint32_t y = sh == 0 ? x : (sh > 0 ? (x >> sh) : (x << (-sh)));
+          return and_or(y, kmask, kmagic);
+        };
+        const uint4 wv = make_uint4(pair(0), pair(1), pair(2), pair(3));
+#pragma unroll
+        for (int t = 0; t < MT; ++t) accg[j][t] = W4<T>::mfma(wv, af[t], first ? zero4 : accg[j][t]);
+        if constexpr (MT >= 4) __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int t = 0; t < MT; ++t) accs[t] = W4<T>::mfma(ones, af[t], first ? zero4 : accs[t]);
+      if (kstep == 3) flush(gbuf);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    store_a(buf ^ 1, ar);
+    if constexpr (closes) store_sc(gbuf ^ 1, scr);
+    __syncthreads();
+  };
+  for (int st = 0; st < n_stages; st += 4) {
+    stage(std::integral_constant<int, 0>{}, st, w0, w3);
+    stage(std::integral_constant<int, 1>{}, st + 1, w1, w0);
+    stage(std::integral_constant<int, 2>{}, st + 2, w2, w1);
+    stage(std::integral_constant<int, 3>{}, st + 3, w3, w2);
+  }
+  w4_tall_epilogue<T, MT, WN, WK, GS, true>(p, accm, lds, wn, wk, lane, r, g, chunk, chunk_ok, m0, split);
+}
+
+// GPTQ int32 [K/8, N] (8 consecutive k of a column per word, low nibble first; optional act-order row gather
+// `perm`) -> the native tensor above.  One thread per output dword.
+__global__ void w4_native_repack_kernel(const uint32_t* __restrict__ qw, const int* __restrict__ perm,
+                                        uint32_t* __restrict__ out, int K, int N) {
+  const int64_t total = (int64_t)(K / 8) * N;       // dwords
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int j = idx & 3;
+  const int lane = (idx >> 2) & 63;
+  const int64_t blk = idx >> 8;                      // kstep * (N/64) + chunk
+  const int chunks = N >> 6;
+  const int ks = blk / chunks, chunk = blk % chunks;
+  const int r = lane & 15, g = lane >> 4;
+  const int n = chunk * 64 + 16 * j + r;
+  const int k0 = ks * 32 + 8 * g;
+  uint32_t res = 0;
+  if (perm == nullptr) {
+    const uint32_t w = qw[(int64_t)(k0 >> 3) * N + n];
+#pragma unroll
+    for (int sidx = 0; sidx < 8; ++sidx) res |= ((w >> (4 * sidx)) & 0xfu) << (4 * ((sidx >> 1) + 4 * (sidx & 1)));
+  } else {
+#pragma unroll
+    for (int sidx = 0; sidx < 8; ++sidx) {
+      const int ksrc = perm[k0 + sidx];
+      const uint32_t code = (qw[(int64_t)(ksrc >> 3) * N + n] >> (4 * (ksrc & 7))) & 0xfu;
+      res |= code << (4 * ((sidx >> 1) + 4 * (sidx & 1)));
+    }
+  }
+  out[idx] = res;
+}
+
+// ---------------------------------------------------------------------------------------------
 // The decode kernel for M <= 32 ("direct"): the tall kernel's wave tile (one 64-column chunk x 16 MT rows,
 // weights as the MFMA A operand, DPP pair exchange, exponent-trick expansion, fp32 group scaling) with
 // NOTHING shared on the operand path -- no LDS staging of the activations, no barrier in the main loop.
@@ -1195,6 +1475,194 @@ __global__ __launch_bounds__(64 * WN * WK) void w4a16_gemm_direct_kernel(const G
 }
 
 // ---------------------------------------------------------------------------------------------
+// The "ring" decode kernel (M <= 32): the direct kernel's wave program fed by LDS-DMA.
+//
+// What the ablations of the tall and the direct kernel showed (tools/ablate_*.py): with the
+// compute removed both stream their weights at HBM speed, and every piece that is put back -- activation
+// operands, expansion + MFMA, the group flush -- adds its full time: a wave requests the bytes of stage s + 3
+// only when it has finished computing stage s, so the time it computes is time its memory pipe drains
+// (closed loop: bandwidth = bytes in flight / (latency + compute)).  Registers bound the bytes in flight (a
+// 4-slot ring is 6 KiB per wave).  Here the operands of the next DEPTH k-steps are in flight at ALL times and
+// cost no registers: each wave owns a FIFO of DEPTH + 1 slots in LDS, one slot = one 32-k step = 1 KiB of
+// Marlin vectors + MT KiB of activation fragments, filled by global_load_lds_dwordx4 (lane-linear: lane l's 16
+// bytes land at slot + 16 l, which is also where lane l reads them back -- conflict-free, no cross-lane
+// contract, no barrier: only the issuing wave's own vmcnt orders the read behind the fill).  8 waves x 16 KiB
+// = 128 KiB in flight per CU, three times the register ring.
+//
+// hipcc knows nothing of this: the DMA issue and the FIFO reads are inline asm (an LDS-DMA it can see makes it
+// wait vmcnt(0) in front of every LDS read), the waits are counted by hand -- one k-step is 1 + MT DMA
+// instructions, so the operands of step ks are complete when at most DEPTH * (1 + MT) younger ones are
+// outstanding -- and the loop issues exactly one step per step consumed, dummy re-loads of the last step past
+// the end included, which keeps that count constant.  The compiler-visible part of the loop touches neither
+// global memory nor the FIFO.  Scale rows sit in LDS for the whole k range as in the direct kernel.
+// Numerics: the direct / tall kernel's, bit for bit (same operands, same order).
+template <typename T, int MT, int WN, int WK, int GS, int DEPTH>
+__global__ __launch_bounds__(GT) void w4a16_gemm_ring_kernel(const GemmParams p) {
+  static_assert(WN * WK == 4, "4 waves per workgroup");
+  static_assert(MT == 1 || MT == 2, "16 or 32 rows");
+  static_assert(GS == 0 || GS == 128, "group 128 or channelwise");
+  constexpr int MAXG = 16;                       // 128-k groups per wave (k range of a wave <= 2048)
+  constexpr int SC_U4 = 4 * MAXG * 8;            // scale rows [wave slot][group][8 x 16 B]
+  constexpr int SLOT_U4 = 64 * (1 + MT);         // one k-step: weights, then MT activation fragments
+  constexpr int NSLOT = DEPTH + 1;
+  constexpr int FIFO_U4 = NSLOT * SLOT_U4;       // per wave
+  constexpr int RED_U4 = (WK > 1) ? (WK - 1) * WN * MT * 256 : 0;
+  static_assert(4 * FIFO_U4 >= RED_U4 && 4 * FIFO_U4 >= GT, "the epilogue reuses the FIFO space");
+  constexpr int VMC = DEPTH * (1 + MT);          // younger DMA instructions that may still be in flight
+  static_assert(VMC <= 63, "vmcnt is a 6-bit counter");
+  __shared__ __attribute__((aligned(16))) uint4 lds[4 * FIFO_U4 + SC_U4];
+  uint4* sc_all = lds + 4 * FIFO_U4;
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wn = wave % WN, wk = wave / WN;
+  const int r = lane & 15, g = lane >> 4;
+  const int blk = r >> 3, n_in = r & 7;
+  const int n_chunks = p.N >> 6;
+  const int chunk = blockIdx.x * WN + wn;
+  const bool chunk_ok = chunk < n_chunks;
+  const int m0 = blockIdx.z * (16 * MT);
+  const int split = blockIdx.y;
+  const int k_wg0 = split * p.k_per_wg;
+  const int k_wg1 = min(k_wg0 + p.k_per_wg, p.K);
+  const int k_per_wave = (k_wg1 - k_wg0) / WK;      // whole 128-k groups (make_plan)
+  const int k_w0 = k_wg0 + wk * k_per_wave;
+  const int gpw = __builtin_amdgcn_readfirstlane(k_per_wave >> 7);
+  const int nk = gpw * 4;                            // k-steps of this wave
+  const int ks_last = nk - 1;
+
+  // global sources of lane (blk, n_in, q = g) / (r, g): as in the direct kernel
+  const int64_t row_u4 = (int64_t)(p.N >> 1);
+  const uint4* bp = p.b + ((int64_t)(chunk_ok ? chunk : 0) * 32 + (n_in * 4 + g)) +
+                    ((int64_t)(k_w0 >> 4) + blk) * row_u4;
+  const uint16_t* ap[MT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t)
+    ap[t] = p.a + (int64_t)min(m0 + 16 * t + r, p.M - 1) * p.K + k_w0 + 8 * g;
+
+  // LDS byte addresses: the wave's FIFO (uniform) and this lane's 16 bytes inside a slot
+  const uint32_t fifo_base = __builtin_amdgcn_readfirstlane(
+      (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)(lds + wave * FIFO_U4));
+  const uint32_t lane_off = (uint32_t)lane * 16u;
+
+  // fill slot (step % NSLOT) with the operands of k-step min(step, last): 1 + MT LDS-DMA instructions
+  auto issue = [&](int step) {
+    const int ks = min(step, ks_last);
+    const uint32_t dst = __builtin_amdgcn_readfirstlane(fifo_base + (uint32_t)(step % NSLOT) * (SLOT_U4 * 16));
+    const uint4* wsrc = bp + (int64_t)ks * (2 * row_u4);
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(wsrc), "s"(dst) : "memory");
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+      const uint16_t* asrc = ap[t] + ks * 32;
+      const uint32_t adst = dst + 1024u * (1 + t);
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(asrc), "s"(adst) : "memory");
+    }
+  };
+
+  const uint32_t kmask = __builtin_amdgcn_readfirstlane(W4<T>::MASK);
+  uint32_t kmagic = W4<T>::MAGIC;
+  asm volatile("" : "+v"(kmagic));
+  const uint32_t rot_lo = blk ? W4<T>::ROT_LO1 : W4<T>::ROT_LO0;
+  const uint32_t rot_hi = blk ? W4<T>::ROT_HI1 : W4<T>::ROT_HI0;
+  const uint4 ones = make_uint4(W4<T>::ONES, W4<T>::ONES, W4<T>::ONES, W4<T>::ONES);
+
+  f32x4_t accm[4][MT], accg[4][MT], accs[MT];
+  const f32x4_t zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int t = 0; t < MT; ++t) { accm[j][t] = zero4; accg[j][t] = zero4; }
+#pragma unroll
+  for (int t = 0; t < MT; ++t) accs[t] = zero4;
+
+  const uint32_t sc_shift = (g >> 1) * 16;
+  const uint4* sc_mine = sc_all + (wk * WN + wn) * (MAXG * 8) + (g & 1) * 4;
+  auto flush = [&](int grp) {
+    float zs[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) zs[t] = -W4_ZP * accs[t][0];
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      uint4 d4 = make_uint4(0, 0, 0, 0);
+      if constexpr (GS != 0) d4 = sc_mine[grp * 8 + reg];
+      const uint32_t d[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float scv = 1.f;
+        if constexpr (GS != 0) scv = T::to_float((uint16_t)(d[j] >> sc_shift));
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+          const float dlt = accg[j][t][reg] + zs[t];
+          if constexpr (GS != 0) accm[j][t][reg] = fmaf(scv, dlt, accm[j][t][reg]);
+          else accm[j][t][reg] += dlt;
+        }
+      }
+    }
+  };
+
+  // ---- prologue: scale rows (ordinary loads, complete before the barrier), then the first DEPTH steps ----
+  if constexpr (GS != 0) {
+    for (int id = threadIdx.x; id < 4 * gpw * 8; id += GT) {
+      const int piece = id & 7, slot = (id >> 3) & 3, grp = id >> 5;
+      const int s_chunk = min(blockIdx.x * WN + (slot % WN), n_chunks - 1);
+      const int k_abs = k_wg0 + (slot / WN) * k_per_wave + grp * 128;
+      sc_all[(slot * MAXG + grp) * 8 + piece] =
+          ld16(p.s + (int64_t)(k_abs >> 7) * p.N + (int64_t)s_chunk * 64 + piece * 8);
+    }
+  }
+  __syncthreads();
+  for (int st = 0; st < DEPTH; ++st) issue(st);
+
+  for (int grp = 0; grp < gpw; ++grp) {
+#pragma unroll
+    for (int k4 = 0; k4 < 4; ++k4) {
+      const int ks = grp * 4 + k4;
+      issue(ks + DEPTH);
+      // operands of step ks: wait until only the DEPTH younger steps are outstanding, read them back
+      const uint32_t src = fifo_base + (uint32_t)(ks % NSLOT) * (SLOT_U4 * 16) + lane_off;
+      u32x4_t wq, aq[MT];
+      if constexpr (MT == 1)
+        asm volatile("s_waitcnt vmcnt(%3)\n\tds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(wq), "=&v"(aq[0]) : "v"(src), "n"(VMC) : "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(%4)\n\tds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:1024\n\t"
+                     "ds_read_b128 %2, %3 offset:2048\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(wq), "=&v"(aq[0]), "=&v"(aq[MT - 1]) : "v"(src), "n"(VMC) : "memory");
+      uint4 af[MT];
+#pragma unroll
+      for (int t = 0; t < MT; ++t) {
+        u32x2_t s0 = __builtin_amdgcn_permlane32_swap(aq[t][0], aq[t][2], false, false);
+        u32x2_t s1 = __builtin_amdgcn_permlane32_swap(aq[t][1], aq[t][3], false, false);
+        u32x2_t t0 = __builtin_amdgcn_permlane16_swap(s0[0], s1[0], false, false);
+        u32x2_t t1 = __builtin_amdgcn_permlane16_swap(s0[1], s1[1], false, false);
+        af[t] = make_uint4(t0[0], t0[1], t1[0], t1[1]);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const uint32_t e = (uint32_t)__builtin_amdgcn_update_dpp((int)wq[j], (int)wq[j], 0x128, 0xf, 0xc, false);
+        const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp((int)wq[j], (int)wq[j], 0x128, 0xf, 0x3, false);
+        const uint4 wv = make_uint4(and_or(__builtin_amdgcn_alignbit(e, e, rot_lo), kmask, kmagic),
+                                    and_or(__builtin_amdgcn_alignbit(e, e, rot_hi), kmask, kmagic),
+                                    and_or(__builtin_amdgcn_alignbit(o, o, rot_lo), kmask, kmagic),
+                                    and_or(__builtin_amdgcn_alignbit(o, o, rot_hi), kmask, kmagic));
+#pragma unroll
+        for (int t = 0; t < MT; ++t) accg[j][t] = W4<T>::mfma(wv, af[t], k4 == 0 ? zero4 : accg[j][t]);
+      }
+#pragma unroll
+      for (int t = 0; t < MT; ++t) accs[t] = W4<T>::mfma(ones, af[t], k4 == 0 ? zero4 : accs[t]);
+    }
+    flush(grp);
+  }
+  // the dummy fills of the last DEPTH steps are still landing in the FIFO, which the epilogue reuses
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  w4_tall_epilogue<T, MT, WN, WK, GS>(p, accm, lds, wn, wk, lane, r, g, chunk, chunk_ok, m0, split);
+}
+
+// ---------------------------------------------------------------------------------------------
 // gptq_marlin_repack: GPTQ [K/pack, N] -> Marlin [K/16, N*16/pack].  One thread per output int32.
 template <int BITS>
 __global__ void marlin_repack_kernel(const uint32_t* __restrict__ qw, const int* __restrict__ perm,
@@ -1267,6 +1735,7 @@ struct GemmPlan {
   int splits, k_per_wg, m_blocks, n_blocks;
   int tall;      // 1: tall register tile (64 columns x 16 mt rows per wave); wn, wk, mt say which
   int direct;    // 1 (with tall): the barrier-free decode form of the tall tile (M <= 32)
+  int ring;      // 1 (with direct): operands through per-wave LDS-DMA FIFOs
 };
 
 static int env_int(const char* name, int dflt) {
@@ -1278,16 +1747,21 @@ static int env_int(const char* name, int dflt) {
 // few microseconds at HBM speed, so the plan aims at >= ~2 workgroups per CU while keeping the
 // fp32 partial traffic (splits * M * N * 4 B) well below the weight bytes (K * N / 2).
 static GemmPlan make_plan(int M, int N, int K, int64_t tickets_len, bool allow_tall = false,
-                          int bits = 4, bool unsplit = false, bool has_zp = false) {
+                          int bits = 4, bool unsplit = false, bool has_zp = false, bool native = false) {
   GemmPlan pl;
   const int n_chunks = N / 64;
   pl.tall = 0;
   pl.direct = 0;
+  pl.ring = 0;
   // M <= 32, 4-bit symmetric: the direct kernel (w4a16_gemm_direct_kernel) -- same tile, no LDS on the
   // operand path.  A wave's k range is an even number of 128-k groups (ping-pong register sets) and at
   // most 2048 (its scale rows live in LDS).
-  if (allow_tall && bits == 4 && !has_zp && M <= 32 && K % 256 == 0 && env_int("NMV_W4_DIRECT", 0)) {
+  const int want_ring = env_int("NMV_W4_RING", 0);
+  if (allow_tall && bits == 4 && !has_zp && !native && M <= 32 && K % 256 == 0 &&
+      (env_int("NMV_W4_DIRECT", 0) || want_ring)) {
     int wk = env_int("NMV_W4_DIRECT_WK", 4);
+    if (want_ring && wk > 4) wk = 4;
+    pl.ring = want_ring ? 1 : 0;
     while (wk > 1 && K % (256 * wk) != 0) wk >>= 1;
     const int unit = 256 * wk;
     const int k_units = K / unit;
@@ -1408,6 +1882,30 @@ static int launch_gemm_gs(const GemmPlan& pl, const GemmParams& p, hipStream_t s
 #undef NMV_ZP_TALL_CASE
         return -1;
       }
+    }
+    if (p.native) {
+      if (!pl.tall || pl.direct || p.bits != 4 || p.zp != nullptr) return -1;
+#define NMV_W4N_CASE(mt_, wn_, wk_)                                                        \
+  if (pl.mt == mt_ && pl.wn == wn_ && pl.wk == wk_) {                                      \
+    hipLaunchKernelGGL((w4n_gemm_kernel<T, mt_, wn_, wk_, GS>), grid, block, 0, s, p);     \
+    return 0;                                                                              \
+  }
+      NMV_W4N_CASE(1, 4, 1) NMV_W4N_CASE(1, 2, 2) NMV_W4N_CASE(1, 1, 4)
+      NMV_W4N_CASE(2, 4, 1) NMV_W4N_CASE(2, 2, 2) NMV_W4N_CASE(2, 1, 4)
+      NMV_W4N_CASE(4, 4, 1) NMV_W4N_CASE(4, 2, 2) NMV_W4N_CASE(4, 1, 4)
+#undef NMV_W4N_CASE
+      return -1;
+    }
+    if (pl.tall && pl.direct && pl.ring) {
+#define NMV_W4_RING_CASE(mt_, wn_, wk_, depth_)                                                          \
+  if (pl.mt == mt_ && pl.wn == wn_ && pl.wk == wk_) {                                                    \
+    hipLaunchKernelGGL((w4a16_gemm_ring_kernel<T, mt_, wn_, wk_, GS, depth_>), grid, block, 0, s, p);     \
+    return 0;                                                                                            \
+  }
+      NMV_W4_RING_CASE(1, 4, 1, 7) NMV_W4_RING_CASE(1, 2, 2, 7) NMV_W4_RING_CASE(1, 1, 4, 7)
+      NMV_W4_RING_CASE(2, 4, 1, 4) NMV_W4_RING_CASE(2, 2, 2, 4) NMV_W4_RING_CASE(2, 1, 4, 4)
+#undef NMV_W4_RING_CASE
+      return -1;
     }
     if (pl.tall && pl.direct) {
       // the last-arriver reduction of the shared epilogue is written for 256-thread workgroups: the
@@ -1551,7 +2049,7 @@ static int marlin_gemm_impl(void* c, const void* a, const int32_t* b_q_weight, c
                             int32_t* workspace, int64_t workspace_len, void* scratch,
                             int64_t scratch_bytes, int num_bits, int size_m, int size_n, int size_k,
                             int num_groups, int is_k_full, nmv_dtype_t dtype, void* stream,
-                            int epi = 0) {
+                            int epi = 0, int native = 0) {
   // `workspace` (the reference's lock array, zero on entry and exit) holds the split-K tickets
   NMV_CHECK(dtype == NMV_F16 || dtype == NMV_BF16,
             "gpt_marlin_gemm only supports bfloat16 and float16");
@@ -1594,7 +2092,9 @@ static int marlin_gemm_impl(void* c, const void* a, const int32_t* b_q_weight, c
   const bool allow_tall = !has_act_order && (group_size == 0 || group_size == 128);
   const GemmPlan pl = make_plan(size_m, size_n, size_k,
                                 epi == 2 ? INT64_MAX : (workspace ? workspace_len : 0), allow_tall,
-                                num_bits, epi == 1, b_zeros != nullptr);
+                                num_bits, epi == 1, b_zeros != nullptr, native != 0);
+  NMV_CHECK(!native || (pl.tall && pl.mt <= 4 && num_bits == 4 && b_zeros == nullptr && !has_act_order),
+            "w4_native_gemm: needs 4-bit symmetric codes, group 128 or channelwise, K %% 256 == 0, M tiles <= 64 rows");
   NMV_CHECK(epi != 2 || (pl.tall && num_bits == 4 && b_zeros == nullptr),
             "gptq_marlin_gemm_partial: needs 4-bit symmetric codes, group 128 or channelwise, no "
             "act-order, K %% 256 == 0");
@@ -1623,6 +2123,7 @@ static int marlin_gemm_impl(void* c, const void* a, const int32_t* b_q_weight, c
   p.k_per_wg = pl.k_per_wg;
   p.splits = pl.splits;
   p.epi = epi;
+  p.native = native;
   hipStream_t s = (hipStream_t)stream;
   const int rc = dtype == NMV_F16 ? launch_gemm<F16>(pl, p, s) : launch_gemm<BF16>(pl, p, s);
   NMV_CHECK(rc == 0, "gptq_marlin_gemm: no kernel for plan mt=%d wn=%d wm=%d wk=%d", pl.mt, pl.wn,
@@ -1713,4 +2214,39 @@ extern "C" int nmv_marlin_gemm(void* c, const void* a, const int32_t* b_q_weight
   return marlin_gemm_impl(c, a, b_q_weight, b_scales, nullptr, nullptr, nullptr, workspace,
                           workspace_len, scratch, scratch_bytes, 4, size_m, size_n, size_k,
                           num_groups, 1, dtype, stream);
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * MFMA-native W4 tensors (not ops of nm-vllm 0.5.1: what GPTQMarlinLinearMethod keeps beside the Marlin
+ * tensor for decode-sized calls; w4a16_gemm.hip "The MFMA-native weight layout").
+ * nmv_w4_native_repack: GPTQ qweight int32 [K/8, N] (+ optional act-order row gather perm[K]) -> native int32
+ * [N/64 * K/32 * 256].  nmv_w4_native_gemm: C = A . ((q - 8) * s) with s the NATURAL [groups, N] scale tensor;
+ * mode 0 = model-dtype output [M, N] (split-K inside the launch: workspace = zeroed tickets, scratch = slabs),
+ * mode 1 = silu(gate) * up on column-interleaved gate_up weights, output [M, N/2], mode 2 = deferred reduction:
+ * fp32 slabs [splits, M, N] in `scratch`, no output.  M tiles up to 64 rows, K % 256 == 0, N % 64 == 0. */
+extern "C" int nmv_w4_native_repack(const int32_t* qweight, const int32_t* perm, int32_t* out, int size_k,
+                                    int size_n, void* stream) {
+  NMV_CHECK(size_k % 32 == 0 && size_n % 64 == 0, "w4_native_repack: K %% 32 and N %% 64 required");
+  const int64_t total = (int64_t)(size_k / 8) * size_n;
+  if (total == 0) return NMV_OK;
+  hipLaunchKernelGGL(w4_native_repack_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const uint32_t*)qweight, perm, (uint32_t*)out, size_k, size_n);
+  NMV_LAUNCH_CHECK();
+  return NMV_OK;
+}
+
+extern "C" int nmv_w4_native_gemm_splits(int size_m, int size_n, int size_k) {
+  if (size_m <= 0 || size_n <= 0 || size_k <= 0 || size_n % 64 != 0 || size_k % 256 != 0) return 0;
+  const GemmPlan pl = make_plan(size_m, size_n, size_k, INT64_MAX, true, 4, false, false, true);
+  return (pl.tall && pl.mt <= 4) ? pl.splits : 0;
+}
+
+extern "C" int nmv_w4_native_gemm(void* c, const void* a, const int32_t* b_native, const void* b_scales,
+                                  int32_t* workspace, int64_t workspace_len, void* scratch, int64_t scratch_bytes,
+                                  int size_m, int size_n, int size_k, int num_groups, nmv_dtype_t dtype, int mode,
+                                  void* stream) {
+  NMV_CHECK(mode >= 0 && mode <= 2, "w4_native_gemm: mode must be 0, 1 or 2");
+  return marlin_gemm_impl(c, a, b_native, b_scales, nullptr, nullptr, nullptr, mode == 2 ? nullptr : workspace,
+                          mode == 2 ? 0 : workspace_len, scratch, scratch_bytes, 4, size_m, size_n, size_k, num_groups, 1,
+                          dtype, stream, mode, 1);
 }

@@ -245,6 +245,11 @@ class GPTQMarlinLinearMethod(LinearMethodBase):
                                     requires_grad=False)
             layer.g_idx_sort_indices = Parameter(torch.empty(0, dtype=torch.int, device=cur_device),
                                                  requires_grad=False)
+        # decode-sized calls run on the MFMA-native tensor (csrc/w4a16_gemm.hip): built here from the same GPTQ
+        # words, beside the Marlin tensor that the reference's op (and prefill) consumes
+        if self.native_eligible(layer):
+            layer.qweight_native = ops.w4_native_repack(layer.qweight.data, None, part_size_k, part_size_n)
+            layer.scales_native = layer.scales.data.clone()      # natural [groups, N]
         marlin_qweight = ops.gptq_marlin_repack(layer.qweight, layer.g_idx_sort_indices,
                                                 part_size_k, part_size_n, cfg.weight_bits)
         replace_tensor("qweight", marlin_qweight)
@@ -252,6 +257,19 @@ class GPTQMarlinLinearMethod(LinearMethodBase):
         marlin_scales = marlin_permute_scales(layer.scales, scales_size_k, part_size_n,
                                               cfg.group_size, cfg.weight_bits)
         replace_tensor("scales", marlin_scales)
+
+    NATIVE_MAX_M = 64   # rows per call up to which the native kernel is used (its M tiles end at 64 rows)
+
+    def native_eligible(self, layer: torch.nn.Module) -> bool:
+        import os
+        cfg = self.quant_config
+        return (os.environ.get("NMV_W4_NATIVE", "0") == "1" and cfg.weight_bits == 4 and not cfg.desc_act
+                and cfg.group_size in (-1, 128) and layer.input_size_per_partition % 256 == 0
+                and layer.output_size_per_partition % 64 == 0 and layer.is_k_full and layer.qweight.is_cuda)
+
+    @staticmethod
+    def _native(layer, size_m: int) -> bool:
+        return size_m <= GPTQMarlinLinearMethod.NATIVE_MAX_M and getattr(layer, "qweight_native", None) is not None
 
     # ---- deferred split-K: the GEMM leaves fp32 slabs, the following fused_add_rms_norm sums them
     # (ops.gptq_marlin_gemm_partial; not part of the reference's LinearMethod) ----
@@ -268,6 +286,9 @@ class GPTQMarlinLinearMethod(LinearMethodBase):
         if layer.marlin_state == GPTQMarlinState.REPACK:
             layer.marlin_state = GPTQMarlinState.READY
             self._repack(layer)
+        if self._native(layer, reshaped_x.shape[0]):
+            return ops.w4_native_gemm(reshaped_x, layer.qweight_native, layer.scales_native, None, reshaped_x.shape[0],
+                                      layer.output_size_per_partition, layer.input_size_per_partition, mode=2)
         return ops.gptq_marlin_gemm_partial(reshaped_x, layer.qweight, layer.scales, reshaped_x.shape[0],
                                             layer.output_size_per_partition, layer.input_size_per_partition)
 
@@ -306,8 +327,12 @@ class GPTQMarlinLinearMethod(LinearMethodBase):
             layer.gate_up_interleaved = True
             self._repack(layer)
         assert getattr(layer, "gate_up_interleaved", False), "layer was repacked without the interleave"
-        out = ops.gptq_marlin_gemm_silu_mul(reshaped_x, layer.qweight, layer.scales, layer.workspace,
-                                            reshaped_x.shape[0], part_size_n, part_size_k)
+        if self._native(layer, reshaped_x.shape[0]):
+            out = ops.w4_native_gemm(reshaped_x, layer.qweight_native, layer.scales_native, layer.workspace,
+                                     reshaped_x.shape[0], part_size_n, part_size_k, mode=1)
+        else:
+            out = ops.gptq_marlin_gemm_silu_mul(reshaped_x, layer.qweight, layer.scales, layer.workspace,
+                                                reshaped_x.shape[0], part_size_n, part_size_k)
         return out.reshape(x.shape[:-1] + (part_size_n // 2, ))
 
     def apply(self, layer: torch.nn.Module, x: torch.Tensor,
@@ -322,10 +347,14 @@ class GPTQMarlinLinearMethod(LinearMethodBase):
         if layer.marlin_state == GPTQMarlinState.REPACK:
             layer.marlin_state = GPTQMarlinState.READY
             self._repack(layer)
-        output = ops.gptq_marlin_gemm(reshaped_x, layer.qweight, layer.scales, layer.g_idx,
-                                      layer.g_idx_sort_indices, layer.workspace,
-                                      self.quant_config.weight_bits, size_m, part_size_n,
-                                      part_size_k, layer.is_k_full)
+        if self._native(layer, size_m):
+            output = ops.w4_native_gemm(reshaped_x, layer.qweight_native, layer.scales_native, layer.workspace, size_m,
+                                        part_size_n, part_size_k, mode=0)
+        else:
+            output = ops.gptq_marlin_gemm(reshaped_x, layer.qweight, layer.scales, layer.g_idx,
+                                          layer.g_idx_sort_indices, layer.workspace,
+                                          self.quant_config.weight_bits, size_m, part_size_n,
+                                          part_size_k, layer.is_k_full)
         if bias is not None:
             output.add_(bias)
         return output.reshape(out_shape)

@@ -164,7 +164,8 @@ def test_fp8_method(gpu_device, serialized, scheme):
 @pytest.mark.parametrize("strategy,dynamic", [("channel", True), ("tensor", True), ("tensor", False)])
 def test_compressed_tensors_w8a8(gpu_device, strategy, dynamic):
     k, parts, dt, m = 512, [256, 128], torch.bfloat16, 11
-    cfg = {"config_groups": {"g": {"targets": ["Linear"],
+    cfg = {"format": "int-quantized",
+           "config_groups": {"g": {"targets": ["Linear"],
                                    "weights": {"num_bits": 8, "type": "int", "symmetric": True, "strategy": strategy},
                                    "input_activations": {"num_bits": 8, "type": "int", "symmetric": True,
                                                          "dynamic": dynamic, "strategy": "token" if dynamic else "tensor"}}}}
@@ -192,7 +193,8 @@ def test_compressed_tensors_w8a8(gpu_device, strategy, dynamic):
 
 def test_compressed_tensors_wna16(gpu_device):
     k, parts, dt, m = 512, [256, 128], torch.bfloat16, 4
-    cfg = {"config_groups": {"g": {"targets": ["Linear"],
+    cfg = {"format": "pack-quantized",
+           "config_groups": {"g": {"targets": ["Linear"],
                                    "weights": {"num_bits": 4, "type": "int", "symmetric": True,
                                                "strategy": "group", "group_size": 128},
                                    "input_activations": None}}}

@@ -1,0 +1,117 @@
+"""GPU: the MFMA-native W4 tensor (nmv_w4_native_repack) and its kernel (nmv_w4_native_gemm), which
+GPTQMarlinLinearMethod uses for decode-sized calls.  Not ops of the reference: the layout is specified by
+oracle/ref_math.w4_native_weights, the arithmetic is the Marlin kernels' (fp32 group scaling), so the checks
+are: repack bit-equal to the specification (with and without the act-order row gather), GEMM against the
+oracle's a @ w_ref at the reference's tolerance (test_marlin_gemm.py:172-179, < 0.04) and this repo's own
+(< 6e-3), a one-hot row reproducing the rounded dequantised weight bit for bit, and the three modes bit-identical
+to each other's op sequences (deferred slabs summed in split order; silu epilogue vs GEMM + silu_and_mul)."""
+import pytest
+import torch
+
+from oracle import ref_math
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_err(out, ref):
+    return ((out.float() - ref.float()).abs().mean() / ref.float().abs().mean()).item()
+
+
+def problem(seed, m, k, n, group_size, dtype):
+    g = torch.Generator().manual_seed(seed)
+    a = torch.randn((m, k), generator=g).to(dtype)
+    w = torch.randn((k, n), generator=g).to(dtype)
+    w_ref, q_w, s, _, _ = ref_math.quantize_weights(w, 4, group_size, False)
+    return a, q_w, s.to(dtype), w_ref.to(dtype)
+
+
+@pytest.mark.parametrize("k,n", [(256, 64), (1024, 448), (512, 1088)])
+@pytest.mark.parametrize("act_order", [False, True])
+def test_native_repack_matches_specification(gpu_device, k, n, act_order):
+    from neural_magic_vllm_amd import _custom_ops as ops
+    g = torch.Generator().manual_seed(0)
+    q_w = torch.randint(0, 16, (k, n), generator=g, dtype=torch.int32)
+    packed = ref_math.gptq_pack(q_w, 4, k, n).to(gpu_device)
+    perm = torch.randperm(k, generator=g).to(torch.int32) if act_order else None
+    out = ops.w4_native_repack(packed, perm.to(gpu_device) if act_order else None, k, n).cpu()
+    want = ref_math.w4_native_weights(q_w[perm.long()] if act_order else q_w)
+    assert torch.equal(out, want)
+
+
+def native_gemm(a, q_w, s, k, n, dev, mode=0):
+    from neural_magic_vllm_amd import _custom_ops as ops
+    packed = ref_math.gptq_pack(q_w, 4, k, n).to(dev)
+    b = ops.w4_native_repack(packed, None, k, n)
+    ws = torch.zeros(max(n // 64 * 16, 16), dtype=torch.int32, device=dev)
+    out = ops.w4_native_gemm(a.to(dev), b, s.to(dev), ws, a.shape[0], n, k, mode)
+    assert int(ws.abs().sum()) == 0, "the ticket array must be returned zeroed"
+    return out
+
+
+@pytest.mark.parametrize("k,n", [(256, 64), (1024, 448), (2048, 1088), (4096, 6144), (14336, 4096)])
+@pytest.mark.parametrize("m", [1, 13, 16, 17, 32, 40, 64])
+@pytest.mark.parametrize("group_size", [-1, 128])
+@pytest.mark.parametrize("dtype", [torch.half, torch.bfloat16])
+def test_native_gemm(gpu_device, k, n, m, group_size, dtype):
+    a, q_w, s, w_ref = problem(1, m, k, n, group_size, dtype)
+    out = native_gemm(a, q_w, s, k, n, gpu_device).cpu()
+    ref = (a.double() @ w_ref.double()).float()
+    e = rel_err(out, ref)
+    assert e < 0.04 and e < 6e-3, e
+
+
+@pytest.mark.parametrize("mt,wk", [(1, 4), (1, 2), (1, 1), (2, 4), (2, 2), (2, 1), (4, 4), (4, 2), (4, 1)])
+@pytest.mark.parametrize("dtype", [torch.half, torch.bfloat16])
+def test_native_gemm_every_tile_variant(gpu_device, monkeypatch, mt, wk, dtype):
+    monkeypatch.setenv("NMV_W4_TALL_MT", str(mt))
+    monkeypatch.setenv("NMV_W4_TALL_WK", str(wk))
+    k, n, m = 2048, 448, 16 * mt - 3
+    a, q_w, s, w_ref = problem(2, m, k, n, 128, dtype)
+    out = native_gemm(a, q_w, s, k, n, gpu_device).cpu()
+    assert rel_err(out, (a.double() @ w_ref.double()).float()) < 6e-3
+
+
+@pytest.mark.parametrize("dtype", [torch.half, torch.bfloat16])
+@pytest.mark.parametrize("group_size", [-1, 128])
+def test_native_gemm_one_hot_is_exact_dequant(gpu_device, dtype, group_size):
+    """a one-hot activation row selects one weight row: the output must be round((q - 8) * s) exactly"""
+    k, n = 512, 448
+    _, q_w, s, w_ref = problem(3, 1, k, n, group_size, dtype)
+    rows = [0, 1, 7, 8, 31, 32, 127, 128, 255, 511]
+    a = torch.zeros((len(rows), k), dtype=dtype)
+    for i, r in enumerate(rows):
+        a[i, r] = 1.0
+    out = native_gemm(a, q_w, s, k, n, gpu_device).cpu()
+    gs = k if group_size == -1 else group_size
+    want = ((q_w[rows].float() - 8) * s.float()[[r // gs for r in rows]]).to(dtype)
+    assert torch.equal(out.view(torch.int16), want.view(torch.int16))
+
+
+@pytest.mark.parametrize("m", [1, 16, 33, 64])
+@pytest.mark.parametrize("k,n", [(4096, 4096), (14336, 4096), (1024, 6144)])
+@pytest.mark.parametrize("dtype", [torch.half, torch.bfloat16])
+def test_native_deferred_slabs_sum_to_the_gemm(gpu_device, m, k, n, dtype):
+    """mode 2 (deferred reduction): the slabs summed in split order from +0 and rounded are the bits of mode 0"""
+    a, q_w, s, _ = problem(4, m, k, n, 128, dtype)
+    full = native_gemm(a, q_w, s, k, n, gpu_device, 0)
+    slab = native_gemm(a, q_w, s, k, n, gpu_device, 2)
+    acc = torch.zeros_like(slab[0])
+    for i in range(slab.shape[0]):
+        acc = acc + slab[i]
+    assert torch.equal(acc.to(dtype).view(torch.int16), full.view(torch.int16))
+
+
+@pytest.mark.parametrize("m", [1, 16, 64])
+@pytest.mark.parametrize("dtype", [torch.half, torch.bfloat16])
+def test_native_silu_mul_epilogue_matches_separate_ops(gpu_device, m, dtype):
+    from neural_magic_vllm_amd import _custom_ops as ops
+    from neural_magic_vllm_amd.model_executor.layers.quantization.gptq_marlin import GPTQMarlinLinearMethod as LM
+    k, inter = 1024, 3584
+    n = 2 * inter
+    a, q_w, s, _ = problem(5, m, k, n, 128, dtype)
+    plain = native_gemm(a, q_w, s, k, n, gpu_device, 0)
+    want = torch.empty((m, inter), dtype=dtype, device=gpu_device)
+    ops.silu_and_mul(want, plain)
+    qi, si = LM._interleave_gate_up(q_w), LM._interleave_gate_up(s)
+    got = native_gemm(a, qi, si, k, n, gpu_device, 1)
+    assert torch.equal(got.view(torch.int16), want.view(torch.int16))

@@ -17,29 +17,42 @@ SHAPES = {"qkv": (4096, 6144), "o": (4096, 4096), "gate_up": (4096, 28672), "dow
 DEFAULT_SHAPES = "qkv,o,gate_up,down"
 
 
-def bench(name, k, n, m, dev, iters=40, gs=128):
+def bench(name, k, n, m, dev, iters=40, gs=128, native=None, mode=0):
+    """native: None = the Marlin ops (mode 0 gptq_marlin_gemm, 1 ..._silu_mul, 2 ..._partial);
+    0 / 1 / 2 = nmv_w4_native_gemm in that mode"""
     nbytes = k * n // 2
     ncopy = max(2, (600 << 20) // nbytes)
     g = torch.Generator(device=dev).manual_seed(0)
     ws = [torch.randint(-2**31, 2**31 - 1, (k // 16, n * 2), dtype=torch.int32, device=dev, generator=g)
           for _ in range(ncopy)]
+    if native is not None:
+        ws = [w.view(-1) for w in ws]
     sc = [(torch.rand((k // gs, n), device=dev, generator=g) * 0.01).to(torch.bfloat16) for _ in range(ncopy)]
     a = torch.randn((m, k), device=dev, dtype=torch.bfloat16)
     wsp = torch.zeros(n // 64 * 16, dtype=torch.int32, device=dev)
     e = torch.empty(0, dtype=torch.int32, device=dev)
+    def call(i):
+        if native is None:
+            if mode == 1:
+                return ops.gptq_marlin_gemm_silu_mul(a, ws[i], sc[i], wsp, m, n, k)
+            if mode == 2:
+                return ops.gptq_marlin_gemm_partial(a, ws[i], sc[i], m, n, k)
+            return ops.gptq_marlin_gemm(a, ws[i], sc[i], e, e, wsp, 4, m, n, k, True)
+        return ops.w4_native_gemm(a, ws[i], sc[i], wsp, m, n, k, native)
+
     for i in range(min(ncopy, 3)):
-        ops.gptq_marlin_gemm(a, ws[i], sc[i], e, e, wsp, 4, m, n, k, True)
+        call(i)
     torch.cuda.synchronize()
     # capture `iters` back-to-back calls in one hipGraph: device time without host launch cost
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     graph = torch.cuda.CUDAGraph()
     with torch.cuda.stream(side):
-        ops.gptq_marlin_gemm(a, ws[0], sc[0], e, e, wsp, 4, m, n, k, True)
+        call(0)
     torch.cuda.current_stream().wait_stream(side)
     with torch.cuda.graph(graph):
         for i in range(iters):
-            ops.gptq_marlin_gemm(a, ws[i % ncopy], sc[i % ncopy], e, e, wsp, 4, m, n, k, True)
+            call(i % ncopy)
     graph.replay()
     torch.cuda.synchronize()
     st = torch.cuda.current_stream()
@@ -59,6 +72,7 @@ if __name__ == "__main__":
     ap.add_argument("--ms", default="1,16,32,64")
     ap.add_argument("--gs", type=int, default=128, help="group size; -1 = channelwise")
     ap.add_argument("--shapes", default=DEFAULT_SHAPES)
+    ap.add_argument("--native", action="store_true", help="also time nmv_w4_native_gemm (modes 0 and 2)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     ms = [int(x) for x in args.ms.split(",")]
@@ -67,7 +81,17 @@ if __name__ == "__main__":
         for m in ms:
             if not args.sweep:
                 us, gbs = bench(name, k, n, m, dev, gs=k if args.gs == -1 else args.gs)
-                print(f"{name:8s} M={m:3d}  {us:8.1f} us  {gbs:7.0f} GB/s", flush=True)
+                extra = ""
+                if args.native:
+                    gs = k if args.gs == -1 else args.gs
+                    n0, g0 = bench(name, k, n, m, dev, gs=gs, native=0)
+                    extra = f"   native {n0:6.1f} us {g0:6.0f} GB/s"
+                    # the fused forms the decode step issues: silu-mul epilogue on gate_up, deferred split-K elsewhere
+                    md = 1 if name.startswith("gate_up") else 2
+                    mm, _ = bench(name, k, n, m, dev, gs=gs, mode=md)
+                    nm, _ = bench(name, k, n, m, dev, gs=gs, native=md)
+                    extra += f"   {'silu-mul' if md == 1 else 'deferred'}: marlin {mm:6.1f} us  native {nm:6.1f} us"
+                print(f"{name:8s} M={m:3d}  {us:8.1f} us  {gbs:7.0f} GB/s{extra}", flush=True)
                 continue
             res = []
             for mt in (0, 1, 2, 4):
