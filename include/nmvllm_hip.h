@@ -265,9 +265,10 @@ int nmv_silu_and_mul_dynamic_int8_quant(void* out_q, float* scales, const void* 
 int nmv_gptq_marlin_repack(const int32_t* b_q_weight, const int32_t* perm, int32_t* out,
                            int size_k, int size_n, int num_bits, void* stream);
 
-/* bytes of scratch nmv_gptq_marlin_gemm needs for (size_m, size_n, size_k): fp32 split-K slabs
- * plus, with act-order, the permuted copy of A (gptq_marlin.cu:1783-1785 allocates the latter) */
-int64_t nmv_gptq_marlin_gemm_scratch_bytes(int size_m, int size_n, int size_k, int has_act_order);
+/* bytes of scratch nmv_gptq_marlin_gemm needs for (size_m, size_n, size_k): fp32 split-K slabs plus, for the
+ * variants named in `variant` (bit 0: act-order, bit 1: 8-bit codes), the permuted copy of A
+ * (gptq_marlin.cu:1783-1785 allocates the latter) and the slabs of the generic kernel */
+int64_t nmv_gptq_marlin_gemm_scratch_bytes(int size_m, int size_n, int size_k, int variant);
 
 /* gptq_marlin_gemm  (gptq_marlin.cu:1735-1868)
  * c[size_m,size_n] = a[size_m,size_k] @ dequant(b_q_weight) ; a, c, b_scales in `dtype`.
@@ -301,10 +302,12 @@ int nmv_marlin_gemm(void* c, const void* a, const int32_t* b_q_weight, const voi
 
 /* fp8_marlin_gemm  (csrc/quantization/fp8/fp8_marlin.cu:1212-1308): fp8-e4m3 weights packed by
  * pack_fp8_to_int32 + gptq_marlin_repack(bits=8), channelwise (or grouped) scales in
- * marlin_permute_scales order. */
+ * marlin_permute_scales order.  scratch: >= nmv_fp8_marlin_gemm_scratch_bytes() (split-K slabs). */
+int64_t nmv_fp8_marlin_gemm_scratch_bytes(int size_m, int size_n, int size_k);
 int nmv_fp8_marlin_gemm(void* c, const void* a, const int32_t* b_q_weight, const void* b_scales,
-                        int32_t* workspace, int64_t workspace_len, int num_bits, int size_m,
-                        int size_n, int size_k, int num_groups, nmv_dtype_t dtype, void* stream);
+                        int32_t* workspace, int64_t workspace_len, void* scratch, int64_t scratch_bytes,
+                        int num_bits, int size_m, int size_n, int size_k, int num_groups, nmv_dtype_t dtype,
+                        void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * GPTQ (exllama) and AWQ checkpoints  (csrc/ops.h:66-73,119-124)

@@ -104,7 +104,8 @@ SIGNATURES = {
     "nmv_gptq_marlin_gemm": (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _P, _L, _I, _I, _I, _I, _I, _I,
                                   _I, _P]),
     "nmv_marlin_gemm": (_I, [_P, _P, _P, _P, _P, _L, _P, _L, _I, _I, _I, _I, _I, _P]),
-    "nmv_fp8_marlin_gemm": (_I, [_P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _P]),
+    "nmv_fp8_marlin_gemm_scratch_bytes": (_L, [_I, _I, _I]),
+    "nmv_fp8_marlin_gemm": (_I, [_P, _P, _P, _P, _P, _L, _P, _L, _I, _I, _I, _I, _I, _I, _P]),
     "nmv_gptq_gemm": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _L, _P]),
     "nmv_wq_gemm_scratch_bytes": (_L, [_I, _I, _I]),
     "nmv_marlin_zp_gemm": (_I, [_P, _P, _P, _P, _P, _P, _L, _P, _L, _I, _I, _I, _I, _I, _P]),

@@ -268,7 +268,8 @@ def gptq_marlin_gemm(a, b_q_weight, b_scales, g_idx, perm, workspace, num_bits, 
     if size_m == 0:
         return c
     L = _lib.load()
-    nbytes = L.nmv_gptq_marlin_gemm_scratch_bytes(size_m, size_n, size_k, int(has_act_order))
+    nbytes = L.nmv_gptq_marlin_gemm_scratch_bytes(size_m, size_n, size_k,
+                                                  int(has_act_order) | (2 if num_bits == 8 else 0))
     scratch = torch.empty((max(nbytes, 16), ), dtype=torch.uint8, device=a.device)
     with device_guard(a):
         check(L.nmv_gptq_marlin_gemm(
@@ -348,11 +349,15 @@ def fp8_marlin_gemm(a, b_q_weight, b_scales, workspace, num_bits, size_m, size_n
          "a, b_q_weight and b_scales must be contiguous")
     _req(b_scales.dtype == a.dtype and b_scales.shape[-1] == size_n, "b_scales must be [G, size_n] of A's dtype")
     c = torch.empty((size_m, size_n), dtype=a.dtype, device=a.device)
+    if size_m == 0:
+        return c
+    L = _lib.load()
+    nbytes = int(L.nmv_fp8_marlin_gemm_scratch_bytes(size_m, size_n, size_k))
+    scratch = torch.empty((max(nbytes, 16), ), dtype=torch.uint8, device=a.device)
     with device_guard(a):
-        check(_lib.load().nmv_fp8_marlin_gemm(ptr(c), ptr(a), ptr(b_q_weight), ptr(b_scales),
-                                              ptr(workspace), workspace.numel(), num_bits, size_m,
-                                              size_n, size_k, b_scales.shape[0],
-                                              dtype_code(a.dtype), stream_of(a)))
+        check(L.nmv_fp8_marlin_gemm(ptr(c), ptr(a), ptr(b_q_weight), ptr(b_scales), ptr(workspace),
+                                    workspace.numel(), ptr(scratch), scratch.numel(), num_bits, size_m, size_n,
+                                    size_k, b_scales.shape[0], dtype_code(a.dtype), stream_of(a)))
     return c
 
 

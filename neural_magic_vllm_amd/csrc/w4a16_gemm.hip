@@ -25,14 +25,18 @@
 // group boundary   acc_main += s[g,n] * (acc_group - 24 * S_group[m]).
 // fp32 scaling is strictly more accurate than the reference's half-precision (q-8)*s products.
 //
-// Two kernels live here:
+// Three kernels live here:
 //   * w4a16_gemm_tall_kernel -- the default: one wave = one 64-column chunk x 16/32/64/128 rows,
 //     weights straight from registers for all its row tiles (a DPP exchange between lane pairs
 //     replaces the second load), 4-slot register ring, in-workgroup K split; 4- and 8-bit codes;
 //     group 128 / channelwise, no act-order, K in whole rings.
 //   * w4a16_gemm_kernel -- the first kernel of this round (a wave = 128 columns x 16 rows, the
 //     lane mapping described above): groups of 32 / 64, act-order with the full K, K % 256 != 0.
-// Both stage the activations of a stage through LDS once per workgroup in MFMA-operand order and
+//   * w4n_gemm_kernel -- the tall kernel's schedule on an MFMA-native weight tensor (one contiguous 1 KB
+//     wave-load per k-step, no lane exchange, 30 % fewer VALU instructions): opt-in (NMV_W4_NATIVE=1 in
+//     GPTQMarlinLinearMethod) because it measured within +-3 % of the tall kernel and needs a second copy
+//     of the weights (DESIGN.md 3.2 "What was tried").
+// All stage the activations of a stage through LDS once per workgroup in MFMA-operand order and
 // split K across workgroups into fp32 slabs that the LAST workgroup of a tile (ticket in the
 // Marlin `workspace`) sums in a fixed order inside the same launch: bit-reproducible, unlike the
 // reference's lock-based fp16 global reduce (:1054-1110).
@@ -542,7 +546,7 @@ __global__ __launch_bounds__(GT) void w4a16_gemm_kernel(const GemmParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Epilogue shared by the tall and the direct kernel: a wave holds accm[j][t] = its 64-column chunk x
+// Epilogue shared by the tall and the native-layout kernel: a wave holds accm[j][t] = its 64-column chunk x
 // 16 MT rows over its k range (lane (r, g): columns chunk*64 + 16 j + 4 g + reg, rows m0 + 16 t + r).
 // Channelwise scales, the in-workgroup K reduction through LDS, then one of: model-dtype store, the
 // silu(gate) * up store, fp32 slabs + ticket + last-arriver sum, or slabs only (deferred reduction).
@@ -713,9 +717,7 @@ __device__ __forceinline__ void w4_tall_epilogue(const GemmParams& p, f32x4_t (&
 // ZP: per-(group, column) zero points (asymmetric AWQ / GPTQ checkpoints repacked to the Marlin
 // layout): p.zp holds z in the model dtype in the layout of the scales; they travel through LDS
 // with the scales (threads 32..63 stage them) and replace the constant 8 in the correction term.
-// DBG (development builds with -DNMV_W4_ABLATION only): timing ablations -- 1 = no expansion / MFMA, 2 = no
-// activation loads and LDS stores (barriers stay), 4 = no group flush, 8 = no stage barrier; results are garbage
-template <typename T, int MT, int WN, int WK, int GS, bool PS = false, int BITS = 4, bool ZP = false, int DBG = 0>
+template <typename T, int MT, int WN, int WK, int GS, bool PS = false, int BITS = 4, bool ZP = false>
 __global__ __launch_bounds__(GT, 2) void w4a16_gemm_tall_kernel(const GemmParams p) {
   static_assert(!ZP || (BITS == 4 && GS == 128), "zero points: 4-bit, group 128");
   static_assert(WN * WK == 4, "4 waves per workgroup");
@@ -892,7 +894,6 @@ __global__ __launch_bounds__(GT, 2) void w4a16_gemm_tall_kernel(const GemmParams
   __syncthreads();
   const uint4 ones = make_uint4(W4<T>::ONES, W4<T>::ONES, W4<T>::ONES, W4<T>::ONES);
 
-  uint32_t dbg_fold = 0;
   // one stage (U = position in the ring: buffer parity and the scale-group schedule are static):
   // fetch the activations of stage st+1 and the weights of stage st+3 (into the slot stage st-1
   // just released), multiply stage st, park stage st+1's activations, barrier
@@ -902,7 +903,7 @@ __global__ __launch_bounds__(GT, 2) void w4a16_gemm_tall_kernel(const GemmParams
     constexpr bool closes = (U + 1) % SPG == 0;   // last stage of a scale group
     // scale buffer of this stage's group: static for 2 groups per ring, else by ring parity
     const int gbuf = SPG == 2 ? ((U >> 1) & 1) : ((st >> 2) & 1);
-    if constexpr (!(DBG & 2)) load_a(st + 1, ar);
+    load_a(st + 1, ar);
     if constexpr (closes) scr = load_sc(st + 1);  // the next stage opens a group
     load_w(st + 3, wfree);
     __builtin_amdgcn_sched_barrier(0);
@@ -924,11 +925,6 @@ __global__ __launch_bounds__(GT, 2) void w4a16_gemm_tall_kernel(const GemmParams
             ps_z[j] = -zc * ps_s[j];
           }
         }
-      }
-      if constexpr (DBG & 1) {
-#pragma unroll
-        for (int h = 0; h < WV; ++h) dbg_fold ^= wc[ks * WV + h].x ^ wc[ks * WV + h].y ^ wc[ks * WV + h].z ^ wc[ks * WV + h].w;
-        continue;
       }
       uint4 af[MT];
 #pragma unroll
@@ -989,19 +985,13 @@ __global__ __launch_bounds__(GT, 2) void w4a16_gemm_tall_kernel(const GemmParams
       if constexpr (!PS) {
 #pragma unroll
         for (int t = 0; t < GT_; ++t) accs[t] = W4<T>::mfma(ones, af[t], first ? zero4 : accs[t]);
-        if constexpr (!(DBG & 4)) { if (kstep == 3) flush(gbuf); }
-        else if (kstep == 3) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int t = 0; t < GT_; ++t) accm[j][t] += accg[j][t];
-        }
+        if (kstep == 3) flush(gbuf);
       }
     }
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (!(DBG & 2)) store_a(buf ^ 1, ar);
+    store_a(buf ^ 1, ar);
     if constexpr (closes) store_sc(gbuf ^ 1, scr);
-    if constexpr (!(DBG & 8)) __syncthreads();
+    __syncthreads();
   };
   for (int st = 0; st < n_stages; st += 4) {
     stage(std::integral_constant<int, 0>{}, st, w0, w3);
@@ -1010,7 +1000,6 @@ __global__ __launch_bounds__(GT, 2) void w4a16_gemm_tall_kernel(const GemmParams
     stage(std::integral_constant<int, 3>{}, st + 3, w3, w2);
   }
 
-  if constexpr (DBG & 1) accm[0][0][0] += __uint_as_float(dbg_fold);
   w4_tall_epilogue<T, MT, WN, WK, GS>(p, accm, lds, wn, wk, lane, r, g, chunk, chunk_ok, m0, split);
 }
 
@@ -1280,389 +1269,6 @@ __global__ void w4_native_repack_kernel(const uint32_t* __restrict__ qw, const i
 }
 
 // ---------------------------------------------------------------------------------------------
-// The decode kernel for M <= 32 ("direct"): the tall kernel's wave tile (one 64-column chunk x 16 MT rows,
-// weights as the MFMA A operand, DPP pair exchange, exponent-trick expansion, fp32 group scaling) with
-// NOTHING shared on the operand path -- no LDS staging of the activations, no barrier in the main loop.
-//
-// Why: at M <= 16 the tall kernel spends ~70 VALU + 5 MFMA instructions per 1 KiB of weights and parks
-// 47 % of its wave-cycles (rocprofv3 PMC, profiles/r01_gemm_tall_pmc.txt): its activations go global ->
-// registers -> LDS (four scattered ds_write_b32 per 16 bytes, because the MFMA contraction slots follow the
-// Marlin k order {2g, 2g+1, 2g+8, 2g+9} x 2) behind one workgroup barrier per 64 k, so every wave waits for
-// the slowest wave's loads twenty times per kilobyte-row.  Here each lane loads its B operand straight from
-// the activation row in NATURAL order -- 16 bytes = k 8g .. 8g+7 of row r, the fragment-shaped load of the
-// int8 kernel (scaled_mm.hip), which streams at 4.8 TB/s -- and the four lanes (g = 0..3) that hold one row
-// transpose their 4 x 4 dwords in registers with v_permlane32_swap + v_permlane16_swap (4 VALU ops per
-// operand): lane g then holds pairs {g, g+4, g+8, g+12} = k {2g, 2g+1, 2g+8, 2g+9, 2g+16, ...}, the slot
-// order of the expanded weights.  Waves are independent: weights and activations of the next 128-k group
-// are requested while the current group is multiplied (two register sets, ping-pong), the group's scale
-// rows for the workgroup's whole k range are parked in LDS once, before the loop (one barrier per
-// launch).  Fewer live registers than the tall kernel at the same tile => more waves per SIMD to cover
-// the loads.  Every wave re-reads its activation rows from L2 (MT x the weight bytes), which is why this
-// form ends at 32 rows; beyond, the workgroup-shared LDS image of the tall kernel is the cheaper side.
-// Same numerics as the tall kernel: identical MFMA operands in identical order => bit-identical output.
-typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
-
-// DBG (only with -DNMV_W4_ABLATION, a development build): 1 = no expansion / MFMA (the weight words are
-// folded into one register so that the loads stay), 2 = no activation loads, 4 = no group flush -- timing
-// ablations, results are garbage
-template <typename T, int MT, int WN, int WK, int GS, int DBG = 0>
-__global__ __launch_bounds__(64 * WN * WK) void w4a16_gemm_direct_kernel(const GemmParams p) {
-  constexpr int NW = WN * WK;                  // waves per workgroup: 4, or 8 (one chunk, eight k groups)
-  constexpr int NT = 64 * NW;
-  static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
-  static_assert(MT == 1 || MT == 2, "16 or 32 rows");
-  static_assert(GS == 0 || GS == 128, "group 128 or channelwise");
-  constexpr int MAXG = 16;                     // 128-k groups per wave (k range of a wave <= 2048)
-  constexpr int SC_U4 = NW * MAXG * 8;         // [wave slot][group][8 x 16 B]
-  constexpr int RED_U4 = (WK > 1) ? (WK - 1) * WN * MT * 256 : 0;
-  constexpr int LDS_U4 = SC_U4 > RED_U4 ? SC_U4 : (RED_U4 > NT ? RED_U4 : NT);
-  __shared__ __attribute__((aligned(16))) uint4 lds[LDS_U4];
-
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wn = wave % WN, wk = wave / WN;
-  const int r = lane & 15, g = lane >> 4;
-  const int blk = r >> 3, n_in = r & 7;
-  const int n_chunks = p.N >> 6;
-  const int chunk = blockIdx.x * WN + wn;
-  const bool chunk_ok = chunk < n_chunks;
-  const int m0 = blockIdx.z * (16 * MT);
-  const int split = blockIdx.y;
-  const int k_wg0 = split * p.k_per_wg;
-  const int k_wg1 = min(k_wg0 + p.k_per_wg, p.K);
-  const int k_per_wave = (k_wg1 - k_wg0) / WK;      // an even number of 128-k groups (make_plan)
-  const int k_w0 = k_wg0 + wk * k_per_wave;
-  const int gpw = __builtin_amdgcn_readfirstlane(k_per_wave >> 7);
-  const int g_last = gpw - 1;
-
-  // ---- weights: lane (blk, n_in, q = g) streams vector n_in*4+q of k-tile 2 ks + blk (as the tall kernel)
-  const int64_t row_u4 = (int64_t)(p.N >> 1);
-  const uint4* bp = p.b + ((int64_t)(chunk_ok ? chunk : 0) * 32 + (n_in * 4 + g)) +
-                    ((int64_t)(k_w0 >> 4) + blk) * row_u4;
-  // ---- activations: lane (r, g) reads k 8g .. 8g+7 of row m0 + 16 t + r (rows past M: clamped duplicates
-  // that only feed rows which are never stored)
-  const uint16_t* ap[MT];
-#pragma unroll
-  for (int t = 0; t < MT; ++t)
-    ap[t] = p.a + (int64_t)min(m0 + 16 * t + r, p.M - 1) * p.K + k_w0 + 8 * g;
-
-  auto load_group = [&](int grp, uint4 (&w)[4], uint4 (&a)[4][MT]) {
-    const int gi = min(grp, g_last);           // the look-ahead past the end re-reads the last group
-    const uint4* q = bp + (int64_t)gi * (8 * row_u4);
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) w[ks] = q[ks * 2 * row_u4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-      for (int t = 0; t < MT; ++t) {
-        if constexpr (DBG & 2) a[ks][t] = make_uint4(W4<T>::ONES, W4<T>::ONES, W4<T>::ONES, W4<T>::ONES);
-        else a[ks][t] = ld16(ap[t] + gi * 128 + ks * 32);
-      }
-  };
-  uint32_t dbg_fold = 0;
-
-  const uint32_t kmask = __builtin_amdgcn_readfirstlane(W4<T>::MASK);
-  uint32_t kmagic = W4<T>::MAGIC;
-  asm volatile("" : "+v"(kmagic));
-  const uint32_t rot_lo = blk ? W4<T>::ROT_LO1 : W4<T>::ROT_LO0;
-  const uint32_t rot_hi = blk ? W4<T>::ROT_HI1 : W4<T>::ROT_HI0;
-  const uint4 ones = make_uint4(W4<T>::ONES, W4<T>::ONES, W4<T>::ONES, W4<T>::ONES);
-
-  f32x4_t accm[4][MT], accg[4][MT], accs[MT];
-  const f32x4_t zero4 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int j = 0; j < 4; ++j)
-#pragma unroll
-    for (int t = 0; t < MT; ++t) { accm[j][t] = zero4; accg[j][t] = zero4; }
-#pragma unroll
-  for (int t = 0; t < MT; ++t) accs[t] = zero4;
-
-  // output fragment of this lane: columns chunk*64 + 16 j + 4 g + reg; grouped scale layout: element
-  // (4 (g&1) + reg) * 8 + 2 j + (g >> 1) of the chunk's 64 (marlin_permute_scales)
-  const uint32_t sc_shift = (g >> 1) * 16;
-  const uint4* sc_mine = lds + (wk * WN + wn) * (MAXG * 8) + (g & 1) * 4;
-  auto flush = [&](int grp) {
-    float zs[MT];
-#pragma unroll
-    for (int t = 0; t < MT; ++t) zs[t] = -W4_ZP * accs[t][0];
-#pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-      uint4 d4 = make_uint4(0, 0, 0, 0);
-      if constexpr (GS != 0) d4 = sc_mine[grp * 8 + reg];
-      const uint32_t d[4] = {d4.x, d4.y, d4.z, d4.w};
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float scv = 1.f;
-        if constexpr (GS != 0) scv = T::to_float((uint16_t)(d[j] >> sc_shift));
-#pragma unroll
-        for (int t = 0; t < MT; ++t) {
-          const float dlt = accg[j][t][reg] + zs[t];
-          if constexpr (GS != 0) accm[j][t][reg] = fmaf(scv, dlt, accm[j][t][reg]);
-          else accm[j][t][reg] += dlt;
-        }
-      }
-    }
-  };
-
-  auto compute_group = [&](int grp, const uint4 (&w)[4], const uint4 (&a)[4][MT]) {
-    if constexpr (DBG & 1) {
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        dbg_fold ^= w[ks].x ^ w[ks].y ^ w[ks].z ^ w[ks].w;
-#pragma unroll
-        for (int t = 0; t < MT; ++t) dbg_fold ^= a[ks][t].x ^ a[ks][t].w;
-      }
-      return;
-    }
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      // B operands: 4 x 4 dword transpose across the four lanes (g) of a row
-      uint4 af[MT];
-#pragma unroll
-      for (int t = 0; t < MT; ++t) {
-        u32x2_t s0 = __builtin_amdgcn_permlane32_swap(a[ks][t].x, a[ks][t].z, false, false);
-        u32x2_t s1 = __builtin_amdgcn_permlane32_swap(a[ks][t].y, a[ks][t].w, false, false);
-        u32x2_t t0 = __builtin_amdgcn_permlane16_swap(s0[0], s1[0], false, false);
-        u32x2_t t1 = __builtin_amdgcn_permlane16_swap(s0[1], s1[1], false, false);
-        af[t] = make_uint4(t0[0], t0[1], t1[0], t1[1]);
-      }
-      const uint32_t own[4] = {w[ks].x, w[ks].y, w[ks].z, w[ks].w};
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const uint32_t e = (uint32_t)__builtin_amdgcn_update_dpp((int)own[j], (int)own[j], 0x128, 0xf, 0xc, false);
-        const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp((int)own[j], (int)own[j], 0x128, 0xf, 0x3, false);
-        const uint4 wv = make_uint4(and_or(__builtin_amdgcn_alignbit(e, e, rot_lo), kmask, kmagic),
-                                    and_or(__builtin_amdgcn_alignbit(e, e, rot_hi), kmask, kmagic),
-                                    and_or(__builtin_amdgcn_alignbit(o, o, rot_lo), kmask, kmagic),
-                                    and_or(__builtin_amdgcn_alignbit(o, o, rot_hi), kmask, kmagic));
-#pragma unroll
-        for (int t = 0; t < MT; ++t) accg[j][t] = W4<T>::mfma(wv, af[t], ks == 0 ? zero4 : accg[j][t]);
-      }
-#pragma unroll
-      for (int t = 0; t < MT; ++t) accs[t] = W4<T>::mfma(ones, af[t], ks == 0 ? zero4 : accs[t]);
-    }
-    if constexpr (!(DBG & 4)) flush(grp);
-    else
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int t = 0; t < MT; ++t) accm[j][t] += accg[j][t];
-  };
-
-  // ---- prologue: first group's operands, then the scale rows of the workgroup's k range -> LDS ----
-  uint4 wA[4], wB[4];
-  uint4 aA[4][MT], aB[4][MT];
-  load_group(0, wA, aA);
-  if constexpr (GS != 0) {
-    for (int id = threadIdx.x; id < NW * gpw * 8; id += NT) {
-      const int piece = id & 7, slot = (id >> 3) % NW, grp = id / (8 * NW);
-      const int s_chunk = min(blockIdx.x * WN + (slot % WN), n_chunks - 1);
-      const int k_abs = k_wg0 + (slot / WN) * k_per_wave + grp * 128;
-      lds[(slot * MAXG + grp) * 8 + piece] =
-          ld16(p.s + (int64_t)(k_abs >> 7) * p.N + (int64_t)s_chunk * 64 + piece * 8);
-    }
-  }
-  __syncthreads();
-
-  for (int grp = 0; grp < gpw; grp += 2) {
-    load_group(grp + 1, wB, aB);
-    compute_group(grp, wA, aA);
-    load_group(grp + 2, wA, aA);
-    compute_group(grp + 1, wB, aB);
-  }
-  if constexpr (DBG & 1) accm[0][0][0] += __uint_as_float(dbg_fold);
-  w4_tall_epilogue<T, MT, WN, WK, GS>(p, accm, lds, wn, wk, lane, r, g, chunk, chunk_ok, m0, split);
-}
-
-// ---------------------------------------------------------------------------------------------
-// The "ring" decode kernel (M <= 32): the direct kernel's wave program fed by LDS-DMA.
-//
-// What the ablations of the tall and the direct kernel showed (tools/ablate_*.py): with the
-// compute removed both stream their weights at HBM speed, and every piece that is put back -- activation
-// operands, expansion + MFMA, the group flush -- adds its full time: a wave requests the bytes of stage s + 3
-// only when it has finished computing stage s, so the time it computes is time its memory pipe drains
-// (closed loop: bandwidth = bytes in flight / (latency + compute)).  Registers bound the bytes in flight (a
-// 4-slot ring is 6 KiB per wave).  Here the operands of the next DEPTH k-steps are in flight at ALL times and
-// cost no registers: each wave owns a FIFO of DEPTH + 1 slots in LDS, one slot = one 32-k step = 1 KiB of
-// Marlin vectors + MT KiB of activation fragments, filled by global_load_lds_dwordx4 (lane-linear: lane l's 16
-// bytes land at slot + 16 l, which is also where lane l reads them back -- conflict-free, no cross-lane
-// contract, no barrier: only the issuing wave's own vmcnt orders the read behind the fill).  8 waves x 16 KiB
-// = 128 KiB in flight per CU, three times the register ring.
-//
-// hipcc knows nothing of this: the DMA issue and the FIFO reads are inline asm (an LDS-DMA it can see makes it
-// wait vmcnt(0) in front of every LDS read), the waits are counted by hand -- one k-step is 1 + MT DMA
-// instructions, so the operands of step ks are complete when at most DEPTH * (1 + MT) younger ones are
-// outstanding -- and the loop issues exactly one step per step consumed, dummy re-loads of the last step past
-// the end included, which keeps that count constant.  The compiler-visible part of the loop touches neither
-// global memory nor the FIFO.  Scale rows sit in LDS for the whole k range as in the direct kernel.
-// Numerics: the direct / tall kernel's, bit for bit (same operands, same order).
-template <typename T, int MT, int WN, int WK, int GS, int DEPTH>
-__global__ __launch_bounds__(GT) void w4a16_gemm_ring_kernel(const GemmParams p) {
-  static_assert(WN * WK == 4, "4 waves per workgroup");
-  static_assert(MT == 1 || MT == 2, "16 or 32 rows");
-  static_assert(GS == 0 || GS == 128, "group 128 or channelwise");
-  constexpr int MAXG = 16;                       // 128-k groups per wave (k range of a wave <= 2048)
-  constexpr int SC_U4 = 4 * MAXG * 8;            // scale rows [wave slot][group][8 x 16 B]
-  constexpr int SLOT_U4 = 64 * (1 + MT);         // one k-step: weights, then MT activation fragments
-  constexpr int NSLOT = DEPTH + 1;
-  constexpr int FIFO_U4 = NSLOT * SLOT_U4;       // per wave
-  constexpr int RED_U4 = (WK > 1) ? (WK - 1) * WN * MT * 256 : 0;
-  static_assert(4 * FIFO_U4 >= RED_U4 && 4 * FIFO_U4 >= GT, "the epilogue reuses the FIFO space");
-  constexpr int VMC = DEPTH * (1 + MT);          // younger DMA instructions that may still be in flight
-  static_assert(VMC <= 63, "vmcnt is a 6-bit counter");
-  __shared__ __attribute__((aligned(16))) uint4 lds[4 * FIFO_U4 + SC_U4];
-  uint4* sc_all = lds + 4 * FIFO_U4;
-
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wn = wave % WN, wk = wave / WN;
-  const int r = lane & 15, g = lane >> 4;
-  const int blk = r >> 3, n_in = r & 7;
-  const int n_chunks = p.N >> 6;
-  const int chunk = blockIdx.x * WN + wn;
-  const bool chunk_ok = chunk < n_chunks;
-  const int m0 = blockIdx.z * (16 * MT);
-  const int split = blockIdx.y;
-  const int k_wg0 = split * p.k_per_wg;
-  const int k_wg1 = min(k_wg0 + p.k_per_wg, p.K);
-  const int k_per_wave = (k_wg1 - k_wg0) / WK;      // whole 128-k groups (make_plan)
-  const int k_w0 = k_wg0 + wk * k_per_wave;
-  const int gpw = __builtin_amdgcn_readfirstlane(k_per_wave >> 7);
-  const int nk = gpw * 4;                            // k-steps of this wave
-  const int ks_last = nk - 1;
-
-  // global sources of lane (blk, n_in, q = g) / (r, g): as in the direct kernel
-  const int64_t row_u4 = (int64_t)(p.N >> 1);
-  const uint4* bp = p.b + ((int64_t)(chunk_ok ? chunk : 0) * 32 + (n_in * 4 + g)) +
-                    ((int64_t)(k_w0 >> 4) + blk) * row_u4;
-  const uint16_t* ap[MT];
-#pragma unroll
-  for (int t = 0; t < MT; ++t)
-    ap[t] = p.a + (int64_t)min(m0 + 16 * t + r, p.M - 1) * p.K + k_w0 + 8 * g;
-
-  // LDS byte addresses: the wave's FIFO (uniform) and this lane's 16 bytes inside a slot
-  const uint32_t fifo_base = __builtin_amdgcn_readfirstlane(
-      (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)(lds + wave * FIFO_U4));
-  const uint32_t lane_off = (uint32_t)lane * 16u;
-
-  // fill slot (step % NSLOT) with the operands of k-step min(step, last): 1 + MT LDS-DMA instructions
-  auto issue = [&](int step) {
-    const int ks = min(step, ks_last);
-    const uint32_t dst = __builtin_amdgcn_readfirstlane(fifo_base + (uint32_t)(step % NSLOT) * (SLOT_U4 * 16));
-    const uint4* wsrc = bp + (int64_t)ks * (2 * row_u4);
-    uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(wsrc), "s"(dst) : "memory");
-#pragma unroll
-    for (int t = 0; t < MT; ++t) {
-      const uint16_t* asrc = ap[t] + ks * 32;
-      const uint32_t adst = dst + 1024u * (1 + t);
-      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                   : "=&s"(keep) : "v"(asrc), "s"(adst) : "memory");
-    }
-  };
-
-  const uint32_t kmask = __builtin_amdgcn_readfirstlane(W4<T>::MASK);
-  uint32_t kmagic = W4<T>::MAGIC;
-  asm volatile("" : "+v"(kmagic));
-  const uint32_t rot_lo = blk ? W4<T>::ROT_LO1 : W4<T>::ROT_LO0;
-  const uint32_t rot_hi = blk ? W4<T>::ROT_HI1 : W4<T>::ROT_HI0;
-  const uint4 ones = make_uint4(W4<T>::ONES, W4<T>::ONES, W4<T>::ONES, W4<T>::ONES);
-
-  f32x4_t accm[4][MT], accg[4][MT], accs[MT];
-  const f32x4_t zero4 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int j = 0; j < 4; ++j)
-#pragma unroll
-    for (int t = 0; t < MT; ++t) { accm[j][t] = zero4; accg[j][t] = zero4; }
-#pragma unroll
-  for (int t = 0; t < MT; ++t) accs[t] = zero4;
-
-  const uint32_t sc_shift = (g >> 1) * 16;
-  const uint4* sc_mine = sc_all + (wk * WN + wn) * (MAXG * 8) + (g & 1) * 4;
-  auto flush = [&](int grp) {
-    float zs[MT];
-#pragma unroll
-    for (int t = 0; t < MT; ++t) zs[t] = -W4_ZP * accs[t][0];
-#pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-      uint4 d4 = make_uint4(0, 0, 0, 0);
-      if constexpr (GS != 0) d4 = sc_mine[grp * 8 + reg];
-      const uint32_t d[4] = {d4.x, d4.y, d4.z, d4.w};
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float scv = 1.f;
-        if constexpr (GS != 0) scv = T::to_float((uint16_t)(d[j] >> sc_shift));
-#pragma unroll
-        for (int t = 0; t < MT; ++t) {
-          const float dlt = accg[j][t][reg] + zs[t];
-          if constexpr (GS != 0) accm[j][t][reg] = fmaf(scv, dlt, accm[j][t][reg]);
-          else accm[j][t][reg] += dlt;
-        }
-      }
-    }
-  };
-
-  // ---- prologue: scale rows (ordinary loads, complete before the barrier), then the first DEPTH steps ----
-  if constexpr (GS != 0) {
-    for (int id = threadIdx.x; id < 4 * gpw * 8; id += GT) {
-      const int piece = id & 7, slot = (id >> 3) & 3, grp = id >> 5;
-      const int s_chunk = min(blockIdx.x * WN + (slot % WN), n_chunks - 1);
-      const int k_abs = k_wg0 + (slot / WN) * k_per_wave + grp * 128;
-      sc_all[(slot * MAXG + grp) * 8 + piece] =
-          ld16(p.s + (int64_t)(k_abs >> 7) * p.N + (int64_t)s_chunk * 64 + piece * 8);
-    }
-  }
-  __syncthreads();
-  for (int st = 0; st < DEPTH; ++st) issue(st);
-
-  for (int grp = 0; grp < gpw; ++grp) {
-#pragma unroll
-    for (int k4 = 0; k4 < 4; ++k4) {
-      const int ks = grp * 4 + k4;
-      issue(ks + DEPTH);
-      // operands of step ks: wait until only the DEPTH younger steps are outstanding, read them back
-      const uint32_t src = fifo_base + (uint32_t)(ks % NSLOT) * (SLOT_U4 * 16) + lane_off;
-      u32x4_t wq, aq[MT];
-      if constexpr (MT == 1)
-        asm volatile("s_waitcnt vmcnt(%3)\n\tds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024\n\ts_waitcnt lgkmcnt(0)"
-                     : "=&v"(wq), "=&v"(aq[0]) : "v"(src), "n"(VMC) : "memory");
-      else
-        asm volatile("s_waitcnt vmcnt(%4)\n\tds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:1024\n\t"
-                     "ds_read_b128 %2, %3 offset:2048\n\ts_waitcnt lgkmcnt(0)"
-                     : "=&v"(wq), "=&v"(aq[0]), "=&v"(aq[MT - 1]) : "v"(src), "n"(VMC) : "memory");
-      uint4 af[MT];
-#pragma unroll
-      for (int t = 0; t < MT; ++t) {
-        u32x2_t s0 = __builtin_amdgcn_permlane32_swap(aq[t][0], aq[t][2], false, false);
-        u32x2_t s1 = __builtin_amdgcn_permlane32_swap(aq[t][1], aq[t][3], false, false);
-        u32x2_t t0 = __builtin_amdgcn_permlane16_swap(s0[0], s1[0], false, false);
-        u32x2_t t1 = __builtin_amdgcn_permlane16_swap(s0[1], s1[1], false, false);
-        af[t] = make_uint4(t0[0], t0[1], t1[0], t1[1]);
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const uint32_t e = (uint32_t)__builtin_amdgcn_update_dpp((int)wq[j], (int)wq[j], 0x128, 0xf, 0xc, false);
-        const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp((int)wq[j], (int)wq[j], 0x128, 0xf, 0x3, false);
-        const uint4 wv = make_uint4(and_or(__builtin_amdgcn_alignbit(e, e, rot_lo), kmask, kmagic),
-                                    and_or(__builtin_amdgcn_alignbit(e, e, rot_hi), kmask, kmagic),
-                                    and_or(__builtin_amdgcn_alignbit(o, o, rot_lo), kmask, kmagic),
-                                    and_or(__builtin_amdgcn_alignbit(o, o, rot_hi), kmask, kmagic));
-#pragma unroll
-        for (int t = 0; t < MT; ++t) accg[j][t] = W4<T>::mfma(wv, af[t], k4 == 0 ? zero4 : accg[j][t]);
-      }
-#pragma unroll
-      for (int t = 0; t < MT; ++t) accs[t] = W4<T>::mfma(ones, af[t], k4 == 0 ? zero4 : accs[t]);
-    }
-    flush(grp);
-  }
-  // the dummy fills of the last DEPTH steps are still landing in the FIFO, which the epilogue reuses
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  w4_tall_epilogue<T, MT, WN, WK, GS>(p, accm, lds, wn, wk, lane, r, g, chunk, chunk_ok, m0, split);
-}
-
-// ---------------------------------------------------------------------------------------------
 // gptq_marlin_repack: GPTQ [K/pack, N] -> Marlin [K/16, N*16/pack].  One thread per output int32.
 template <int BITS>
 __global__ void marlin_repack_kernel(const uint32_t* __restrict__ qw, const int* __restrict__ perm,
@@ -1734,8 +1340,6 @@ struct GemmPlan {
   int mt, wn, wm, wk;  // kernel shape
   int splits, k_per_wg, m_blocks, n_blocks;
   int tall;      // 1: tall register tile (64 columns x 16 mt rows per wave); wn, wk, mt say which
-  int direct;    // 1 (with tall): the barrier-free decode form of the tall tile (M <= 32)
-  int ring;      // 1 (with direct): operands through per-wave LDS-DMA FIFOs
 };
 
 static int env_int(const char* name, int dflt) {
@@ -1751,44 +1355,6 @@ static GemmPlan make_plan(int M, int N, int K, int64_t tickets_len, bool allow_t
   GemmPlan pl;
   const int n_chunks = N / 64;
   pl.tall = 0;
-  pl.direct = 0;
-  pl.ring = 0;
-  // M <= 32, 4-bit symmetric: the direct kernel (w4a16_gemm_direct_kernel) -- same tile, no LDS on the
-  // operand path.  A wave's k range is an even number of 128-k groups (ping-pong register sets) and at
-  // most 2048 (its scale rows live in LDS).
-  const int want_ring = env_int("NMV_W4_RING", 0);
-  if (allow_tall && bits == 4 && !has_zp && !native && M <= 32 && K % 256 == 0 &&
-      (env_int("NMV_W4_DIRECT", 0) || want_ring)) {
-    int wk = env_int("NMV_W4_DIRECT_WK", 4);
-    if (want_ring && wk > 4) wk = 4;
-    pl.ring = want_ring ? 1 : 0;
-    while (wk > 1 && K % (256 * wk) != 0) wk >>= 1;
-    const int unit = 256 * wk;
-    const int k_units = K / unit;
-    pl.tall = 1;
-    pl.direct = 1;
-    pl.wm = 1;
-    pl.mt = M <= 16 ? 1 : 2;
-    pl.m_blocks = 1;
-    pl.wk = wk;
-    pl.wn = wk >= 4 ? 1 : 4 / wk;
-    pl.n_blocks = (n_chunks + pl.wn - 1) / pl.wn;
-    int splits = std::max(1, env_int("NMV_W4_DIRECT_WGS", 512) / pl.n_blocks);
-    splits = std::min(splits, env_int("NMV_W4_DIRECT_MAX_SPLITS", 8));
-    splits = env_int("NMV_W4_SPLITS", splits);
-    splits = std::max(1, std::min(splits, k_units));
-    if ((int64_t)pl.n_blocks > tickets_len || unsplit) splits = 1;
-    const int min_splits = (K + 2048 * wk - 1) / (2048 * wk);
-    if (min_splits > 1 && ((int64_t)pl.n_blocks > tickets_len || unsplit)) {
-      pl.direct = 0;  // a wave's k range would exceed the scale rows the kernel keeps in LDS
-    } else {
-      splits = std::max(splits, min_splits);
-      pl.k_per_wg = ((k_units + splits - 1) / splits) * unit;
-      pl.splits = (K + pl.k_per_wg - 1) / pl.k_per_wg;
-      return pl;
-    }
-    pl.tall = 0;
-  }
   // K in whole 256-k rings per wave, group 128 / channelwise, no act-order: the tall register
   // tile (measured faster than the kernels below at every M on the Llama-3-8B shapes)
   if (allow_tall && M >= env_int("NMV_W4_TALL_MIN_M", 1) && K % 256 == 0 && env_int("NMV_W4_TALL", 1)) {
@@ -1884,7 +1450,7 @@ static int launch_gemm_gs(const GemmPlan& pl, const GemmParams& p, hipStream_t s
       }
     }
     if (p.native) {
-      if (!pl.tall || pl.direct || p.bits != 4 || p.zp != nullptr) return -1;
+      if (!pl.tall || p.bits != 4 || p.zp != nullptr) return -1;
 #define NMV_W4N_CASE(mt_, wn_, wk_)                                                        \
   if (pl.mt == mt_ && pl.wn == wn_ && pl.wk == wk_) {                                      \
     hipLaunchKernelGGL((w4n_gemm_kernel<T, mt_, wn_, wk_, GS>), grid, block, 0, s, p);     \
@@ -1896,63 +1462,6 @@ static int launch_gemm_gs(const GemmPlan& pl, const GemmParams& p, hipStream_t s
 #undef NMV_W4N_CASE
       return -1;
     }
-    if (pl.tall && pl.direct && pl.ring) {
-#define NMV_W4_RING_CASE(mt_, wn_, wk_, depth_)                                                          \
-  if (pl.mt == mt_ && pl.wn == wn_ && pl.wk == wk_) {                                                    \
-    hipLaunchKernelGGL((w4a16_gemm_ring_kernel<T, mt_, wn_, wk_, GS, depth_>), grid, block, 0, s, p);     \
-    return 0;                                                                                            \
-  }
-      NMV_W4_RING_CASE(1, 4, 1, 7) NMV_W4_RING_CASE(1, 2, 2, 7) NMV_W4_RING_CASE(1, 1, 4, 7)
-      NMV_W4_RING_CASE(2, 4, 1, 4) NMV_W4_RING_CASE(2, 2, 2, 4) NMV_W4_RING_CASE(2, 1, 4, 4)
-#undef NMV_W4_RING_CASE
-      return -1;
-    }
-    if (pl.tall && pl.direct) {
-      // the last-arriver reduction of the shared epilogue is written for 256-thread workgroups: the
-      // 8-wave form runs unsplit or with deferred reduction only
-      if (pl.wn * pl.wk == 8 && pl.splits > 1 && p.epi != 2) return -1;
-#ifdef NMV_W4_ABLATION
-      if constexpr (GS == 128 && std::is_same<T, BF16>::value) {
-        const int dbg = env_int("NMV_W4_DBG", 0);
-#define NMV_W4_DBG_CASE(wk_, dbg_)                                                                               \
-  if (dbg == dbg_ && pl.mt == 1 && pl.wn == 1 && pl.wk == wk_) {                                                 \
-    hipLaunchKernelGGL((w4a16_gemm_direct_kernel<T, 1, 1, wk_, GS, dbg_>), grid, dim3(64 * wk_), 0, s, p);         \
-    return 0;                                                                                                    \
-  }
-        NMV_W4_DBG_CASE(4, 1) NMV_W4_DBG_CASE(4, 2) NMV_W4_DBG_CASE(4, 3) NMV_W4_DBG_CASE(4, 4) NMV_W4_DBG_CASE(4, 6)
-        NMV_W4_DBG_CASE(8, 1) NMV_W4_DBG_CASE(8, 2) NMV_W4_DBG_CASE(8, 3) NMV_W4_DBG_CASE(8, 4) NMV_W4_DBG_CASE(8, 6)
-#undef NMV_W4_DBG_CASE
-      }
-#endif
-#define NMV_W4_DIRECT_CASE(mt_, wn_, wk_)                                                        \
-  if (pl.mt == mt_ && pl.wn == wn_ && pl.wk == wk_) {                                            \
-    hipLaunchKernelGGL((w4a16_gemm_direct_kernel<T, mt_, wn_, wk_, GS>), grid, dim3(64 * wn_ * wk_), 0, s, p);  \
-    return 0;                                                                                    \
-  }
-      NMV_W4_DIRECT_CASE(1, 4, 1) NMV_W4_DIRECT_CASE(1, 2, 2) NMV_W4_DIRECT_CASE(1, 1, 4) NMV_W4_DIRECT_CASE(1, 1, 8)
-      NMV_W4_DIRECT_CASE(2, 4, 1) NMV_W4_DIRECT_CASE(2, 2, 2) NMV_W4_DIRECT_CASE(2, 1, 4) NMV_W4_DIRECT_CASE(2, 1, 8)
-#undef NMV_W4_DIRECT_CASE
-      return -1;
-    }
-#ifdef NMV_W4_ABLATION
-    if constexpr (GS == 128 && std::is_same<T, BF16>::value) {
-      const int dbg = env_int("NMV_W4_DBG", 0);
-      if (pl.tall && dbg && p.bits == 4 && p.zp == nullptr) {
-#define NMV_W4_TDBG_CASE(mt_, wn_, wk_, dbg_)                                                                    \
-  if (dbg == dbg_ && pl.mt == mt_ && pl.wn == wn_ && pl.wk == wk_) {                                             \
-    hipLaunchKernelGGL((w4a16_gemm_tall_kernel<T, mt_, wn_, wk_, GS, false, 4, false, dbg_>), grid, block, 0, s, p); \
-    return 0;                                                                                                    \
-  }
-#define NMV_W4_TDBG_ALL(mt_, wn_, wk_)                                                                           \
-  NMV_W4_TDBG_CASE(mt_, wn_, wk_, 1) NMV_W4_TDBG_CASE(mt_, wn_, wk_, 2) NMV_W4_TDBG_CASE(mt_, wn_, wk_, 4)        \
-  NMV_W4_TDBG_CASE(mt_, wn_, wk_, 6) NMV_W4_TDBG_CASE(mt_, wn_, wk_, 10) NMV_W4_TDBG_CASE(mt_, wn_, wk_, 14)     \
-  NMV_W4_TDBG_CASE(mt_, wn_, wk_, 15)
-        NMV_W4_TDBG_ALL(1, 1, 4) NMV_W4_TDBG_ALL(2, 2, 2) NMV_W4_TDBG_ALL(2, 1, 4) NMV_W4_TDBG_ALL(4, 2, 2) NMV_W4_TDBG_ALL(4, 1, 4)
-#undef NMV_W4_TDBG_ALL
-#undef NMV_W4_TDBG_CASE
-      }
-    }
-#endif
     if (pl.tall) {
 #define NMV_W4_TALL_CASE(mt_, wn_, wk_)                                                        \
   if (pl.mt == mt_ && pl.wn == wn_ && pl.wk == wk_) {                                          \
@@ -2003,10 +1512,11 @@ static int launch_gemm(const GemmPlan& pl, const GemmParams& p, hipStream_t s) {
 }
 
 // csrc/wq_generic.hip: LDS-staged generic path for the Marlin variants not covered above
+int64_t wq_marlin_fallback_scratch_bytes(int size_m, int size_n, int size_k);
 int wq_marlin_fallback(void* c, const void* a, const int32_t* b_q_weight, const void* b_scales,
                        const int32_t* g_idx, const int32_t* perm, int num_bits, int size_m,
                        int size_n, int size_k, int num_groups, int is_fp8, nmv_dtype_t dtype,
-                       hipStream_t stream);
+                       void* scratch, int64_t scratch_bytes, hipStream_t stream);
 
 }  // namespace nmv
 
@@ -2031,8 +1541,8 @@ extern "C" int nmv_gptq_marlin_repack(const int32_t* b_q_weight, const int32_t* 
   return NMV_OK;
 }
 
-extern "C" int64_t nmv_gptq_marlin_gemm_scratch_bytes(int size_m, int size_n, int size_k,
-                                                      int has_act_order) {
+extern "C" int64_t nmv_gptq_marlin_gemm_scratch_bytes(int size_m, int size_n, int size_k, int variant) {
+  const bool has_act_order = (variant & 1) != 0;
   // the A gather is fused into the LDS staging: no a_tmp copy, only the split-K slabs
   if (size_m <= 0 || size_n <= 0 || size_k <= 0) return 0;
   // upper bound over every plan the entry point may pick (the ticket array only lowers splits)
@@ -2041,7 +1551,10 @@ extern "C" int64_t nmv_gptq_marlin_gemm_scratch_bytes(int size_m, int size_n, in
     max_splits = std::max(max_splits, make_plan(size_m, size_n, size_k, INT64_MAX, true, 4).splits);
     max_splits = std::max(max_splits, make_plan(size_m, size_n, size_k, INT64_MAX, true, 8).splits);
   }
-  return max_splits > 1 ? (int64_t)max_splits * size_m * size_n * 4 : 0;
+  // ... and of the generic kernel that takes the remaining variants (8-bit groups of 32 / 64, act-order on a K
+  // shard): its gathered activations + slabs
+  const int64_t tuned = max_splits > 1 ? (int64_t)max_splits * size_m * size_n * 4 : (int64_t)0;
+  return variant ? std::max(tuned, wq_marlin_fallback_scratch_bytes(size_m, size_n, size_k)) : tuned;
 }
 
 static int marlin_gemm_impl(void* c, const void* a, const int32_t* b_q_weight, const void* b_scales,
@@ -2082,7 +1595,8 @@ static int marlin_gemm_impl(void* c, const void* a, const int32_t* b_q_weight, c
     // through g_idx), take the generic LDS-staged kernel; same math, not HBM-tuned
     const int rc = wq_marlin_fallback(c, a, b_q_weight, b_scales, has_act_order ? g_idx : nullptr,
                                       has_act_order ? perm : nullptr, num_bits, size_m, size_n,
-                                      size_k, num_groups, 0, dtype, (hipStream_t)stream);
+                                      size_k, num_groups, 0, dtype, scratch, scratch_bytes, (hipStream_t)stream);
+    NMV_CHECK(rc != -2, "gptq_marlin_gemm: scratch too small (see nmv_gptq_marlin_gemm_scratch_bytes)");
     NMV_CHECK(rc == 0, "gptq_marlin_gemm: generic path launch failed");
     NMV_LAUNCH_CHECK();
     return NMV_OK;

@@ -133,15 +133,146 @@ template <> struct Mfma16<F16> {
   }
 };
 
+// ---- the same element definitions, word by word: a thread's dequantisation cell is 8 consecutive k of one
+// column; its packed words, group ids, scale and zero point are fetched as raw words AHEAD of their use (the
+// generic kernel below runs them through a three-deep register pipeline), and decoded when they are consumed ----
+struct WqRaw {
+  uint32_t w[8];   // packed words holding the 8 codes (GPTQ 1-2, Marlin 4, AWQ 8)
+  int gi[8];       // group of every k (g_idx formats), else gi[0] only
+  bool uniform;    // the 8 k share one group (always without g_idx): scale / zero are those of gi[0]
+};
+struct WqSz { uint32_t sw; uint32_t zw[2]; };   // raw scale element and zero-point word(s) of (group, column)
+
+template <int FMT>
+__device__ __forceinline__ void wq_load_raw(const WqParams& p, int k8, int n, WqRaw& r) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r.w[i] = 0;
+  if constexpr (FMT == WQ_GPTQ) {
+    if (p.bits == 4) {
+      r.w[0] = p.qweight[(int64_t)(k8 >> 3) * p.N + n];
+    } else if (p.bits == 8) {
+      r.w[0] = p.qweight[(int64_t)(k8 >> 2) * p.N + n];
+      r.w[1] = p.qweight[(int64_t)((k8 >> 2) + 1) * p.N + n];
+    } else if (p.bits == 2) {
+      r.w[0] = p.qweight[(int64_t)(k8 >> 4) * p.N + n];
+    } else {  // 3 bits: the cell is 24 bits of the 96-bit stream of its 32-k run, from bit 0 / 24 / 48 / 72
+      const int wi = ((k8 & 31) * 3) >> 5;
+      const uint32_t* col = p.qweight + (int64_t)((k8 >> 5) * 3) * p.N + n;
+      r.w[0] = col[(int64_t)wi * p.N];
+      r.w[1] = wi < 2 ? col[(int64_t)(wi + 1) * p.N] : 0;
+    }
+  } else if constexpr (FMT == WQ_AWQ) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) r.w[e] = p.qweight[(int64_t)(k8 + e) * (p.N / 8) + (n >> 3)];
+  } else {
+    const int kt = k8 >> 4, chunk = n >> 6, c64 = n & 63;
+    const int j = c64 >> 4, blk = (c64 >> 3) & 1, n_in = c64 & 7;
+    if (p.bits == 4) {
+      const uint32_t* base = p.qweight + (int64_t)kt * (p.N * 2) + chunk * 128 + n_in * 16 + j;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) r.w[q] = base[q * 4];
+    } else {
+      const uint32_t* base = p.qweight + (int64_t)kt * (p.N * 4) + chunk * 256 + n_in * 32 + j * 2 + blk;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) r.w[q] = base[q * 8];
+    }
+  }
+  if (p.g_idx) {
+    const int4 g0 = *reinterpret_cast<const int4*>(p.g_idx + k8);
+    const int4 g1 = *reinterpret_cast<const int4*>(p.g_idx + k8 + 4);
+    r.gi[0] = g0.x; r.gi[1] = g0.y; r.gi[2] = g0.z; r.gi[3] = g0.w;
+    r.gi[4] = g1.x; r.gi[5] = g1.y; r.gi[6] = g1.z; r.gi[7] = g1.w;
+    r.uniform = (g0.x == g0.y) & (g0.x == g0.z) & (g0.x == g0.w) & (g0.x == g1.x) & (g0.x == g1.y) &
+                (g0.x == g1.z) & (g0.x == g1.w);
+  } else {
+    r.gi[0] = p.group_size > 0 ? k8 / p.group_size : 0;   // groups are multiples of 8 k
+    r.uniform = true;
+  }
+}
+
+// code of element e (k = k8 + e) of the cell
+template <int FMT>
+__device__ __forceinline__ uint32_t wq_raw_code(const WqParams& p, const WqRaw& r, int k8, int n, int e) {
+  if constexpr (FMT == WQ_GPTQ) {
+    if (p.bits == 4) return (r.w[0] >> (4 * e)) & 0xf;
+    if (p.bits == 8) return (r.w[e >> 2] >> (8 * (e & 3))) & 0xff;
+    if (p.bits == 2) return (r.w[0] >> (2 * ((k8 & 15) + e))) & 3u;
+    const uint64_t v = ((uint64_t)r.w[1] << 32) | r.w[0];
+    return (uint32_t)(v >> ((((k8 & 31) * 3) & 31) + 3 * e)) & 7u;
+  } else if constexpr (FMT == WQ_AWQ) {
+    const int c = n & 7;
+    return (r.w[e] >> (4 * (((c & 1) << 2) | (c >> 1)))) & 0xf;
+  } else {
+    const int blk = (n >> 3) & 1, hi8 = (k8 >> 3) & 1, odd = e & 1;
+    if (p.bits == 4) return (r.w[e >> 1] >> (4 * ((odd << 2) | (blk << 1) | hi8))) & 0xf;
+    return (r.w[e >> 1] >> (8 * ((odd << 1) | hi8))) & 0xff;
+  }
+}
+
+template <int FMT>
+__device__ __forceinline__ void wq_load_sz(const WqParams& p, int g, int n, WqSz& z) {
+  int pos = n;
+  if constexpr (FMT == WQ_MARLIN || FMT == WQ_MARLIN_FP8) {
+    if (p.num_groups > 1) { const int c = n & 63; pos = (n & ~63) + (c & 7) * 8 + (c >> 3); }
+    else { const int c = n & 31; pos = (n & ~31) + ((c & 7) >> 1) * 8 + 2 * (c >> 3) + (c & 1); }
+  }
+  z.sw = p.scales[(int64_t)g * p.N + pos];
+  z.zw[0] = z.zw[1] = 0;
+  if constexpr (FMT == WQ_GPTQ) {
+    if (p.qzeros != nullptr) {
+      if (p.bits == 3) {
+        const int wi = ((n & 31) * 3) >> 5;
+        const uint32_t* row = p.qzeros + (int64_t)g * (p.N * 3 / 32) + (n >> 5) * 3;
+        z.zw[0] = row[wi];
+        z.zw[1] = wi < 2 ? row[wi + 1] : 0;
+      } else {
+        z.zw[0] = p.qzeros[(int64_t)g * (p.N / (32 / p.bits)) + n / (32 / p.bits)];
+      }
+    }
+  } else if constexpr (FMT == WQ_AWQ) {
+    z.zw[0] = p.qzeros[(int64_t)g * (p.N / 8) + (n >> 3)];
+  }
+}
+
+template <typename T, int FMT>
+__device__ __forceinline__ void wq_decode_sz(const WqParams& p, const WqSz& z, int n, float& scale, float& zero) {
+  scale = T::to_float((uint16_t)z.sw);
+  if constexpr (FMT == WQ_GPTQ) {
+    if (p.qzeros == nullptr) zero = (float)(1 << (p.bits - 1));
+    else if (p.bits == 3) {
+      const uint64_t v = ((uint64_t)z.zw[1] << 32) | z.zw[0];
+      zero = (float)(((uint32_t)(v >> (((n & 31) * 3) & 31)) & 7u) + 1);
+    } else {
+      const int pack = 32 / p.bits;
+      zero = (float)(((z.zw[0] >> (p.bits * (n % pack))) & ((1u << p.bits) - 1)) + 1);
+    }
+  } else if constexpr (FMT == WQ_AWQ) {
+    const int c = n & 7;
+    zero = (float)((z.zw[0] >> (4 * (((c & 1) << 2) | (c >> 1)))) & 0xf);
+  } else {
+    zero = (float)(1 << (p.bits - 1));
+  }
+}
+
+// Generic kernel: any format of this file, any group structure (g_idx runs of any length), M <= 64 rows per
+// workgroup.  grid = (N / 64, split-K, M blocks); K is split across workgroups into fp32 slabs that
+// wq_reduce_kernel sums in split order (slab == nullptr: one split, direct store).  A workgroup's four waves
+// dequantise a 64-column x 32-k tile per step into LDS in MFMA-operand order (w = (q - z) * s rounded to the
+// model dtype: the reference's reconstruct-then-GEMM numerics) and multiply it against all its rows.  Every
+// global operand is fetched ahead of its use: the packed words and group ids three steps ahead, the scale / zero
+// point of a cell whose 8 k share a group two steps ahead, the activation fragment one step ahead; only cells
+// that straddle a group boundary look their scales up element by element.
 template <typename T, int FMT, int MT>
-__global__ __launch_bounds__(256) void wq_gemm_kernel(const WqParams p) {
+__global__ __launch_bounds__(256) void wq_gemm_kernel(const WqParams p, float* __restrict__ slab, int k_per_wg) {
   // [2 buffers][64 columns][32 k] in the model dtype; row = one column's 32 k values (64 B)
   __shared__ __attribute__((aligned(16))) uint16_t w_s[2][64][32 + 8];  // +8: spread rows over banks
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r = lane & 15, g = lane >> 4;
   const int n0 = blockIdx.x * 64;
-  const int m0 = blockIdx.y * (16 * MT);
+  const int m0 = blockIdx.z * (16 * MT);
+  const int k_lo = blockIdx.y * k_per_wg;
+  const int k_hi = min(k_lo + k_per_wg, p.K);
   // dequantisation cell of this thread: column dn, k group dk (8 consecutive k)
   const int dn = threadIdx.x & 63, dk = threadIdx.x >> 6;
   const int n_d = min(n0 + dn, p.N - 1);
@@ -150,48 +281,70 @@ __global__ __launch_bounds__(256) void wq_gemm_kernel(const WqParams p) {
 #pragma unroll
   for (int t = 0; t < MT; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  auto dequant = [&](int buf, int k0) {
-    uint32_t pk[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float lo = wq_weight<T, FMT>(p, k0 + dk * 8 + 2 * e, n_d);
-      const float hi = wq_weight<T, FMT>(p, k0 + dk * 8 + 2 * e + 1, n_d);
-      pk[e] = T::pack2(lo, hi);
-    }
-    *reinterpret_cast<uint4*>(&w_s[buf][dn][dk * 8]) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+  const int ksteps = (k_hi - k_lo) / 32;
+  auto cell_k = [&](int ks) { return k_lo + min(ks, ksteps - 1) * 32 + dk * 8; };  // look-ahead past the end re-reads
+  auto load_sz = [&](const WqRaw& raw, WqSz& z) {
+    if (raw.uniform) wq_load_sz<FMT>(p, raw.gi[0], n_d, z);
   };
-
-  const int ksteps = p.K / 32;
-  dequant(0, 0);
-  __syncthreads();
-  for (int ks = 0; ks < ksteps; ++ks) {
-    const int buf = ks & 1;
-    const int k0 = ks * 32;
-    if (ks + 1 < ksteps) dequant(buf ^ 1, k0 + 32);
-    // activation fragments: rows m0 + 16 t + r, k = k0 + 8 g .. + 8 (gathered through perm if given)
-    uint4 af[MT];
+  auto dequant = [&](int buf, int ks, const WqRaw& raw, const WqSz& z) {
+    const int k8 = cell_k(ks);
+    float sc = 0.f, zr = 0.f;
+    if (raw.uniform) wq_decode_sz<T, FMT>(p, z, n_d, sc, zr);
+    float wv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      if (!raw.uniform) {  // the cell straddles a group boundary (act-order runs)
+        WqSz ze;
+        wq_load_sz<FMT>(p, raw.gi[e], n_d, ze);
+        wq_decode_sz<T, FMT>(p, ze, n_d, sc, zr);
+      }
+      const uint32_t code = wq_raw_code<FMT>(p, raw, k8, n_d, e);
+      if constexpr (FMT == WQ_MARLIN_FP8) wv[e] = T::to_float(T::from_float(fp8_to_f32((uint8_t)code) * sc));
+      else wv[e] = T::to_float(T::from_float(((float)code - zr) * sc));
+    }
+    *reinterpret_cast<uint4*>(&w_s[buf][dn][dk * 8]) =
+        make_uint4(T::pack2(wv[0], wv[1]), T::pack2(wv[2], wv[3]), T::pack2(wv[4], wv[5]), T::pack2(wv[6], wv[7]));
+  };
+  // activation fragments: rows m0 + 16 t + r, k = k0 + 8 g .. + 8 (act-order: the caller has gathered the columns)
+  auto load_a = [&](int ks, uint4 (&af)[MT]) {
+    const int k0 = k_lo + min(ks, ksteps - 1) * 32;
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
       const int m = m0 + t * 16 + r;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (m < p.M) {
-        const uint16_t* row = p.a + (int64_t)m * p.K;
-        if (p.perm == nullptr) {
-          v = ld16(row + k0 + g * 8);
-        } else {
-          uint16_t e[8];
-#pragma unroll
-          for (int j = 0; j < 8; ++j) e[j] = row[p.perm[k0 + g * 8 + j]];
-          v = make_uint4(e[0] | ((uint32_t)e[1] << 16), e[2] | ((uint32_t)e[3] << 16),
-                         e[4] | ((uint32_t)e[5] << 16), e[6] | ((uint32_t)e[7] << 16));
-        }
-      }
-      af[t] = v;
+      af[t] = m < p.M ? ld16(p.a + (int64_t)m * p.K + k0 + g * 8) : make_uint4(0, 0, 0, 0);
     }
-    const uint4 wf = *reinterpret_cast<const uint4*>(&w_s[buf][wave * 16 + r][g * 8]);
-#pragma unroll
-    for (int t = 0; t < MT; ++t) acc[t] = Mfma16<T>::run(wf, af[t], acc[t]);
+  };
+
+  if (ksteps > 0) {
+    WqRaw ra, rb, rc;          // raw cells of steps ks+1, ks+2, ks+3
+    WqSz sa, sb;               // scale / zero of steps ks+1, ks+2
+    uint4 af[MT], af_next[MT];
+    {
+      WqRaw r0;
+      WqSz s0;
+      wq_load_raw<FMT>(p, cell_k(0), n_d, r0);
+      wq_load_raw<FMT>(p, cell_k(1), n_d, ra);
+      wq_load_raw<FMT>(p, cell_k(2), n_d, rb);
+      load_a(0, af);
+      load_sz(r0, s0);
+      load_sz(ra, sa);
+      dequant(0, 0, r0, s0);
+    }
     __syncthreads();
+    for (int ks = 0; ks < ksteps; ++ks) {
+      const int buf = ks & 1;
+      wq_load_raw<FMT>(p, cell_k(ks + 3), n_d, rc);
+      load_sz(rb, sb);
+      load_a(ks + 1, af_next);
+      if (ks + 1 < ksteps) dequant(buf ^ 1, ks + 1, ra, sa);
+      const uint4 wf = *reinterpret_cast<const uint4*>(&w_s[buf][wave * 16 + r][g * 8]);
+#pragma unroll
+      for (int t = 0; t < MT; ++t) acc[t] = Mfma16<T>::run(wf, af[t], acc[t]);
+      __syncthreads();
+      ra = rb; rb = rc; sa = sb;
+#pragma unroll
+      for (int t = 0; t < MT; ++t) af[t] = af_next[t];
+    }
   }
   // D[row = column index][col = m]: lane (m = r, g) holds columns n0 + 16 wave + 4 g + i
   const int nb = n0 + wave * 16 + 4 * g;
@@ -199,9 +352,17 @@ __global__ __launch_bounds__(256) void wq_gemm_kernel(const WqParams p) {
   for (int t = 0; t < MT; ++t) {
     const int m = m0 + t * 16 + r;
     if (m >= p.M) continue;
+    if (slab != nullptr) {
+      float* dst = slab + ((int64_t)blockIdx.y * p.M + m) * p.N + nb;
+      if (nb + 3 < p.N) *reinterpret_cast<f32x4_t*>(dst) = acc[t];
+      else
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-      if (nb + i < p.N) p.c[(int64_t)m * p.N + nb + i] = T::from_float(acc[t][i]);
+        for (int i = 0; i < 4; ++i) if (nb + i < p.N) dst[i] = acc[t][i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (nb + i < p.N) p.c[(int64_t)m * p.N + nb + i] = T::from_float(acc[t][i]);
+    }
   }
 }
 
@@ -501,39 +662,87 @@ __global__ void gptq_permute_rows_3bit_kernel(const uint32_t* __restrict__ src, 
   }
 }
 
+// plan of the generic kernel: ~512 workgroups, at least 4 k-steps per split
+struct WqGenericPlan { int mt, splits, k_per_wg; };
+static WqGenericPlan wq_generic_plan(int M, int N, int K) {
+  WqGenericPlan pl;
+  pl.mt = M <= 16 ? 1 : (M <= 32 ? 2 : 4);
+  const int base = ((N + 63) / 64) * ((M + 16 * pl.mt - 1) / (16 * pl.mt));
+  const int k_units = K / 32;
+  int splits = std::max(1, std::min(512 / std::max(base, 1), 16));
+  splits = std::min(splits, std::max(1, k_units / 4));
+  pl.k_per_wg = ((k_units + splits - 1) / splits) * 32;
+  pl.splits = (K + pl.k_per_wg - 1) / pl.k_per_wg;
+  return pl;
+}
+static int64_t wq_generic_scratch_bytes(int M, int N, int K) {
+  const WqGenericPlan pl = wq_generic_plan(M, N, K);
+  const int64_t a_bytes = ((int64_t)M * K * 2 + 255) & ~(int64_t)255;   // gathered activations (act-order)
+  return a_bytes + (pl.splits > 1 ? (int64_t)pl.splits * M * N * 4 : 0);
+}
+
+// scratch = [gathered activations (act-order only)] [split-K slabs]; without enough scratch for the slabs the
+// launch runs unsplit, without room for the gathered activations it fails (-2)
 template <typename T, int FMT>
-static void launch_wq(const WqParams& p, hipStream_t s) {
-  const int nblk = (p.N + 63) / 64;
-  if (p.M <= 16) {
-    hipLaunchKernelGGL((wq_gemm_kernel<T, FMT, 1>), dim3(nblk, (p.M + 15) / 16), dim3(256), 0, s, p);
-  } else if (p.M <= 32) {
-    hipLaunchKernelGGL((wq_gemm_kernel<T, FMT, 2>), dim3(nblk, (p.M + 31) / 32), dim3(256), 0, s, p);
-  } else {
-    hipLaunchKernelGGL((wq_gemm_kernel<T, FMT, 4>), dim3(nblk, (p.M + 63) / 64), dim3(256), 0, s, p);
+static int launch_wq(const WqParams& p_in, void* scratch, int64_t scratch_bytes, hipStream_t s) {
+  WqParams p = p_in;
+  WqGenericPlan pl = wq_generic_plan(p.M, p.N, p.K);
+  uint8_t* cur = reinterpret_cast<uint8_t*>(scratch);
+  int64_t left = scratch ? scratch_bytes : 0;
+  if (p.perm) {
+    const int64_t a_bytes = ((int64_t)p.M * p.K * 2 + 255) & ~(int64_t)255;
+    if (left < a_bytes) return -2;
+    uint16_t* a_perm = reinterpret_cast<uint16_t*>(cur);
+    const int64_t cells = (int64_t)p.M * (p.K / 8);
+    hipLaunchKernelGGL(permute_cols_kernel, dim3((unsigned)cdiv64(cells, 256)), dim3(256), 0, s, p.a, p.perm, a_perm,
+                       p.M, p.K);
+    p.a = a_perm;
+    p.perm = nullptr;
+    cur += a_bytes;
+    left -= a_bytes;
   }
+  const int64_t mn = (int64_t)p.M * p.N;
+  if (pl.splits > 1 && (left < (int64_t)pl.splits * mn * 4 || mn % 4 != 0)) {
+    pl.splits = 1;
+    pl.k_per_wg = p.K;
+  }
+  float* slab = pl.splits > 1 ? reinterpret_cast<float*>(cur) : nullptr;
+  const int nblk = (p.N + 63) / 64;
+  dim3 grid(nblk, pl.splits, (p.M + 16 * pl.mt - 1) / (16 * pl.mt));
+  if (pl.mt == 1) hipLaunchKernelGGL((wq_gemm_kernel<T, FMT, 1>), grid, dim3(256), 0, s, p, slab, pl.k_per_wg);
+  else if (pl.mt == 2) hipLaunchKernelGGL((wq_gemm_kernel<T, FMT, 2>), grid, dim3(256), 0, s, p, slab, pl.k_per_wg);
+  else hipLaunchKernelGGL((wq_gemm_kernel<T, FMT, 4>), grid, dim3(256), 0, s, p, slab, pl.k_per_wg);
+  if (pl.splits > 1)
+    hipLaunchKernelGGL((wq_reduce_kernel<T>), dim3((unsigned)cdiv64(mn / 4, 256)), dim3(256), 0, s, slab, p.c, mn,
+                       pl.splits);
+  return 0;
 }
 
 template <typename T>
-static int launch_wq_fmt(int fmt, const WqParams& p, hipStream_t s) {
+static int launch_wq_fmt(int fmt, const WqParams& p, void* scratch, int64_t scratch_bytes, hipStream_t s) {
   switch (fmt) {
-    case WQ_GPTQ: launch_wq<T, WQ_GPTQ>(p, s); return 0;
-    case WQ_AWQ: launch_wq<T, WQ_AWQ>(p, s); return 0;
-    case WQ_MARLIN: launch_wq<T, WQ_MARLIN>(p, s); return 0;
-    case WQ_MARLIN_FP8: launch_wq<T, WQ_MARLIN_FP8>(p, s); return 0;
+    case WQ_GPTQ: return launch_wq<T, WQ_GPTQ>(p, scratch, scratch_bytes, s);
+    case WQ_AWQ: return launch_wq<T, WQ_AWQ>(p, scratch, scratch_bytes, s);
+    case WQ_MARLIN: return launch_wq<T, WQ_MARLIN>(p, scratch, scratch_bytes, s);
+    case WQ_MARLIN_FP8: return launch_wq<T, WQ_MARLIN_FP8>(p, scratch, scratch_bytes, s);
   }
   return -1;
 }
 
 // used by w4a16_gemm.hip for the Marlin variants its tuned kernel does not cover
+int64_t wq_marlin_fallback_scratch_bytes(int size_m, int size_n, int size_k) {
+  return wq_generic_scratch_bytes(size_m, size_n, size_k);
+}
 int wq_marlin_fallback(void* c, const void* a, const int32_t* b_q_weight, const void* b_scales,
                        const int32_t* g_idx, const int32_t* perm, int num_bits, int size_m,
                        int size_n, int size_k, int num_groups, int is_fp8, nmv_dtype_t dtype,
-                       hipStream_t stream) {
+                       void* scratch, int64_t scratch_bytes, hipStream_t stream) {
   WqParams p{(const uint16_t*)a, (const uint32_t*)b_q_weight, nullptr, (const uint16_t*)b_scales,
              g_idx, perm, (uint16_t*)c, size_m, size_n, size_k, num_bits,
              num_groups > 1 ? size_k / num_groups : 0, num_groups};
   const int fmt = is_fp8 ? WQ_MARLIN_FP8 : WQ_MARLIN;
-  return dtype == NMV_F16 ? launch_wq_fmt<F16>(fmt, p, stream) : launch_wq_fmt<BF16>(fmt, p, stream);
+  return dtype == NMV_F16 ? launch_wq_fmt<F16>(fmt, p, scratch, scratch_bytes, stream)
+                          : launch_wq_fmt<BF16>(fmt, p, scratch, scratch_bytes, stream);
 }
 
 }  // namespace nmv
@@ -541,11 +750,16 @@ int wq_marlin_fallback(void* c, const void* a, const int32_t* b_q_weight, const 
 using namespace nmv;
 
 extern "C" int64_t nmv_wq_gemm_scratch_bytes(int size_m, int size_n, int size_k) {
-  if (size_m <= 0 || size_n <= 0 || size_k <= 0 || size_k % WS_K != 0 || size_n % 64 != 0) return 0;
-  const WqStreamPlan pl = wq_stream_plan(size_m, size_n, size_k);
-  // the gathered activations of an act-order call (the caller does not say whether it is one) + the slabs
-  const int64_t a_bytes = ((int64_t)size_m * size_k * 2 + 255) & ~(int64_t)255;
-  return a_bytes + (pl.splits > 1 ? (int64_t)pl.splits * size_m * size_n * 4 : 0);
+  if (size_m <= 0 || size_n <= 0 || size_k <= 0) return 0;
+  // the larger of what the two kernels want (the caller does not say which format / act-order it will pass):
+  // the gathered activations of an act-order call + the split-K slabs
+  int64_t need = wq_generic_scratch_bytes(size_m, size_n, size_k);
+  if (size_k % WS_K == 0 && size_n % 64 == 0) {
+    const WqStreamPlan pl = wq_stream_plan(size_m, size_n, size_k);
+    const int64_t a_bytes = ((int64_t)size_m * size_k * 2 + 255) & ~(int64_t)255;
+    need = std::max(need, a_bytes + (pl.splits > 1 ? (int64_t)pl.splits * size_m * size_n * 4 : 0));
+  }
+  return need;
 }
 
 extern "C" int nmv_gptq_gemm(void* c, const void* a, const int32_t* b_q_weight,
@@ -571,8 +785,9 @@ extern "C" int nmv_gptq_gemm(void* c, const void* a, const int32_t* b_q_weight,
              : launch_wq_stream<BF16, WQ_GPTQ>(p, (float*)scratch, scratch_bytes, (hipStream_t)stream);
     NMV_CHECK(rc != -2, "gptq_gemm: scratch too small (see nmv_wq_gemm_scratch_bytes)");
   } else {
-    rc = dtype == NMV_F16 ? launch_wq_fmt<F16>(WQ_GPTQ, p, (hipStream_t)stream)
-                          : launch_wq_fmt<BF16>(WQ_GPTQ, p, (hipStream_t)stream);
+    rc = dtype == NMV_F16 ? launch_wq_fmt<F16>(WQ_GPTQ, p, scratch, scratch_bytes, (hipStream_t)stream)
+                          : launch_wq_fmt<BF16>(WQ_GPTQ, p, scratch, scratch_bytes, (hipStream_t)stream);
+    NMV_CHECK(rc != -2, "gptq_gemm: scratch too small (see nmv_wq_gemm_scratch_bytes)");
   }
   NMV_CHECK(rc == 0, "gptq_gemm: launch failed");
   NMV_LAUNCH_CHECK();
@@ -618,8 +833,8 @@ extern "C" int nmv_awq_gemm(void* c, const void* a, const int32_t* qweight, cons
              : launch_wq_stream<BF16, WQ_AWQ>(p, (float*)scratch, scratch_bytes, (hipStream_t)stream);
     NMV_CHECK(rc != -2, "awq_gemm: scratch too small (see nmv_wq_gemm_scratch_bytes)");
   } else {
-    rc = dtype == NMV_F16 ? launch_wq_fmt<F16>(WQ_AWQ, p, (hipStream_t)stream)
-                          : launch_wq_fmt<BF16>(WQ_AWQ, p, (hipStream_t)stream);
+    rc = dtype == NMV_F16 ? launch_wq_fmt<F16>(WQ_AWQ, p, scratch, scratch_bytes, (hipStream_t)stream)
+                          : launch_wq_fmt<BF16>(WQ_AWQ, p, scratch, scratch_bytes, (hipStream_t)stream);
   }
   NMV_CHECK(rc == 0, "awq_gemm: launch failed");
   NMV_LAUNCH_CHECK();
@@ -644,17 +859,22 @@ extern "C" int nmv_awq_dequantize(void* out, const int32_t* qweight, const void*
   return NMV_OK;
 }
 
+extern "C" int64_t nmv_fp8_marlin_gemm_scratch_bytes(int size_m, int size_n, int size_k) {
+  if (size_m <= 0 || size_n <= 0 || size_k <= 0) return 0;
+  return wq_generic_scratch_bytes(size_m, size_n, size_k);
+}
+
 extern "C" int nmv_fp8_marlin_gemm(void* c, const void* a, const int32_t* b_q_weight,
                                    const void* b_scales, int32_t* workspace, int64_t workspace_len,
-                                   int num_bits, int size_m, int size_n, int size_k, int num_groups,
-                                   nmv_dtype_t dtype, void* stream) {
+                                   void* scratch, int64_t scratch_bytes, int num_bits, int size_m, int size_n,
+                                   int size_k, int num_groups, nmv_dtype_t dtype, void* stream) {
   (void)workspace; (void)workspace_len;
   NMV_CHECK(dtype == NMV_F16 || dtype == NMV_BF16, "fp8_marlin_gemm only supports bfloat16 and float16");
   NMV_CHECK(num_bits == 8, "num_bits must be 8 for fp8. Got = %d", num_bits);
   NMV_CHECK(size_n % 64 == 0 && size_k % 32 == 0, "fp8_marlin_gemm: N %% 64 and K %% 32 required");
   if (size_m == 0) return NMV_OK;
   const int rc = wq_marlin_fallback(c, a, b_q_weight, b_scales, nullptr, nullptr, 8, size_m, size_n,
-                                    size_k, num_groups, 1, dtype, (hipStream_t)stream);
+                                    size_k, num_groups, 1, dtype, scratch, scratch_bytes, (hipStream_t)stream);
   NMV_CHECK(rc == 0, "fp8_marlin_gemm: launch failed");
   NMV_LAUNCH_CHECK();
   return NMV_OK;

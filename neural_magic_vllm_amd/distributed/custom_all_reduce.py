@@ -66,6 +66,9 @@ class CustomAllReduce:
                     raise RuntimeError(f"device {device.index} cannot access peer device {g[3]}")
             with torch.cuda.device(device):
                 check(lib.nmv_ar_open(self.state, b"".join(g[1] for g in gathered)))
+            # bound of a flag wait (default 2 s): ranks that time-share one GPU (rehearsals) need a longer one
+            if os.environ.get("NMV_CUSTOM_AR_TIMEOUT_MS"):
+                check(lib.nmv_ar_set_timeout_ms(self.state, int(os.environ["NMV_CUSTOM_AR_TIMEOUT_MS"])))
         except Exception as e:
             ok, self.disabled_reason = False, f"open: {e}"
         if not self._all_agree(ok):

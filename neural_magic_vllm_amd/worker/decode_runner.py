@@ -166,6 +166,8 @@ class DecodeRunner:
         self.cache_config = cache_config or CacheConfig()
         self.tp_size = get_tensor_model_parallel_world_size()
         self.fused_step_tail = os.environ.get("NMV_FUSED_GLUE", "1") != "0"
+        self.keep_logits = False
+        self.last_logits: Optional[torch.Tensor] = None
         self.tp_rank = get_tensor_model_parallel_rank()
         if quant_config is not None:
             pass  # the checkpoint's own QuantizationConfig (from_pretrained)
@@ -270,6 +272,8 @@ class DecodeRunner:
         logits = torch.matmul(hidden_states, self.model.lm_head.weight.t())
         if self.tp_size > 1:
             logits = tensor_model_parallel_all_gather(logits)
+        if self.keep_logits:
+            self.last_logits = logits[:, :self.arch.vocab_size].float().clone()
         return torch.argmax(logits[:, :self.arch.vocab_size], dim=-1)
 
     def _step_body(self) -> torch.Tensor:
@@ -295,6 +299,8 @@ class DecodeRunner:
                                                 self.cache_config.block_size)
             if self.tp_size > 1:
                 logits = tensor_model_parallel_all_gather(logits)
+            if self.keep_logits:  # tests: the logits the token was drawn from (eager steps only)
+                self.last_logits = logits[:, :self.arch.vocab_size].float().clone()
             return ops.greedy_sample_advance(logits[:, :self.arch.vocab_size], self.input_ids, self.positions,
                                              self.seq_lens, self.slot_mapping, self.block_tables,
                                              self.cache_config.block_size)

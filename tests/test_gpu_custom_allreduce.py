@@ -43,6 +43,11 @@ def _worker(rank, world, port, q, run_model, algo=0):
         assert car is not None and car.enabled, getattr(car, "disabled_reason", "custom all-reduce not created")
         out = {}
         car.set_algo(algo)   # 0 = the reference's size rule, 2 = every call in the two-shot form
+        # the ranks of this test are processes TIME-SHARING one GPU: a kernel spinning on a peer's flag waits
+        # for the peer process to be scheduled, which has been seen to take longer than the 2 s production
+        # bound with four processes (one spurious timeout -> NaN output in ~10 runs); one process per GPU, the
+        # deployment, has no such wait
+        car.set_timeout_ms(30000)
         if run_model == "timeout":
             # rank 1 skips a call: rank 0's flag wait must run out (bound lowered to 0.3 s), its output must
             # be NaN -- not a sum of stale buffers -- and the error must surface on every rank
@@ -107,7 +112,7 @@ def _worker(rank, world, port, q, run_model, algo=0):
                         assert car.should_use(x)
                         y = tp.all_reduce(x)
                         assert torch.equal(y.cpu().view(torch.int16), _expected(world, numel, dtype, it).view(torch.int16)), \
-                            (numel, dtype, it)
+                            (numel, dtype, it, "timed out" if car.local_error() else "no timeout: wrong sum")
                         it += 1
             # messages the custom path does not take go to the group's backend
             odd = torch.ones(5, dtype=torch.bfloat16, device=dev)

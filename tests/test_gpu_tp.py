@@ -21,8 +21,9 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run(runner, try_capture=False):
-    """prefill + greedy decode; returns the token ids per step"""
+def _run(runner, try_capture=False, logits=None):
+    """prefill + greedy decode; returns the token ids per step (and appends each decode step's logits to `logits`)"""
+    runner.keep_logits = logits is not None
     runner.setup_batch(BATCH, PROMPT, STEPS + 4)
     first = runner.prefill(PROMPT, seed=7)
     toks = [first.cpu()]
@@ -38,6 +39,8 @@ def _run(runner, try_capture=False):
     for _ in range(STEPS):
         nxt = runner.decode_step()
         toks.append(nxt.cpu())
+        if logits is not None:
+            logits.append(runner.last_logits.cpu())
     return torch.stack(toks)
 
 
@@ -71,7 +74,8 @@ def test_tp_matches_single_process(gpu_device, world):
     """world = 4 > the tiny model's 2 KV heads: also covers KV-head replication (llama.py:109-117)"""
     from neural_magic_vllm_amd.worker import decode_runner as dr
     ref_runner = dr.DecodeRunner(dr.TINY, gpu_device, torch.bfloat16, QUANT, dr.CacheConfig(16, "auto"))
-    ref = _run(ref_runner).tolist()
+    ref_logits = []
+    ref = _run(ref_runner, logits=ref_logits).tolist()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -84,12 +88,20 @@ def test_tp_matches_single_process(gpu_device, world):
     errs = [m for s, m in res if s == "err"]
     assert not errs, errs
     got = [m for s, m in res if m is not None][0]
-    # greedy tokens: TP changes the fp32 summation order of the row-parallel GEMMs, so allow a rare
-    # near-tie flip but require the prefill token and at least all but one decode token to agree
-    flat_ref = [t for step in ref for t in step]
-    flat_got = [t for step in got for t in step]
-    assert flat_got[:BATCH] == flat_ref[:BATCH]
-    assert sum(a != b for a, b in zip(flat_got, flat_ref)) <= 1, (got, ref)
+    # greedy tokens: TP changes the fp32 summation order of the row-parallel GEMMs, so a sequence may leave the
+    # single-process one -- but only at a NEAR TIE of the single-process logits: where a sequence first differs,
+    # the token TP chose must be within 2 bf16 ulps of the top logit there (later tokens of that sequence follow
+    # a different context and are not compared).  The prefill token must agree.
+    assert got[0] == ref[0]
+    for b in range(BATCH):
+        for step in range(1, STEPS + 1):
+            if got[step][b] == ref[step][b]:
+                continue
+            row = ref_logits[step - 1][b]
+            top, alt = row[ref[step][b]].item(), row[got[step][b]].item()
+            assert top - alt <= 2 * 2.0**-8 * abs(top), \
+                f"seq {b} step {step}: TP token {got[step][b]} (logit {alt}) is no near tie of {ref[step][b]} ({top})"
+            break
 
 
 def _bench_cmd(root, extra):
@@ -115,7 +127,7 @@ def test_bench_py_multi_rank_rehearsal(gpu_device, custom_ar):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, NMV_BENCH_DIST_BACKEND="gloo", NMV_BENCH_SINGLE_DEVICE="1",
-               NMV_CUSTOM_ALLREDUCE=custom_ar)
+               NMV_CUSTOM_ALLREDUCE=custom_ar, NMV_CUSTOM_AR_TIMEOUT_MS="30000")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port())] + _bench_cmd(root, [])
     out = _one_json_line(subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600))
@@ -136,7 +148,8 @@ def test_bench_py_starts_its_own_ranks(gpu_device):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
-    env.update(NMV_BENCH_DIST_BACKEND="gloo", NMV_BENCH_SINGLE_DEVICE="1", NMV_CUSTOM_ALLREDUCE="force")
+    env.update(NMV_BENCH_DIST_BACKEND="gloo", NMV_BENCH_SINGLE_DEVICE="1", NMV_CUSTOM_ALLREDUCE="force",
+               NMV_CUSTOM_AR_TIMEOUT_MS="30000")
     out = _one_json_line(subprocess.run([sys.executable] + _bench_cmd(root, ["--no-sweep"]), env=env,
                                         capture_output=True, text=True, timeout=600))
     assert out["n_gpus"] == 2 and out["config"]["parallelism"] == "tp2"

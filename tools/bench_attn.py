@@ -13,7 +13,9 @@ from neural_magic_vllm_amd import _custom_ops as ops  # noqa: E402
 from neural_magic_vllm_amd.attention.ops.paged_attn import PagedAttention  # noqa: E402
 
 
-def bench(b, L, dev, kv, iters=20, nq=32, nkv=8, d=128, bs=16):
+def bench(b, L, dev, kv, iters=20, nq=32, nkv=8, d=128, bs=16, fused=0):
+    """fused = S > 0: the decode step's form -- the kernel starts from S fp32 split-K slabs of the qkv projection
+    (slab sums + rotary + cache store of the new token in its prologue; L counts the new token)"""
     blocks_per_seq = (L + bs - 1) // bs
     nb = max(b * blocks_per_seq * 2, (640 << 20) // (2 * nkv * d * bs * (1 if kv == "fp8" else 2)))
     cdt = torch.uint8 if kv == "fp8" else torch.bfloat16
@@ -32,9 +34,19 @@ def bench(b, L, dev, kv, iters=20, nq=32, nkv=8, d=128, bs=16):
     tables = [torch.randperm(nb, device=dev, generator=g)[:b * blocks_per_seq].to(torch.int32)
               .view(b, blocks_per_seq) for _ in range(iters)]
 
+    if fused:
+        slab = torch.randn((fused, b, (nq + 2 * nkv) * d), device=dev, dtype=torch.float32, generator=g) * 0.05
+        positions = torch.full((b, ), L - 1, dtype=torch.int64, device=dev)
+        t = torch.arange(8192, device=dev, dtype=torch.float32)[:, None] * \
+            (10000.0 ** (-torch.arange(0, d, 2, device=dev, dtype=torch.float32) / d))[None, :]
+        cos_sin = torch.cat([t.cos(), t.sin()], dim=-1).to(torch.bfloat16).contiguous()
+        slots = [(tb[:, (L - 1) // bs].to(torch.int64) * bs + (L - 1) % bs).contiguous() for tb in tables]
+
     def run(i):
-        PagedAttention.forward_decode(q, kc, vc, tables[i], seq_lens, L, "fp8" if kv == "fp8" else "auto",
-                                      nkv, d**-0.5, None, 1.0, out=out) if False else \
+        if fused:
+            ops.paged_attention_rope_partial(out, slab, positions, cos_sin, slots[i], kc, vc, nq, nkv, d, d**-0.5,
+                                             tables[i], seq_lens, bs, L, "fp8" if kv == "fp8" else "auto", 1.0)
+        else:
             ops.paged_attention_v1(out, q, kc, vc, nkv, d**-0.5, tables[i], seq_lens, bs, L, None,
                                    "fp8" if kv == "fp8" else "auto", 1.0)
 
@@ -65,12 +77,18 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", default="64:512,32:512,8:512,1:512,64:2048,8:8192")
     ap.add_argument("--kv", default="auto")
+    ap.add_argument("--fused", type=int, default=0, help="also time the fused rope + cache + attention form from "
+                    "this many fp32 qkv slabs")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     for c in args.cases.split(","):
         b, L = (int(v) for v in c.split(":"))
         us, gbs = bench(b, L, dev, args.kv)
-        print(f"attn v1 B={b:3d} L={L:5d} kv={args.kv}  {us:8.1f} us  {gbs:7.0f} GB/s", flush=True)
+        extra = ""
+        if args.fused:
+            fu, fg = bench(b, L, dev, args.kv, fused=args.fused)
+            extra = f"   fused prologue ({args.fused} slabs) {fu:8.1f} us {fg:7.0f} GB/s"
+        print(f"attn v1 B={b:3d} L={L:5d} kv={args.kv}  {us:8.1f} us  {gbs:7.0f} GB/s{extra}", flush=True)
 
 
 def bench_prefill(L, nseq, dev, iters=10, nq=32, nkv=8, d=128):

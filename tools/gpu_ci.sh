@@ -40,6 +40,14 @@ for step in "$@"; do
               find gpurun_out/tr_$c -name "*counter_collection.csv" | head -1 | xargs -I{} cp {} gpurun_out/traffic_$c.csv
               rm -rf gpurun_out/tr_$c
             done ;;
+    attnprof) cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
+            run attnprof rocprofv3 --kernel-trace --output-format csv -d gpurun_out/aprof -- python tools/bench_attn.py ${ATTN_ARGS:-}
+            find gpurun_out/aprof -name "*kernel_trace.csv" | head -1 | xargs -I{} cp {} gpurun_out/attn_trace.csv
+            rm -rf gpurun_out/aprof ;;
+    attntraffic) cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
+            run attntraffic rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/atr -- python tools/bench_attn.py ${ATTN_ARGS:-}
+            find gpurun_out/atr -name "*counter_collection.csv" | head -1 | xargs -I{} cp {} gpurun_out/attn_fetch.csv
+            rm -rf gpurun_out/atr ;;
     gemmsweep) run gemmsweep python tools/bench_gemm.py --sweep ;;
     prof)   cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
             run prof rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -- python bench.py --steps 16 --warmup 4 --no-sweep --no-cpu-baseline ${BENCH_ARGS:-}

@@ -1,19 +1,32 @@
-"""Summarise a rocprofv3 kernel-trace CSV: per (kernel, grid) device time, second half of the calls."""
-import collections
+"""Summarise a rocprofv3 kernel-trace CSV: device time per RUN of identical launches (same kernel, same grid,
+consecutive in time), second half of each run's calls.  Runs are printed in time order, so two benchmark cases
+that share kernel and grid (o_proj and down_proj at M = 64) stay on separate lines.
+usage: trace_summary.py <kernel_trace.csv> [name regex] [--labels a,b,c]   (labels: one per run, in order)"""
 import csv
 import re
 import sys
 
-rows = list(csv.DictReader(open(sys.argv[1])))
-pat = sys.argv[2] if len(sys.argv) > 2 else "nmv::"
-agg = collections.OrderedDict()
+args = [a for a in sys.argv[1:] if not a.startswith("--labels")]
+labels = []
+for a in sys.argv[1:]:
+    if a.startswith("--labels"):
+        labels = (a.split("=", 1)[1] if "=" in a else "").split(",")
+rows = list(csv.DictReader(open(args[0])))
+pat = args[1] if len(args) > 1 else "nmv::"
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+runs = []
 for r in rows:
     if not re.search(pat, r["Kernel_Name"]):
         continue
     name = re.sub(r"^void ", "", r["Kernel_Name"])
     name = re.sub(r"\(.*", "", name)[:70]
     key = (name, r["Grid_Size_X"], r["Grid_Size_Y"], r["Grid_Size_Z"])
-    agg.setdefault(key, []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
-for k, v in agg.items():
+    us = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+    if runs and runs[-1][0] == key:
+        runs[-1][1].append(us)
+    else:
+        runs.append((key, [us]))
+for i, (k, v) in enumerate(runs):
     v = v[len(v) // 2:]
-    print(f"{k[0]:70s} grid=({k[1]},{k[2]},{k[3]}) n={len(v):4d} avg={sum(v)/len(v):8.1f}us min={min(v):8.1f}")
+    lab = f"{labels[i]:22s} " if i < len(labels) else ""
+    print(f"{lab}{k[0]:70s} grid=({k[1]},{k[2]},{k[3]}) n={len(v):4d} avg={sum(v)/len(v):8.1f}us min={min(v):8.1f}")
