@@ -354,7 +354,10 @@ int nmv_prefill_attention_supported(int head_size);
  * Triton context_attention_fwd): the new tokens [query_start_loc[i], query_start_loc[i+1]) of sequence
  * i attend causally to ALL its keys [0, seq_lens[i]) read from the paged cache (the backend has
  * written the new tokens' K/V before the call); context_lens[i] = seq_lens[i] - new tokens.
- * kv cache dtype auto (fp16 / bf16) only; layouts as paged_attention. */
+ * kv cache dtype auto (fp16 / bf16) only, as in the reference (its forward_prefix takes no cache dtype);
+ * layouts as paged_attention.  alibi_slopes: float [H] or NULL -- bias slope * (key - query) on the scaled
+ * logits (prefix_prefill.py:552-557); sliding_window > 0: a query sees the keys fewer than that many
+ * positions back (:130-144, :201-204); both also on nmv_prefill_attention. */
 int nmv_prefix_prefill_attention(void* out, const void* q, const void* key_cache,
                                  const void* value_cache, const int32_t* block_tables,
                                  const int32_t* query_start_loc, const int32_t* seq_lens,
@@ -362,11 +365,13 @@ int nmv_prefix_prefill_attention(void* out, const void* q, const void* key_cache
                                  int max_blocks_per_seq, int block_size, int num_heads,
                                  int num_kv_heads, int head_size, float scale, int64_t q_stride,
                                  int64_t o_stride, int64_t kv_block_stride, int64_t kv_head_stride,
-                                 nmv_dtype_t dtype, void* stream);
+                                 const float* alibi_slopes, int sliding_window, nmv_dtype_t dtype,
+                                 void* stream);
 int nmv_prefill_attention(void* out, const void* q, const void* k, const void* v,
                           const int32_t* cu_seqlens, int num_seqs, int max_seq_len, int num_heads,
                           int num_kv_heads, int head_size, float scale, int64_t q_stride,
-                          int64_t kv_stride, int64_t o_stride, nmv_dtype_t dtype, void* stream);
+                          int64_t kv_stride, int64_t o_stride, const float* alibi_slopes,
+                          int sliding_window, nmv_dtype_t dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * W8A8: activation quantisers and the scaled matmul

@@ -309,9 +309,10 @@ def get_max_shared_memory_per_block_device_attribute(device: int) -> int:
 # prompt attention: not an op of the reference's _C library (it calls flash-attn / Triton / SDPA
 # from Python, rocm_flash_attn.py:349-430); exposed here for the attention backend
 def prefill_attention(out: torch.Tensor, query: torch.Tensor, key: torch.Tensor, value: torch.Tensor,
-                      cu_seqlens: torch.Tensor, max_seq_len: int, scale: float) -> None:
+                      cu_seqlens: torch.Tensor, max_seq_len: int, scale: float,
+                      alibi_slopes: Optional[torch.Tensor] = None, sliding_window: Optional[int] = None) -> None:
     from neural_magic_vllm_amd import _torch_bindings as tb
-    tb.prefill_attention(out, query, key, value, cu_seqlens, max_seq_len, scale)
+    tb.prefill_attention(out, query, key, value, cu_seqlens, max_seq_len, scale, alibi_slopes, sliding_window)
 
 
 def prefill_attention_supported(head_size: int) -> bool:
@@ -322,10 +323,12 @@ def prefill_attention_supported(head_size: int) -> bool:
 def prefix_prefill_attention(out: torch.Tensor, query: torch.Tensor, key_cache: torch.Tensor,
                              value_cache: torch.Tensor, block_tables: torch.Tensor,
                              query_start_loc: torch.Tensor, seq_lens: torch.Tensor,
-                             context_lens: torch.Tensor, max_query_len: int, scale: float) -> None:
+                             context_lens: torch.Tensor, max_query_len: int, scale: float,
+                             alibi_slopes: Optional[torch.Tensor] = None,
+                             sliding_window: Optional[int] = None) -> None:
     from neural_magic_vllm_amd import _torch_bindings as tb
     tb.prefix_prefill_attention(out, query, key_cache, value_cache, block_tables, query_start_loc,
-                                seq_lens, context_lens, max_query_len, scale)
+                                seq_lens, context_lens, max_query_len, scale, alibi_slopes, sliding_window)
 
 
 # AWQ / asymmetric checkpoints on the Marlin kernel (not ops of nm-vllm 0.5.1; later vLLM: awq_marlin)

@@ -112,8 +112,8 @@ SIGNATURES = {
     "nmv_awq_marlin_repack": (_I, [_P, _P, _I, _I, _P]),
     "nmv_prefill_attention_supported": (_I, [_I]),
     "nmv_prefix_prefill_attention": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F,
-                                          _L, _L, _L, _L, _I, _P]),
-    "nmv_prefill_attention": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _L, _L, _L, _I, _P]),
+                                          _L, _L, _L, _L, _P, _I, _I, _P]),
+    "nmv_prefill_attention": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _L, _L, _L, _P, _I, _I, _P]),
     "nmv_gptq_shuffle": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "nmv_awq_gemm": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _L, _P]),
     "nmv_awq_dequantize": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),

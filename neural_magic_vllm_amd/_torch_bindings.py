@@ -423,9 +423,19 @@ def awq_gemm(input, kernel, scaling_factors, zeros, split_k_iters) -> torch.Tens
     return c
 
 
-def prefill_attention(out, query, key, value, cu_seqlens, max_seq_len, scale) -> None:
+def _alibi_arg(alibi_slopes, num_heads, like):
+    if alibi_slopes is None:
+        return None
+    _req(alibi_slopes.dtype == torch.float32 and alibi_slopes.numel() == num_heads and alibi_slopes.is_contiguous()
+         and alibi_slopes.device == like.device, "alibi_slopes must be float32 [num_heads] on the query's device")
+    return ptr(alibi_slopes)
+
+
+def prefill_attention(out, query, key, value, cu_seqlens, max_seq_len, scale, alibi_slopes=None,
+                      sliding_window=None) -> None:
     """varlen causal GQA prompt attention (csrc/prefill_attention.hip); q [T, H, D], k/v [T, KVH, D]
-    (last dim contiguous, may be slices of qkv), cu_seqlens int32 [num_seqs + 1]"""
+    (last dim contiguous, may be slices of qkv), cu_seqlens int32 [num_seqs + 1]; optional ALiBi slopes
+    (float32 [H]) and sliding window (keys fewer than that many positions back)"""
     _req(query.dim() == 3 and key.dim() == 3 and value.dim() == 3 and out.dim() == 3, "prefill_attention: [T, H, D] tensors")
     _req(query.stride(2) == 1 and key.stride(2) == 1 and value.stride(2) == 1 and out.stride(2) == 1,
          "prefill_attention: head dim must be contiguous")
@@ -439,11 +449,14 @@ def prefill_attention(out, query, key, value, cu_seqlens, max_seq_len, scale) ->
         check(_lib.load().nmv_prefill_attention(ptr(out), ptr(query), ptr(key), ptr(value), ptr(cu_seqlens),
                                                 cu_seqlens.numel() - 1, int(max_seq_len), h, kvh, d,
                                                 float(scale), query.stride(0), key.stride(0),
-                                                out.stride(0), dtype_code(query.dtype), stream_of(query)))
+                                                out.stride(0), _alibi_arg(alibi_slopes, h, query),
+                                                int(sliding_window or 0), dtype_code(query.dtype),
+                                                stream_of(query)))
 
 
 def prefix_prefill_attention(out, query, key_cache, value_cache, block_tables, query_start_loc,
-                             seq_lens, context_lens, max_query_len, scale) -> None:
+                             seq_lens, context_lens, max_query_len, scale, alibi_slopes=None,
+                             sliding_window=None) -> None:
     """PagedAttention.forward_prefix on the paged cache (csrc/prefill_attention.hip); query/out
     [new tokens, H, D]; key_cache [NB, KVH, D/x, BS, x], value_cache [NB, KVH, D, BS] (16-bit)"""
     _req(query.dim() == 3 and out.dim() == 3 and query.stride(2) == 1 and out.stride(2) == 1,
@@ -451,7 +464,8 @@ def prefix_prefill_attention(out, query, key_cache, value_cache, block_tables, q
     t, h, d = query.shape
     _req(query.stride(1) == d and out.stride(1) == d, "prefix_prefill_attention: heads must be packed")
     _req(key_cache.dtype == query.dtype and value_cache.dtype == query.dtype,
-         "prefix_prefill_attention: kv cache dtype must be auto (the model dtype)")
+         "prefix_prefill_attention: kv cache dtype must be auto (the model dtype), as for the reference's "
+         "forward_prefix (vllm/attention/ops/paged_attn.py:184-216 passes no cache dtype)")
     nb, kvh, _, bs = value_cache.shape
     for x in (block_tables, query_start_loc, seq_lens, context_lens):
         _req(x.dtype == torch.int32 and x.is_contiguous(), "prefix_prefill_attention: int32 index tensors")
@@ -460,8 +474,8 @@ def prefix_prefill_attention(out, query, key_cache, value_cache, block_tables, q
             ptr(out), ptr(query), ptr(key_cache), ptr(value_cache), ptr(block_tables),
             ptr(query_start_loc), ptr(seq_lens), ptr(context_lens), seq_lens.numel(),
             int(max_query_len), block_tables.shape[1], bs, h, kvh, d, float(scale), query.stride(0),
-            out.stride(0), value_cache.stride(0), value_cache.stride(1), dtype_code(query.dtype),
-            stream_of(query)))
+            out.stride(0), value_cache.stride(0), value_cache.stride(1), _alibi_arg(alibi_slopes, h, query),
+            int(sliding_window or 0), dtype_code(query.dtype), stream_of(query)))
 
 
 def prefill_attention_supported(head_size: int) -> bool:

@@ -107,8 +107,10 @@ class ROCmHipAttentionImpl(AttentionImpl):
                  sliding_window: Optional[int] = None, kv_cache_dtype: str = "auto",
                  blocksparse_params: Optional[Dict[str, Any]] = None) -> None:
         assert blocksparse_params is None, "the gfx950 backend does not support block-sparse attention"
-        if sliding_window is not None:
-            raise NotImplementedError("sliding-window attention is outside the hot-path scope")
+        # prompt attention masks the window in the kernel (rocm_flash_attn.py:244-246,394-406 hands it to
+        # flash-attention / forward_prefix); decode sees it through the block tables and sequence lengths the
+        # model runner builds, as in the reference (paged_attention takes no window)
+        self.sliding_window = sliding_window
         self.num_heads = num_heads
         self.head_size = head_size
         self.scale = float(scale)
@@ -239,9 +241,8 @@ class ROCmHipAttentionImpl(AttentionImpl):
                 output[:num_prefill_tokens] = PagedAttention.forward_prefix(
                     query[:num_prefill_tokens], key[:num_prefill_tokens], value[:num_prefill_tokens],
                     key_cache, value_cache, pm.block_tables, pm.query_start_loc, pm.seq_lens_tensor,
-                    pm.context_lens_tensor, pm.max_query_len, self.alibi_slopes, None, self.scale)
-            elif self.alibi_slopes is None and ops.prefill_attention_supported(self.head_size) \
-                    and query.dtype in (torch.float16, torch.bfloat16):
+                    pm.context_lens_tensor, pm.max_query_len, self.alibi_slopes, self.sliding_window, self.scale)
+            elif ops.prefill_attention_supported(self.head_size) and query.dtype in (torch.float16, torch.bfloat16):
                 # the hand-written HIP flash-attention forward (csrc/prefill_attention.hip)
                 cu = pm.seq_start_loc
                 if cu is None or cu.dtype != torch.int32:
@@ -249,9 +250,12 @@ class ROCmHipAttentionImpl(AttentionImpl):
                                       dtype=torch.int32, device=query.device)
                 ops.prefill_attention(output[:num_prefill_tokens], query[:num_prefill_tokens],
                                       key[:num_prefill_tokens], value[:num_prefill_tokens], cu,
-                                      pm.max_prefill_seq_len or max(pm.seq_lens), self.scale)
+                                      pm.max_prefill_seq_len or max(pm.seq_lens), self.scale, self.alibi_slopes,
+                                      self.sliding_window)
             else:
-                # ALiBi prompts and head sizes other than 64 / 128: the reference's "naive" SDPA option
+                if self.sliding_window is not None:
+                    raise NotImplementedError("sliding-window prompts need head size 64 or 128")
+                # head sizes other than 64 / 128: the reference's "naive" SDPA option
                 output[:num_prefill_tokens] = _sdpa_prefill(query[:num_prefill_tokens],
                                                             key[:num_prefill_tokens],
                                                             value[:num_prefill_tokens], pm.seq_lens,

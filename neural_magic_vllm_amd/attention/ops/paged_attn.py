@@ -121,14 +121,13 @@ class PagedAttention:
         """prefix-enabled prefill (paged_attn.py:184-216).  `key` / `value` (the new tokens) are
         accepted for signature parity; the backend has already written them into the cache, which
         is where the kernel reads every key from (kv cache dtype auto)."""
-        if alibi_slopes is not None or sliding_window is not None:
-            raise NotImplementedError("prefix prefill: ALiBi / sliding window are not built on gfx950")
         output = torch.empty_like(query)
         head_size = query.shape[-1]
         ops.prefix_prefill_attention(output, query, key_cache, value_cache, block_tables,
                                      query_start_loc.to(torch.int32), seq_lens_tensor.to(torch.int32),
                                      context_lens.to(torch.int32), max_query_len,
-                                     scale if scale is not None else head_size**-0.5)
+                                     scale if scale is not None else head_size**-0.5,
+                                     alibi_slopes, sliding_window)
         return output
 
     @staticmethod

@@ -51,7 +51,19 @@ struct FaParams {
   int64_t q_stride, kv_stride, o_stride;
   int num_heads, num_kv_heads;
   float scale;
+  const float* alibi_slopes;  // [H] or null: bias slope * (key - query) on the scaled logits
+  int window;                 // sliding window (0 = none): a query sees the keys less than `window` positions back
 };
+
+// logit of (query position qp, key position key) after the softmax scale: ALiBi bias, causal / length mask
+// (-inf) and the sliding window, which the reference masks with -10000 rather than -inf because a whole tile of
+// a row may lie outside the window (prefix_prefill.py:130-144, :201-204; alibi :552-557)
+__device__ __forceinline__ float fa_mask(float x, int key, int qp, int L, float slope, int window) {
+  x += slope * (float)(key - qp);
+  if (window > 0 && qp - key >= window) x = -10000.f;
+  if (key > qp || key >= L) x = -INFINITY;
+  return x;
+}
 
 // QU = 16-query sub-tiles per wave: 1 (64 queries per workgroup; short prompts, more workgroups) or
 // 2 (128 queries: every K / V operand read from LDS feeds two MFMAs).
@@ -106,7 +118,11 @@ __global__ __launch_bounds__(256) void prefill_attention_kernel(const FaParams p
   const uint16_t* vbase = p.v + (int64_t)tok0 * p.kv_stride + (int64_t)kv_head * D;
   const int last_q = min(qt0 + QT, L) - 1;         // causal: keys 0 .. last_q
   const int n_kt = last_q / FA_KT + 1;
+  // sliding window: the tiles wholly before the window of the workgroup's first query are skipped
+  const int kt_lo = p.window > 0 ? max(qt0 - p.window + 1, 0) / FA_KT : 0;
   const float sc = p.scale;
+  const float slope = p.alibi_slopes ? p.alibi_slopes[head] : 0.f;
+  const bool every_tile = p.window > 0 || slope != 0.f;   // uniform: masks / bias touch every tile
 
   // tile loader: thread t owns pieces t, t+256, ... of the K and of the V tile (row = piece / (D/8))
   uint4 kreg[PPT], vreg[PPT];
@@ -130,11 +146,11 @@ __global__ __launch_bounds__(256) void prefill_attention_kernel(const FaParams p
       *reinterpret_cast<uint4*>(&kv_s[(buf * 2 + 1) * TILE + row * VS + c8 * 8]) = vreg[i];
     }
   };
-  fetch(0);
-  park(0);
+  fetch(kt_lo);
+  park(kt_lo & 1);
   __syncthreads();
 
-  for (int kt = 0; kt < n_kt; ++kt) {
+  for (int kt = kt_lo; kt < n_kt; ++kt) {
     const int k0 = kt * FA_KT;
     const int buf = kt & 1;
     const uint16_t* k_s = &kv_s[(buf * 2 + 0) * TILE];
@@ -155,7 +171,7 @@ __global__ __launch_bounds__(256) void prefill_attention_kernel(const FaParams p
       }
     }
     // ---- scale, causal / length mask, online softmax (row = this lane's query) ----
-    const bool diag = k0 + FA_KT - 1 > qt0;   // uniform: only tiles that reach past the first query
+    const bool diag = every_tile || k0 + FA_KT - 1 > qt0;   // uniform: else only tiles that reach past the first query
     uint32_t pp[QU][8];                              // packed P: [t][pair]
 #pragma unroll
     for (int u = 0; u < QU; ++u) {
@@ -166,13 +182,13 @@ __global__ __launch_bounds__(256) void prefill_attention_kernel(const FaParams p
         for (int i = 0; i < 4; ++i) {
           const int key = k0 + t * 16 + 4 * g + i;
           float x = s[u][t][i] * sc;
-          if (diag && (key > q_row[u] || key >= L)) x = -INFINITY;
+          if (diag) x = fa_mask(x, key, q_row[u], L, slope, p.window);
           s[u][t][i] = x;
           mx = fmaxf(mx, x);
         }
       mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float m_new = fmaxf(m_run[u], mx);        // finite: key 0 is visible to every query
+      const float m_new = fmaxf(m_run[u], mx);        // finite: the first tile holds a key at or before every query
       const float alpha = __expf(m_run[u] - m_new);
       float psum = 0.f;
 #pragma unroll
@@ -254,6 +270,8 @@ struct PfxParams {
   int64_t q_stride, o_stride, kv_block_stride, kv_head_stride;  // elements
   int max_blocks, block_size, num_heads, num_kv_heads;
   float scale;
+  const float* alibi_slopes;  // [H] or null
+  int window;                 // sliding window, 0 = none
 };
 
 template <typename T, int D>
@@ -288,9 +306,12 @@ __global__ __launch_bounds__(256) void prefix_attention_kernel(const PfxParams p
   float m_run = -INFINITY, l_run = 0.f;
   const int last_pos = ctx + min(qt0 + FA_QT, q_len) - 1;   // causal: keys 0 .. last_pos (< L)
   const int n_kt = last_pos / FA_KT + 1;
+  const int kt_lo = p.window > 0 ? max(ctx + qt0 - p.window + 1, 0) / FA_KT : 0;
   const float sc = p.scale;
+  const float slope = p.alibi_slopes ? p.alibi_slopes[head] : 0.f;
+  const bool every_tile = p.window > 0 || slope != 0.f;   // uniform
 
-  for (int kt = 0; kt < n_kt; ++kt) {
+  for (int kt = kt_lo; kt < n_kt; ++kt) {
     const int k0 = kt * FA_KT;
     // ---- S^T = K . Q^T, keys gathered through the block table ----
     f32x4_t s[4];
@@ -302,7 +323,7 @@ __global__ __launch_bounds__(256) void prefix_attention_kernel(const PfxParams p
 #pragma unroll
       for (int c = 0; c < DC; ++c) s[t] = FaMfma<T>::run(ld16(kp + (int64_t)(c * 4 + g) * bs * 8), qf[c], s[t]);
     }
-    const bool diag = k0 + FA_KT - 1 > ctx + qt0;   // uniform
+    const bool diag = every_tile || k0 + FA_KT - 1 > ctx + qt0;   // uniform
     float mx = -INFINITY;
 #pragma unroll
     for (int t = 0; t < 4; ++t)
@@ -310,7 +331,7 @@ __global__ __launch_bounds__(256) void prefix_attention_kernel(const PfxParams p
       for (int i = 0; i < 4; ++i) {
         const int key = k0 + t * 16 + 4 * g + i;
         float x = s[t][i] * sc;
-        if (diag && (key > q_pos || key >= L)) x = -INFINITY;
+        if (diag) x = fa_mask(x, key, q_pos, L, slope, p.window);
         s[t][i] = x;
         mx = fmaxf(mx, x);
       }
@@ -381,6 +402,7 @@ extern "C" int nmv_prefill_attention(void* out, const void* q, const void* k, co
                                      const int32_t* cu_seqlens, int num_seqs, int max_seq_len,
                                      int num_heads, int num_kv_heads, int head_size, float scale,
                                      int64_t q_stride, int64_t kv_stride, int64_t o_stride,
+                                     const float* alibi_slopes, int sliding_window,
                                      nmv_dtype_t dtype, void* stream) {
   NMV_CHECK(dtype == NMV_F16 || dtype == NMV_BF16, "prefill_attention: fp16 / bf16 only");
   NMV_CHECK(head_size == 64 || head_size == 128, "prefill_attention: head size %d not built (64, 128)", head_size);
@@ -389,7 +411,8 @@ extern "C" int nmv_prefill_attention(void* out, const void* q, const void* k, co
             "prefill_attention: token strides must keep 16-byte (q, k, v) / 8-byte (out) alignment");
   if (num_seqs <= 0 || max_seq_len <= 0) return NMV_OK;
   FaParams p{(const uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v, (uint16_t*)out, cu_seqlens,
-             q_stride, kv_stride, o_stride, num_heads, num_kv_heads, scale};
+             q_stride, kv_stride, o_stride, num_heads, num_kv_heads, scale, alibi_slopes,
+             sliding_window > 0 ? sliding_window : 0};
   hipStream_t s = (hipStream_t)stream;
   // QU = 2 (128-query workgroups, each K / V operand feeding two MFMAs) was measured slower at every
   // size (L = 8192: 2.09 ms vs 1.44 ms: twice the registers, more masked work on the diagonal)
@@ -413,7 +436,8 @@ extern "C" int nmv_prefix_prefill_attention(void* out, const void* q, const void
                                             int max_query_len, int max_blocks_per_seq, int block_size,
                                             int num_heads, int num_kv_heads, int head_size, float scale,
                                             int64_t q_stride, int64_t o_stride, int64_t kv_block_stride,
-                                            int64_t kv_head_stride, nmv_dtype_t dtype, void* stream) {
+                                            int64_t kv_head_stride, const float* alibi_slopes,
+                                            int sliding_window, nmv_dtype_t dtype, void* stream) {
   NMV_CHECK(dtype == NMV_F16 || dtype == NMV_BF16, "prefix_prefill_attention: fp16 / bf16 only (kv cache dtype auto)");
   NMV_CHECK(head_size == 64 || head_size == 128, "prefix_prefill_attention: head size %d not built (64, 128)", head_size);
   NMV_CHECK(block_size == 8 || block_size == 16 || block_size == 32, "prefix_prefill_attention: block size %d", block_size);
@@ -422,7 +446,8 @@ extern "C" int nmv_prefix_prefill_attention(void* out, const void* q, const void
   if (num_seqs <= 0 || max_query_len <= 0) return NMV_OK;
   PfxParams p{(const uint16_t*)q, (uint16_t*)out, (const uint16_t*)key_cache, (const uint16_t*)value_cache,
               block_tables, query_start_loc, seq_lens, context_lens, q_stride, o_stride, kv_block_stride,
-              kv_head_stride, max_blocks_per_seq, block_size, num_heads, num_kv_heads, scale};
+              kv_head_stride, max_blocks_per_seq, block_size, num_heads, num_kv_heads, scale, alibi_slopes,
+              sliding_window > 0 ? sliding_window : 0};
   dim3 grid((max_query_len + FA_QT - 1) / FA_QT, num_heads, num_seqs), block(256);
   hipStream_t s = (hipStream_t)stream;
   if (dtype == NMV_BF16) {
