@@ -244,7 +244,7 @@ def cpu_baseline(arch, batch, context, budget_s=12.0):
         F.linear(a, w_nk)
     t_gemm = t_attn = 0.0
     layers = 0
-    while layers == 0 or (t_gemm + t_attn < budget_s and layers < 256):
+    while layers == 0 or (t_gemm + t_attn < budget_s and layers < 2048):
         t0 = time.perf_counter()
         for a, w_nk in dense:
             F.linear(a, w_nk)
@@ -343,6 +343,7 @@ def main():
         if world > 1:
             nd.get_tp_group().barrier()
         torch.cuda.synchronize(dev)
+        ctx0 = int(runner.seq_lens[0])       # tokens the first timed step attends to (the new one included)
         t0 = time.perf_counter()
         for _ in range(steps):
             runner.decode_step()
@@ -350,11 +351,14 @@ def main():
         if world > 1:
             nd.get_tp_group().barrier()
         dt = max_over_ranks(time.perf_counter() - t0)
+        timed_ctx[:] = [ctx0, int(runner.seq_lens[0]) - 1]
         # a P2P all-reduce that gave up waiting for a peer wrote NaN: no number from such a run
         runner.check_collectives()
         return dt, graphed
 
+    timed_ctx = [args.context, args.context]   # context of the first / last step of the last measure() call
     dt, graphed = measure(args.batch, args.steps, args.warmup)
+    ctx_first, ctx_last = timed_ctx
     ms_per_step = dt / args.steps * 1e3
     value = args.batch * args.steps / dt
 
@@ -372,6 +376,8 @@ def main():
         "config": {"workload": f"{args.model} {args.quant} decode step, batch {args.batch}, "
                                f"context {args.context} tokens/seq, block 16, kv {args.kv_cache_dtype}",
                    "global_batch": args.batch, "context_len": args.context,
+                   # every step appends a token: the KV the timed steps walk grows from / to
+                   "context_len_timed_steps": [ctx_first, ctx_last],
                    "parallelism": f"tp{world}", "hip_graph": graphed},
     }
     if dt < 0.5 and not args.no_sweep:
@@ -406,8 +412,10 @@ def main():
     if rank == 0:
         wb = runner.weight_bytes_per_step()
         kv_elem = 1 if args.kv_cache_dtype.startswith("fp8") else 2
-        kvb = 2 * args.context * runner.num_kv_heads * arch.head_dim * kv_elem * args.batch * arch.num_hidden_layers
-        out["step_roofline"] = {"weight_bytes": wb, "kv_bytes": kvb,
+        # KV bytes of a step at the MEAN context of the timed steps (the cache grows by a token per step)
+        mean_ctx = (ctx_first + ctx_last) / 2
+        kvb = int(2 * mean_ctx * runner.num_kv_heads * arch.head_dim * kv_elem * args.batch * arch.num_hidden_layers)
+        out["step_roofline"] = {"weight_bytes": wb, "kv_bytes": kvb, "mean_context": mean_ctx,
                                 "hbm_bound_ms": round((wb + kvb) / (HBM_PEAK_GBS * 1e9) * 1e3, 4),
                                 "frac_of_hbm_bound": round((wb + kvb) / (HBM_PEAK_GBS * 1e9) / (ms_per_step * 1e-3), 4)}
         if args.quant == "w4a16":

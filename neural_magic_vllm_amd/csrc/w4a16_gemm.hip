@@ -70,12 +70,16 @@ __device__ __forceinline__ uint32_t and_or(uint32_t x, uint32_t mask_sgpr, uint3
 // non-temporal policy so that they do not displace the activation tile and the scales in the XCD's L2
 // (measured: -2..4 % at M <= 16); with two row blocks the second one finds them in L2 and nt costs 10 %.
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ uint4 ld_stream(const uint4* ptr, bool nt) {
-  if (nt) {
+// NT is a template parameter of the kernels: a run-time choice is a uniform branch around the load, which
+// makes hipcc fall back to `vmcnt(0)` waits and costs the whole software pipeline (measured: +10 %).
+template <bool NT>
+__device__ __forceinline__ uint4 ld_stream(const uint4* ptr) {
+  if constexpr (NT) {
     const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(ptr));
     return make_uint4(v.x, v.y, v.z, v.w);
+  } else {
+    return *ptr;
   }
-  return *ptr;
 }
 
 template <typename T> struct W4;
@@ -717,7 +721,7 @@ __device__ __forceinline__ void w4_tall_epilogue(const GemmParams& p, f32x4_t (&
 // ZP: per-(group, column) zero points (asymmetric AWQ / GPTQ checkpoints repacked to the Marlin
 // layout): p.zp holds z in the model dtype in the layout of the scales; they travel through LDS
 // with the scales (threads 32..63 stage them) and replace the constant 8 in the correction term.
-template <typename T, int MT, int WN, int WK, int GS, bool PS = false, int BITS = 4, bool ZP = false>
+template <typename T, int MT, int WN, int WK, int GS, bool PS = false, int BITS = 4, bool ZP = false, bool NT = false>
 __global__ __launch_bounds__(GT, 2) void w4a16_gemm_tall_kernel(const GemmParams p) {
   static_assert(!ZP || (BITS == 4 && GS == 128), "zero points: 4-bit, group 128");
   static_assert(WN * WK == 4, "4 waves per workgroup");
@@ -764,13 +768,12 @@ __global__ __launch_bounds__(GT, 2) void w4a16_gemm_tall_kernel(const GemmParams
   const int64_t row_u4 = (int64_t)(p.N >> 1) * WV;
   const uint4* bp = p.b + ((int64_t)(chunk_ok ? chunk : 0) * 32 + (n_in * 4 + g)) * WV +
                     ((int64_t)(k_w0 >> 4) + blk) * row_u4;
-  const bool w_nt = gridDim.z == 1;
   auto load_w = [&](int st, uint4 (&w)[KSS * WV]) {
     const uint4* q = bp + (int64_t)min(st, st_last) * (2 * KSS * row_u4);
 #pragma unroll
     for (int ks = 0; ks < KSS; ++ks)
 #pragma unroll
-      for (int h = 0; h < WV; ++h) w[ks * WV + h] = ld_stream(q + ks * 2 * row_u4 + h, w_nt);
+      for (int h = 0; h < WV; ++h) w[ks * WV + h] = ld_stream<NT>(q + ks * 2 * row_u4 + h);
   };
   const uint32_t kmask = __builtin_amdgcn_readfirstlane(W4<T>::MASK);
   uint32_t kmagic = W4<T>::MAGIC;
@@ -1039,7 +1042,7 @@ template <> struct W4N<F16> {    // nibble in mantissa bits [9:6]: 16 + q
   static constexpr float ZPC = 24.0f;
 };
 
-template <typename T, int MT, int WN, int WK, int GS>
+template <typename T, int MT, int WN, int WK, int GS, bool NT = false>
 __global__ __launch_bounds__(GT, 2) void w4n_gemm_kernel(const GemmParams p) {
   static_assert(WN * WK == 4, "4 waves per workgroup");
   static_assert(MT == 1 || MT == 2 || MT == 4, "16, 32 or 64 rows");
@@ -1079,11 +1082,10 @@ __global__ __launch_bounds__(GT, 2) void w4n_gemm_kernel(const GemmParams p) {
   // ---- weights: one 16-byte load per lane and k-step, a wave reads 1 KiB contiguous ----
   const int64_t kstep_u4 = (int64_t)n_chunks * 64;     // one k-step of every chunk: N * 16 bytes, contiguous
   const uint4* bp = p.b + ((int64_t)(k_w0 >> 5) * n_chunks + (chunk_ok ? chunk : 0)) * 64 + lane;
-  const bool w_nt = gridDim.z == 1;
   auto load_w = [&](int st, uint4 (&w)[KSS]) {
     const uint4* q = bp + (int64_t)min(st, st_last) * (KSS * kstep_u4);
 #pragma unroll
-    for (int ks = 0; ks < KSS; ++ks) w[ks] = ld_stream(q + ks * kstep_u4, w_nt);
+    for (int ks = 0; ks < KSS; ++ks) w[ks] = ld_stream<NT>(q + ks * kstep_u4);
   };
   const uint32_t kmask = __builtin_amdgcn_readfirstlane(N4::MASK);
   uint32_t kmagic = N4::MAGIC;
@@ -1463,9 +1465,13 @@ static int launch_gemm_gs(const GemmPlan& pl, const GemmParams& p, hipStream_t s
       return -1;
     }
     if (pl.tall) {
+      // weights read once by the launch (a single block of rows) stream non-temporally; the 64-row tile is
+      // only planned for M > 64, i.e. several row blocks
+      const bool nt = pl.m_blocks == 1 && pl.mt <= 2 && env_int("NMV_W4_NT", 1);
 #define NMV_W4_TALL_CASE(mt_, wn_, wk_)                                                        \
   if (pl.mt == mt_ && pl.wn == wn_ && pl.wk == wk_) {                                          \
-    hipLaunchKernelGGL((w4a16_gemm_tall_kernel<T, mt_, wn_, wk_, GS>), grid, block, 0, s, p);  \
+    if (nt) hipLaunchKernelGGL((w4a16_gemm_tall_kernel<T, mt_, wn_, wk_, GS, false, 4, false, true>), grid, block, 0, s, p); \
+    else hipLaunchKernelGGL((w4a16_gemm_tall_kernel<T, mt_, wn_, wk_, GS>), grid, block, 0, s, p);  \
     return 0;                                                                                  \
   }
       NMV_W4_TALL_CASE(1, 4, 1) NMV_W4_TALL_CASE(1, 2, 2) NMV_W4_TALL_CASE(1, 1, 4)
