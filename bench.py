@@ -332,7 +332,11 @@ def main():
         return max(vals)
 
     def measure(batch, steps, warmup):
-        runner.setup_batch(batch, args.context, steps + warmup + 8)
+        # every step appends a token and attention is linear in the context, so the timed steps are CENTRED on
+        # the nominal context: they start far enough below it that the mean context they attend to is
+        # args.context (a 256-step region that started at 512 would measure a mean context of 648)
+        start_ctx = max(16, args.context - warmup - steps // 2)
+        runner.setup_batch(batch, start_ctx, steps + warmup + 8)
         runner.fill_context()
         # capture() decides graph-or-eager for the whole group (a step that holds collectives of a
         # non-capturable backend is never offered to the graph) and checks the P2P error word
@@ -374,7 +378,8 @@ def main():
                  "w8a8": "synthetic (random-init N(0,0.02) weights quantised to int8 per channel, random KV context)",
                  "bf16": "synthetic (random-init N(0,0.02) bf16 weights, random KV context)"}[args.quant],
         "config": {"workload": f"{args.model} {args.quant} decode step, batch {args.batch}, "
-                               f"context {args.context} tokens/seq, block 16, kv {args.kv_cache_dtype}",
+                               f"context {args.context} tokens/seq (mean over the timed steps), block 16, "
+                               f"kv {args.kv_cache_dtype}",
                    "global_batch": args.batch, "context_len": args.context,
                    # every step appends a token: the KV the timed steps walk grows from / to
                    "context_len_timed_steps": [ctx_first, ctx_last],
