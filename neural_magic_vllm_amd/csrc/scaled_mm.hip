@@ -239,10 +239,20 @@ static MMPlan mm_plan(int M, int N, int K, int64_t scratch_bytes) {
   MMPlan pl{1, 1, 4, 1, K};
   const int n16 = (N + 15) / 16;
   int splits = 1;
-  if (M <= 16) {
-    // one column tile per wave: pure weight streaming (4.9 TB/s on gate_up)
-  } else if (M <= 32) {
-    pl.mt = 2, pl.nt = n16 >= 1024 ? 2 : 1;
+  if (M <= 32) {
+    // M = 1: one column tile per wave is pure weight streaming (4.8 TB/s on gate_up).  With more rows every
+    // workgroup re-reads the whole activation block from L2 -- at 16 columns per workgroup that is as many
+    // bytes as the weights -- so wider column tiles (the fragment is reused NT times) win as soon as they
+    // leave enough workgroups
+    pl.mt = M <= 16 ? 1 : 2;
+    // measured (int8, us, NT = 1 / 2 / 4): gate_up M=8 30.3 / 31.5 / 32.0, M=16 36.0 / 35.0 / 33.7, M=32 48.3 / 42.7 /
+    // 36.3; qkv M=32 16.0 / 14.3 / 19.2; o and down (256 column tiles) are fastest at NT = 1 up to M = 32
+    pl.nt = 1;
+    if (n16 >= 1024 && M > 8) pl.nt = 4;
+    else if (n16 >= 384 && n16 < 1024 && M > 16) pl.nt = 2;
+    const int nt = env_int("NMV_MM_NT", 0);
+    if (nt == 1 || nt == 2 || nt == 4) pl.nt = nt;
+    pl.un = pl.nt == 4 ? 2 : 4;
   } else {
     // Every activation fragment a wave loads is reused for NT column tiles, so the L2 traffic for
     // activations is 4/NT x the weight bytes: take the widest NT that still leaves >= 192
@@ -281,8 +291,11 @@ static void launch_mm(MMParams p, const MMPlan& pl, hipStream_t s) {
     hipLaunchKernelGGL((scaled_mm_kernel<T, FP8, MT_, NT_, UN_>), grid, dim3(MM_THREADS), 0, s, p);  \
   }
   MM_CASE(1, 1, 4)
+  MM_CASE(1, 2, 4)
+  MM_CASE(1, 4, 2)
   MM_CASE(2, 1, 4)
   MM_CASE(2, 2, 4)
+  MM_CASE(2, 4, 2)
   MM_CASE(4, 1, 4)
   MM_CASE(4, 2, 2)
   MM_CASE(4, 4, 2)

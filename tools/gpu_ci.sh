@@ -48,6 +48,10 @@ for step in "$@"; do
             run attntraffic rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/atr -- python tools/bench_attn.py ${ATTN_ARGS:-}
             find gpurun_out/atr -name "*counter_collection.csv" | head -1 | xargs -I{} cp {} gpurun_out/attn_fetch.csv
             rm -rf gpurun_out/atr ;;
+    w8prof) cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
+            run w8prof rocprofv3 --kernel-trace --output-format csv -d gpurun_out/w8prof -- python tools/bench_w8a8.py ${W8_ARGS:-}
+            find gpurun_out/w8prof -name "*kernel_trace.csv" | head -1 | xargs -I{} cp {} gpurun_out/w8a8_trace.csv
+            rm -rf gpurun_out/w8prof ;;
     gemmsweep) run gemmsweep python tools/bench_gemm.py --sweep ;;
     prof)   cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
             run prof rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -- python bench.py --steps 16 --warmup 4 --no-sweep --no-cpu-baseline ${BENCH_ARGS:-}
