@@ -402,9 +402,10 @@ def main():
             msg = args.batch * arch.hidden_size * 2
             out["config"]["all_reduce"] = (f"p2p {'two-shot' if car.is_two_shot(msg) else 'one-shot'} over HIP IPC, "
                                            f"fused with residual-add + RMSNorm ({msg} B per call)")
-            if os.environ.get("NMV_BENCH_COMPARE_RCCL", "1") != "0" and not args.no_sweep:
-                # the same step with the P2P communicator switched off: every all-reduce / gather goes
-                # through the process group (RCCL) -- so that the scaling curve can be read for both
+            if os.environ.get("NMV_BENCH_COMPARE_RCCL", "0") == "1" and not args.no_sweep:
+                # opt-in (NMV_BENCH_COMPARE_RCCL=1): the same step with the P2P communicator switched off -- every
+                # all-reduce / gather through the process group (RCCL) -- so that the scaling curve can be read for
+                # both.  Not by default: a fault in that second path would cost the line of the first.
                 tp.custom_ar = None
                 try:
                     d3, g3 = measure(args.batch, args.steps, args.warmup)

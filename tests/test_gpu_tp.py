@@ -127,7 +127,7 @@ def test_bench_py_multi_rank_rehearsal(gpu_device, custom_ar):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, NMV_BENCH_DIST_BACKEND="gloo", NMV_BENCH_SINGLE_DEVICE="1",
-               NMV_CUSTOM_ALLREDUCE=custom_ar, NMV_CUSTOM_AR_TIMEOUT_MS="30000")
+               NMV_CUSTOM_ALLREDUCE=custom_ar, NMV_CUSTOM_AR_TIMEOUT_MS="30000", NMV_BENCH_COMPARE_RCCL="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port())] + _bench_cmd(root, [])
     out = _one_json_line(subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600))
