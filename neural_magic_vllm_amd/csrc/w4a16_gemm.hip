@@ -736,7 +736,14 @@ __global__ __launch_bounds__(GT, 2) void w4a16_gemm_tall_kernel(const GemmParams
   constexpr int TS_K = 32 * KSS;               // k per stage
   constexpr int SPG = 4 / KSS;                 // stages per 128-k scale group
   constexpr int PPR = 4 * KSS;                 // 16-byte activation pieces per row and stage
-  constexpr int A_U4 = KSS * 4 * MP;           // uint4 per (stage, k-group): [k-step][g][row]
+  // [k-step][g] planes of MP rows x 16 B (a plane read back by ds_read_b128 is conflict-free exactly with this
+  // 256-byte row pitch: the instruction's 16-lane groups are {0-3,12-15,20-27}, ...).  With two k-steps per stage a
+  // staging write instruction stores one dword of rows 0..3 into plane (k-step 0, g) AND (k-step 1, g) -- a multiple
+  // of 256 B apart, the same 16 of the 32 write banks twice, four times with the paired ds_write2 -- so the row index
+  // of k-step 1's planes is XORed with 4: rows 0..3 go to banks 16..31 there (PMC: SQ_LDS_BANK_CONFLICT was 30 % of
+  // SQ_LDS_IDX_ACTIVE); the read applies the same XOR and stays a permutation of a plane's 16 rows.
+  constexpr int PSTR = MP;
+  constexpr int A_U4 = KSS * 4 * PSTR;         // uint4 per (stage, k-group): [k-step][g][row]
   constexpr int SC_U4 = 4 * 8;                 // one scale group: [k-group * WN + wn] x 128 B
   constexpr int MAIN_U4 = 2 * WK * A_U4 + (ZP ? 4 : 2) * SC_U4;
   constexpr int RED_U4 = (WK > 1) ? (WK - 1) * WN * MT * 256 : 0;
@@ -807,11 +814,11 @@ __global__ __launch_bounds__(GT, 2) void w4a16_gemm_tall_kernel(const GemmParams
       const int id = (threadIdx.x + i * GT) % A_CHUNKS;
       const int c8 = id % PPR, row = (id / PPR) % MP, kg = (id / PPR) / MP;
       const int ks = c8 >> 2, cc = c8 & 3;
-      const int e0 = ((buf * WK + kg) * A_U4 + (ks * 4 + 0) * MP + row) * 4 + cc;
+      const int e0 = ((buf * WK + kg) * A_U4 + (ks * 4 + 0) * PSTR + (row ^ (ks << 2))) * 4 + cc;
       base[e0] = av[i].x;
-      base[e0 + 4 * MP] = av[i].y;
-      base[e0 + 8 * MP] = av[i].z;
-      base[e0 + 12 * MP] = av[i].w;
+      base[e0 + 4 * PSTR] = av[i].y;
+      base[e0 + 8 * PSTR] = av[i].z;
+      base[e0 + 12 * PSTR] = av[i].w;
     }
   };
   // scale rows: threads 0..31 = (k-group*WN + wn') x 8 pieces of 16 B (64 columns x 2 B)
@@ -931,7 +938,7 @@ __global__ __launch_bounds__(GT, 2) void w4a16_gemm_tall_kernel(const GemmParams
       }
       uint4 af[MT];
 #pragma unroll
-      for (int t = 0; t < MT; ++t) af[t] = a_s[(buf * WK + wk) * A_U4 + (ks * 4 + g) * MP + t * 16 + r];
+      for (int t = 0; t < MT; ++t) af[t] = a_s[(buf * WK + wk) * A_U4 + (ks * 4 + g) * PSTR + ((t * 16 + r) ^ (ks << 2))];
       uint32_t own[4 * WV];
 #pragma unroll
       for (int h = 0; h < WV; ++h) {
