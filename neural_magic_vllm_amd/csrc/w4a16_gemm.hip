@@ -1371,14 +1371,19 @@ static GemmPlan make_plan(int M, int N, int K, int64_t tickets_len, bool allow_t
     pl.wm = 1;
     // 128-row prescale tile: measured to win from M = 1024 on every Llama-3-8B projection and from
     // M = 384 on the wide ones (gate_up: 153 vs 176 us at M = 512, 481 vs 666 us at M = 2048)
-    const bool big = M >= 1024 || (M >= 384 && n_chunks >= 256);
-    pl.mt = env_int("NMV_W4_TALL_MT", M <= 16 ? 1 : M <= 64 ? 2 : big ? 8 : 4);
+    // (round 2, tools/sweep_tall.py at M = 128 / 256 / 512): the prescale tile already wins at M = 256 on the wide
+    // projections (gate_up 88.9 vs 98.6 us); the narrow ones (qkv, o: < 256 chunks) are faster with the 32-row
+    // tile and four k groups up to M = 256 (o 14.2 vs 17.6 us at M = 128, 20.5 vs 23.6 at 256), a long K (down)
+    // only up to M = 128 (32.8 vs 39.3 us)
+    const bool big = M >= 1024 || (M >= 256 && n_chunks >= 256);
+    const bool narrow32 = n_chunks < 256 && (M <= 128 || (M <= 256 && K <= 8192));
+    pl.mt = env_int("NMV_W4_TALL_MT", M <= 16 ? 1 : (M <= 64 || narrow32) ? 2 : big ? 8 : 4);
     if (bits == 8 && pl.mt > 4) pl.mt = 4;       // no prescale variant for 8-bit codes  // measured: 64-row tile wins only past M = 64
     const int rows = 16 * pl.mt;
     pl.m_blocks = (M + rows - 1) / rows;
     // wide N: two chunks per workgroup, two k groups; narrow N: one chunk, four k groups (the
     // in-workgroup k reduction goes through LDS and saves split-K slabs)
-    int wk = (M > 32 && n_chunks * pl.m_blocks >= 256) ? 2 : 4;
+    int wk = (M > 32 && n_chunks * pl.m_blocks >= 256 && !(M > 64 && pl.mt == 2)) ? 2 : 4;
     wk = env_int("NMV_W4_TALL_WK", wk);
     if (pl.mt == 8) wk = 1;                     // the 128-row tile exists as 4 chunks x 1 k group only
     if (bits == 8 && pl.mt == 4 && wk == 4) wk = 2;  // 8-bit 64-row tile: registers allow 4x1 / 2x2

@@ -36,7 +36,7 @@ if __name__ == "__main__":
                 kw = dict(native=md) if args.native else dict(mode=md)
                 base, _ = bench_gemm.bench(name, k, n, m, dev, iters=24, **kw)
                 res = []
-                for mt in (1, 2, 4):
+                for mt in (1, 2, 4, 8):
                     for wk in (4, 2, 1):
                         for sp in (1, 2, 3, 4, 8):
                             clear()
