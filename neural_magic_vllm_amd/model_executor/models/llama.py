@@ -128,17 +128,23 @@ class LlamaAttention(nn.Module):
                               num_kv_heads=self.num_kv_heads, cache_config=cache_config,
                               quant_config=quant_config)
         self.fused_glue = fused_glue_default()
+        # experiment switch: "1" = rope + cache write in the attention launch's prologue (default), "0" = in their own
+        # launch between the qkv GEMM and the attention
+        self.attn_prologue = os.environ.get("NMV_ATTN_PROLOGUE", "1")
 
     def forward(self, positions: torch.Tensor, hidden_states: torch.Tensor,
                 kv_cache: Optional[torch.Tensor], attn_metadata: AttentionMetadata) -> torch.Tensor:
         qkv = None
-        if self.fused_glue and isinstance(hidden_states, torch.Tensor) and hidden_states.dim() == 2:
+        if self.fused_glue and isinstance(hidden_states, torch.Tensor) and hidden_states.dim() == 2 \
+                and self.attn_prologue != "plain":
             # deferred split-K: the rope + cache launch sums the qkv projection's fp32 slabs
             slab = self.qkv_proj.forward_partial(hidden_states)
             if slab is not None:
                 # decode-only batch: rope + cache write + paged attention in one launch
-                attn_output = self.attn.decode_rope_partial(positions, slab, self.rotary_emb, kv_cache,
-                                                            attn_metadata, hidden_states.dtype)
+                attn_output = None
+                if self.attn_prologue == "1":
+                    attn_output = self.attn.decode_rope_partial(positions, slab, self.rotary_emb, kv_cache,
+                                                                attn_metadata, hidden_states.dtype)
                 if attn_output is not None:
                     return self._o(attn_output)
                 qkv = self.attn.rope_and_cache_partial(positions, slab, self.rotary_emb, kv_cache,
@@ -148,7 +154,7 @@ class LlamaAttention(nn.Module):
             attn_output = self.attn(q, k, v, kv_cache, attn_metadata, cache_written=True)
             return self._o(attn_output)
         qkv, _ = self.qkv_proj(hidden_states)
-        if self.fused_glue and qkv.is_cuda and qkv.dim() == 2:
+        if self.fused_glue and qkv.is_cuda and qkv.dim() == 2 and self.attn_prologue == "1":
             # decode-only batch: rope + cache write + paged attention in one launch, from the finished row
             attn_output = self.attn.decode_rope_partial(positions, qkv, self.rotary_emb, kv_cache,
                                                         attn_metadata, qkv.dtype)
