@@ -91,7 +91,11 @@ int nmv_convert_fp8(void* dst, const void* src, int64_t num_blocks, int64_t bloc
  * out, query: [num_seqs, num_heads, head_size]; q_stride = query.stride(0); out is contiguous.
  * block_tables: int32 [num_seqs, max_num_blocks_per_seq]; seq_lens: int32 [num_seqs].
  * kv_block_stride = key_cache.stride(0), kv_head_stride = key_cache.stride(1).
- * alibi_slopes: float [num_heads] or NULL. */
+ * alibi_slopes: float [num_heads] or NULL.
+ * Block-sparse attention (attention_kernels.cu:209-251,385-393; the last five ints of the reference op):
+ * blocksparse_vert_stride <= 1 = dense; else a head attends to the last `blocksparse_local_blocks` blocks of
+ * `blocksparse_block_size` tokens and to every block whose id + head offset is a multiple of the stride, the
+ * offset sliding with the query head (head_sliding_step >= 0) or the kv head (< 0) and tp_rank. */
 int nmv_paged_attention_v1(void* out, const void* query, const void* key_cache,
                            const void* value_cache, int num_seqs, int num_heads, int head_size,
                            int num_kv_heads, float scale, const int32_t* block_tables,
@@ -99,7 +103,8 @@ int nmv_paged_attention_v1(void* out, const void* query, const void* key_cache,
                            int max_num_blocks_per_seq, const float* alibi_slopes,
                            int64_t q_stride, int64_t kv_block_stride, int64_t kv_head_stride,
                            nmv_dtype_t dtype, nmv_kv_dtype_t kv_dtype, float kv_scale,
-                           void* stream);
+                           int tp_rank, int blocksparse_local_blocks, int blocksparse_vert_stride,
+                           int blocksparse_block_size, int blocksparse_head_sliding_step, void* stream);
 
 /* paged_attention_v2  (attention_kernels.cu:966-990): partition size 512.
  * exp_sums, max_logits: float [num_seqs, num_heads, max_num_partitions];
@@ -111,7 +116,9 @@ int nmv_paged_attention_v2(void* out, float* exp_sums, float* max_logits, void* 
                            int block_size, int max_seq_len, int max_num_blocks_per_seq,
                            const float* alibi_slopes, int64_t q_stride, int64_t kv_block_stride,
                            int64_t kv_head_stride, nmv_dtype_t dtype, nmv_kv_dtype_t kv_dtype,
-                           float kv_scale, void* stream);
+                           float kv_scale, int tp_rank, int blocksparse_local_blocks,
+                           int blocksparse_vert_stride, int blocksparse_block_size,
+                           int blocksparse_head_sliding_step, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Glue ops so a whole decoder layer runs without the reference's csrc

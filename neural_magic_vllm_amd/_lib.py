@@ -45,9 +45,9 @@ SIGNATURES = {
     "nmv_swap_blocks": (_I, [_P, _P, _P, _I, _L, _I, _P]),
     "nmv_convert_fp8": (_I, [_P, _P, _L, _L, _I, _I, _F, _P]),
     "nmv_paged_attention_v1": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _F, _P, _P, _I, _I, _I, _P,
-                                    _L, _L, _L, _I, _I, _F, _P]),
+                                    _L, _L, _L, _I, _I, _F, _I, _I, _I, _I, _I, _P]),
     "nmv_paged_attention_v2": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P, _P, _I,
-                                    _I, _I, _P, _L, _L, _L, _I, _I, _F, _P]),
+                                    _I, _I, _P, _L, _L, _L, _I, _I, _F, _I, _I, _I, _I, _I, _P]),
     "nmv_rms_norm": (_I, [_P, _P, _P, _F, _I, _I, _I, _P]),
     "nmv_fused_add_rms_norm": (_I, [_P, _P, _P, _F, _I, _I, _I, _P]),
     "nmv_rotary_embedding": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _L, _L, _P, _I, _I, _P]),

@@ -27,9 +27,11 @@ def _req(cond: bool, msg: str) -> None:
 
 
 # ----------------------------------------------------------------------------- attention
-def _pa_common(query, key_cache, value_cache, block_tables, seq_lens, blocksparse_vert_stride):
-    _req(blocksparse_vert_stride <= 1,
-         "blocksparse paged attention (blocksparse_vert_stride > 1) is out of scope on gfx950")
+def _pa_common(query, key_cache, value_cache, block_tables, seq_lens, blocksparse_vert_stride,
+               blocksparse_block_size, block_size):
+    # attention_kernels.cu:235: the sparsity block of a KV block is block_idx * BLOCK_SIZE / blocksparse_block_size
+    _req(blocksparse_vert_stride <= 1 or (blocksparse_block_size > 0 and blocksparse_block_size % block_size == 0),
+         "blocksparse_block_size must be a positive multiple of the KV block size")
     _req(block_tables.dtype == torch.int32 and seq_lens.dtype == torch.int32,
          "block_tables and seq_lens must be int32")
     _req(query.stride(-1) == 1 and query.stride(1) == query.shape[2],
@@ -42,7 +44,8 @@ def paged_attention_v1(out, query, key_cache, value_cache, num_kv_heads, scale, 
                        tp_rank, blocksparse_local_blocks, blocksparse_vert_stride,
                        blocksparse_block_size, blocksparse_head_sliding_step) -> None:
     """csrc/attention/attention_kernels.cu:805-826"""
-    _pa_common(query, key_cache, value_cache, block_tables, seq_lens, blocksparse_vert_stride)
+    _pa_common(query, key_cache, value_cache, block_tables, seq_lens, blocksparse_vert_stride,
+               blocksparse_block_size, block_size)
     num_seqs, num_heads, head_size = query.shape
     _req(out.is_contiguous(), "out must be contiguous")
     L = _lib.load()
@@ -52,7 +55,9 @@ def paged_attention_v1(out, query, key_cache, value_cache, num_kv_heads, scale, 
             head_size, num_kv_heads, scale, ptr(block_tables), ptr(seq_lens), block_size,
             max_seq_len, block_tables.shape[1], ptr(alibi_slopes), query.stride(0),
             key_cache.stride(0), key_cache.stride(1), dtype_code(query.dtype),
-            kv_dtype_code(kv_cache_dtype), kv_scale, stream_of(query)))
+            kv_dtype_code(kv_cache_dtype), kv_scale, int(tp_rank), int(blocksparse_local_blocks),
+            int(blocksparse_vert_stride), int(blocksparse_block_size), int(blocksparse_head_sliding_step),
+            stream_of(query)))
 
 
 def paged_attention_v2(out, exp_sums, max_logits, tmp_out, query, key_cache, value_cache,
@@ -61,7 +66,8 @@ def paged_attention_v2(out, exp_sums, max_logits, tmp_out, query, key_cache, val
                        blocksparse_vert_stride, blocksparse_block_size,
                        blocksparse_head_sliding_step) -> None:
     """csrc/attention/attention_kernels.cu:966-990"""
-    _pa_common(query, key_cache, value_cache, block_tables, seq_lens, blocksparse_vert_stride)
+    _pa_common(query, key_cache, value_cache, block_tables, seq_lens, blocksparse_vert_stride,
+               blocksparse_block_size, block_size)
     num_seqs, num_heads, head_size = query.shape
     _req(out.is_contiguous() and tmp_out.is_contiguous() and exp_sums.is_contiguous()
          and max_logits.is_contiguous(), "out/tmp_out/exp_sums/max_logits must be contiguous")
@@ -77,7 +83,9 @@ def paged_attention_v2(out, exp_sums, max_logits, tmp_out, query, key_cache, val
             ptr(value_cache), num_seqs, num_heads, head_size, num_kv_heads, scale,
             ptr(block_tables), ptr(seq_lens), block_size, max_seq_len, block_tables.shape[1],
             ptr(alibi_slopes), query.stride(0), key_cache.stride(0), key_cache.stride(1),
-            dtype_code(query.dtype), kv_dtype_code(kv_cache_dtype), kv_scale, stream_of(query)))
+            dtype_code(query.dtype), kv_dtype_code(kv_cache_dtype), kv_scale, int(tp_rank),
+            int(blocksparse_local_blocks), int(blocksparse_vert_stride), int(blocksparse_block_size),
+            int(blocksparse_head_sliding_step), stream_of(query)))
 
 
 def paged_attention_rope_partial(out, slab, positions, cos_sin_cache, slot_mapping, key_cache, value_cache,

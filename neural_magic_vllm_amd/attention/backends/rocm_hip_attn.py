@@ -106,7 +106,9 @@ class ROCmHipAttentionImpl(AttentionImpl):
                  num_kv_heads: Optional[int] = None, alibi_slopes: Optional[List[float]] = None,
                  sliding_window: Optional[int] = None, kv_cache_dtype: str = "auto",
                  blocksparse_params: Optional[Dict[str, Any]] = None) -> None:
-        assert blocksparse_params is None, "the gfx950 backend does not support block-sparse attention"
+        # the decode op takes the block-sparse arguments (PagedAttention.forward_decode); the block-sparse PROMPT path
+        # is the reference's separate BlocksparseFlashAttentionBackend, which this backend does not replace
+        assert blocksparse_params is None, "block-sparse models need the reference's blocksparse backend for prompts"
         # prompt attention masks the window in the kernel (rocm_flash_attn.py:244-246,394-406 hands it to
         # flash-attention / forward_prefix); decode sees it through the block tables and sequence lengths the
         # model runner builds, as in the reference (paged_attention takes no window)

@@ -85,10 +85,19 @@ struct PAFused {
   const int64_t* slot_mapping;  // [num_seqs] cache slot of the new token (< 0: padding)
 };
 
+// Block-sparse attention (attention_kernels.cu:209-251, 385-393): the context is cut into blocks of `block_size`
+// tokens; a head attends to a block when it is one of the last `local_blocks` blocks of the sequence ("local")
+// or when (block id + head offset) is a multiple of `vert_stride` ("remote"); the head offset slides with the
+// query head (head_sliding_step >= 0) or with the kv head (< 0).  vert_stride <= 1: dense.  Every other token
+// is left out of the softmax (the reference stores -FLT_MAX for it and skips its V block).
+struct PASparse {
+  int tp_rank, local_blocks, vert_stride, block_size, head_sliding_step;
+};
+
 // NW waves per workgroup: 4 when the grid fills the chip, 8 when it does not (few sequences):
 // the same KV run is then split over twice the waves and the per-wave chain of dependent windows
 // halves (B=1, L=530: 14.7 -> 10.9 us; at B=64 the 4-wave form is 15 % faster).
-template <typename T, bool FP8, int HEAD_SIZE, int BLOCK_SIZE, int HG, int NW>
+template <typename T, bool FP8, int HEAD_SIZE, int BLOCK_SIZE, int HG, int NW, bool SPARSE = false>
 __global__ __launch_bounds__(NW * WAVE) void paged_attention_kernel(
     float* __restrict__ exp_sums,    // [num_seqs, num_heads, max_num_partitions] (partitioned only)
     float* __restrict__ max_logits,  // same
@@ -100,7 +109,7 @@ __global__ __launch_bounds__(NW * WAVE) void paged_attention_kernel(
     const int* __restrict__ seq_lens, int max_num_blocks_per_seq,
     const float* __restrict__ alibi_slopes, int64_t q_stride, int64_t kv_block_stride,
     int64_t kv_head_stride, float kv_scale, int partition_size /* 0 = not partitioned */,
-    const PAFused f) {
+    const PAFused f, const PASparse sp) {
   using G = PAGeom<HEAD_SIZE, BLOCK_SIZE, HG, FP8>;
   const int seq_idx = blockIdx.y;
   const int part_idx = blockIdx.z;
@@ -305,14 +314,32 @@ __global__ __launch_bounds__(NW * WAVE) void paged_attention_kernel(
     }
 
     // ================= online softmax =================
+    // block-sparse: the sparsity block of this lane's token, by KV block as the reference computes it
+    // (SPARSE is a template parameter: as a run-time flag the integer divisions below cost the dense kernel
+    // 35 % at B = 64 and 4x at B = 1)
+    int kb = 0;
+    bool kb_local = false;
+    if constexpr (SPARSE) {
+      kb = (tok_c / BLOCK_SIZE) * BLOCK_SIZE / sp.block_size;
+      kb_local = kb > (seq_len - 1) / sp.block_size - sp.local_blocks;
+    }
 #pragma unroll
     for (int h = 0; h < HG; ++h) {
       float sv = s[h] * qk_scale;
       sv += (slope[h] != 0.f) ? slope[h] * (float)(tok - seq_len + 1) : 0.f;
-      sv = valid ? sv : -INFINITY;
+      bool attend = valid;
+      if constexpr (SPARSE) {
+        const int off = sp.head_sliding_step >= 0
+                            ? (sp.tp_rank * num_heads + head0 + h) * sp.head_sliding_step + 1
+                            : (sp.tp_rank * num_kv_heads + kv_head) * (-sp.head_sliding_step) + 1;
+        attend = valid && (kb_local || (kb + off) % sp.vert_stride == 0);
+      }
+      sv = attend ? sv : -INFINITY;
       const float m_new = fmaxf(m_run[h], wave_max(sv));
-      const float alpha = __expf(m_run[h] - m_new);  // exp(-inf) = 0 on the first window
-      const float p = valid ? __expf(sv - m_new) : 0.f;
+      // exp(-inf) = 0 on the first window; a window in which this head attends to nothing (block-sparse) leaves
+      // m_new at -inf: nothing has been accumulated yet, 0 keeps it so (and avoids exp(-inf + inf))
+      const float alpha = m_new == -INFINITY ? 0.f : __expf(m_run[h] - m_new);
+      const float p = attend ? __expf(sv - m_new) : 0.f;
       l_lane[h] = l_lane[h] * alpha + p;
       m_run[h] = m_new;
 #pragma unroll
@@ -430,7 +457,8 @@ __global__ __launch_bounds__(NW * WAVE) void paged_attention_kernel(
     float mg = red_m[0][h];
 #pragma unroll
     for (int ww = 1; ww < NW; ++ww) mg = fmaxf(mg, red_m[ww][h]);
-    const float f = __expf(m_run[h] - mg) * kvs;  // wave without work: exp(-inf) = 0
+    // wave without work: exp(-inf) = 0; mg = -inf (block-sparse: no token of this partition attended): 0
+    const float f = mg == -INFINITY ? 0.f : __expf(m_run[h] - mg) * kvs;
 #pragma unroll
     for (int i = 0; i < G::NVL; ++i) {
       const int row = i * G::RPL + row_l;
@@ -448,7 +476,7 @@ __global__ __launch_bounds__(NW * WAVE) void paged_attention_kernel(
     float lg = 0.f, o = 0.f;
 #pragma unroll
     for (int ww = 0; ww < NW; ++ww) {
-      lg += red_l[ww][h] * __expf(red_m[ww][h] - mg);
+      lg += mg == -INFINITY ? 0.f : red_l[ww][h] * __expf(red_m[ww][h] - mg);
       o += out_red[ww][h][d];
     }
     const float inv = __fdividef(1.f, lg + 1e-6f);  // attention_kernels.cu:342
@@ -517,6 +545,7 @@ struct PAArgs {
   const float* alibi_slopes; int64_t q_stride, kv_block_stride, kv_head_stride;
   float kv_scale; bool partitioned; hipStream_t stream;
   PAFused fused = {nullptr, nullptr, 0, 0, 0, nullptr, nullptr, nullptr};
+  PASparse sparse = {0, 0, 1, 64, 0};
 };
 
 template <typename T, bool FP8, int HEAD_SIZE, int BLOCK_SIZE, int HG>
@@ -525,16 +554,24 @@ static void launch_pa(const PAArgs& a) {
   dim3 grid(a.num_heads / HG, a.num_seqs, parts);
   // no more workgroups than CUs: 8 waves each
   const bool wide = (int64_t)grid.x * grid.y * grid.z <= 256;
-#define NMV_PA_LAUNCH(NW_)                                                                        \
-  hipLaunchKernelGGL((paged_attention_kernel<T, FP8, HEAD_SIZE, BLOCK_SIZE, HG, NW_>), grid,       \
+#define NMV_PA_LAUNCH(NW_) NMV_PA_LAUNCH_S(NW_, false)
+#define NMV_PA_LAUNCH_S(NW_, SP_)                                                                 \
+  hipLaunchKernelGGL((paged_attention_kernel<T, FP8, HEAD_SIZE, BLOCK_SIZE, HG, NW_, SP_>), grid,  \
                      dim3(NW_ * WAVE), 0, a.stream, a.exp_sums, a.max_logits,                      \
                      (uint16_t*)(a.partitioned ? a.tmp_out : a.out), (const uint16_t*)a.query,     \
                      (const uint8_t*)a.key_cache, (const uint8_t*)a.value_cache, a.num_heads,      \
                      a.num_kv_heads, a.scale, a.block_tables, a.seq_lens,                          \
                      a.max_num_blocks_per_seq, a.alibi_slopes, a.q_stride, a.kv_block_stride,      \
-                     a.kv_head_stride, a.kv_scale, a.partitioned ? PA_PARTITION : 0, a.fused)
-  if (wide) NMV_PA_LAUNCH(8); else NMV_PA_LAUNCH(4);
+                     a.kv_head_stride, a.kv_scale, a.partitioned ? PA_PARTITION : 0, a.fused, a.sparse)
+  if (a.sparse.vert_stride > 1) {   // block-sparse: one form (4 waves), no fused prologue
+    NMV_PA_LAUNCH_S(4, true);
+  } else if (wide) {
+    NMV_PA_LAUNCH(8);
+  } else {
+    NMV_PA_LAUNCH(4);
+  }
 #undef NMV_PA_LAUNCH
+#undef NMV_PA_LAUNCH_S
   if (a.partitioned) {
     dim3 rgrid(a.num_heads, a.num_seqs);
     hipLaunchKernelGGL((paged_attention_v2_reduce_kernel<T, HEAD_SIZE>), rgrid, dim3(WAVE),
@@ -633,11 +670,16 @@ extern "C" int nmv_paged_attention_v1(void* out, const void* query, const void* 
                                       const float* alibi_slopes, int64_t q_stride,
                                       int64_t kv_block_stride, int64_t kv_head_stride,
                                       nmv_dtype_t dtype, nmv_kv_dtype_t kv_dtype, float kv_scale,
+                                      int tp_rank, int blocksparse_local_blocks, int blocksparse_vert_stride,
+                                      int blocksparse_block_size, int blocksparse_head_sliding_step,
                                       void* stream) {
   PAArgs a{nullptr, nullptr, out, nullptr, query, key_cache, value_cache, num_seqs, num_heads,
            head_size, num_kv_heads, scale, block_tables, seq_lens, block_size, max_seq_len,
            max_num_blocks_per_seq, alibi_slopes, q_stride, kv_block_stride, kv_head_stride,
            kv_scale, false, (hipStream_t)stream};
+  NMV_CHECK(blocksparse_vert_stride <= 1 || blocksparse_block_size > 0, "paged_attention_v1: blocksparse_block_size");
+  a.sparse = PASparse{tp_rank, blocksparse_local_blocks, blocksparse_vert_stride, blocksparse_block_size,
+                      blocksparse_head_sliding_step};
   return pa_entry(a, dtype, kv_dtype, "paged_attention_v1");
 }
 
@@ -650,12 +692,17 @@ extern "C" int nmv_paged_attention_v2(void* out, float* exp_sums, float* max_log
                                       const float* alibi_slopes, int64_t q_stride,
                                       int64_t kv_block_stride, int64_t kv_head_stride,
                                       nmv_dtype_t dtype, nmv_kv_dtype_t kv_dtype, float kv_scale,
+                                      int tp_rank, int blocksparse_local_blocks, int blocksparse_vert_stride,
+                                      int blocksparse_block_size, int blocksparse_head_sliding_step,
                                       void* stream) {
   NMV_CHECK(exp_sums && max_logits && tmp_out, "paged_attention_v2: null partition buffers");
+  NMV_CHECK(blocksparse_vert_stride <= 1 || blocksparse_block_size > 0, "paged_attention_v2: blocksparse_block_size");
   PAArgs a{exp_sums, max_logits, out, tmp_out, query, key_cache, value_cache, num_seqs,
            num_heads, head_size, num_kv_heads, scale, block_tables, seq_lens, block_size,
            max_seq_len, max_num_blocks_per_seq, alibi_slopes, q_stride, kv_block_stride,
            kv_head_stride, kv_scale, true, (hipStream_t)stream};
+  a.sparse = PASparse{tp_rank, blocksparse_local_blocks, blocksparse_vert_stride, blocksparse_block_size,
+                      blocksparse_head_sliding_step};
   return pa_entry(a, dtype, kv_dtype, "paged_attention_v2");
 }
 

@@ -80,9 +80,29 @@ def make_paged_attention_inputs(seed: int, num_seqs: int, num_heads: Tuple[int, 
                 block_size=block_size)
 
 
-def ref_paged_attention_torch(inp, kv_scale: float = 1.0) -> torch.Tensor:
+def blocksparse_mask(seq_len: int, num_heads: int, num_kv_heads: int, tp_rank: int, local_blocks: int,
+                     vert_stride: int, block_size: int, head_sliding_step: int) -> torch.Tensor:
+    """[heads, seq_len] additive mask (0 / -inf) of block-sparse attention for the LAST token of a sequence, as the
+    reference's test builds it (tests/kernels/test_blocksparse_attention.py:117-139; the kernel:
+    attention_kernels.cu:209-251): block kb of `block_size` tokens is attended when it is one of the last
+    `local_blocks` blocks or when kb + head offset is a multiple of `vert_stride`"""
+    qb = (seq_len - 1) // block_size
+    mask = torch.full((num_heads, seq_len), float("-inf"))
+    for h in range(num_heads):
+        if head_sliding_step >= 0:
+            off = (tp_rank * num_heads + h) * head_sliding_step + 1
+        else:
+            off = (tp_rank * num_kv_heads + h // (num_heads // num_kv_heads)) * (-head_sliding_step) + 1
+        for kb in range(qb + 1):
+            if qb - kb < local_blocks or (kb + off) % vert_stride == 0:
+                mask[h, kb * block_size:min((kb + 1) * block_size, seq_len)] = 0
+    return mask
+
+
+def ref_paged_attention_torch(inp, kv_scale: float = 1.0, blocksparse=None) -> torch.Tensor:
     """Plain-torch fp32 gather + softmax (the reference test's own checker,
-    tests/kernels/test_attention.py:47-116), used to cross-check the C oracle."""
+    tests/kernels/test_attention.py:47-116), used to cross-check the C oracle.  blocksparse = dict(tp_rank,
+    local_blocks, vert_stride, block_size, head_sliding_step) adds the block-sparse mask."""
     q = inp["query"].float()
     kc, vc = inp["key_cache"], inp["value_cache"]
     if kc.dtype == torch.uint8:
@@ -106,6 +126,8 @@ def ref_paged_attention_torch(inp, kv_scale: float = 1.0) -> torch.Tensor:
         att = inp["scale"] * torch.einsum("hd,lhd->hl", q[i], k)
         if inp["alibi_slopes"] is not None:
             att = att + inp["alibi_slopes"].view(-1, 1) * (tok - L + 1).float().view(1, -1)
+        if blocksparse is not None and blocksparse["vert_stride"] > 1:
+            att = att + blocksparse_mask(L, nh, nkv, **blocksparse)
         att = torch.softmax(att, dim=-1)
         out[i] = torch.einsum("hl,lhd->hd", att, v)
     return out

@@ -14,8 +14,11 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-def run_hip(inp, version, dev, kv_cache_dtype="auto", kv_scale=1.0, query=None):
+def run_hip(inp, version, dev, kv_cache_dtype="auto", kv_scale=1.0, query=None, sparse=None):
+    """sparse = dict(tp_rank, local_blocks, vert_stride, block_size, head_sliding_step): block-sparse attention"""
     from neural_magic_vllm_amd import _custom_ops as ops
+    sp = (0, 0, 0, 64, 0) if sparse is None else tuple(sparse[k] for k in (
+        "tp_rank", "local_blocks", "vert_stride", "block_size", "head_sliding_step"))
     q = inp["query"].to(dev) if query is None else query
     kc, vc = inp["key_cache"].to(dev), inp["value_cache"].to(dev)
     bt, sl = inp["block_tables"].to(dev), inp["seq_lens"].to(dev)
@@ -24,7 +27,7 @@ def run_hip(inp, version, dev, kv_cache_dtype="auto", kv_scale=1.0, query=None):
     nkv, bs, msl = inp["num_kv_heads"], inp["block_size"], inp["max_seq_len"]
     if version == "v1":
         ops.paged_attention_v1(out, q, kc, vc, nkv, inp["scale"], bt, sl, bs, msl, al,
-                               kv_cache_dtype, kv_scale)
+                               kv_cache_dtype, kv_scale, *sp)
         return out.cpu(), None
     ns, nh, hs = q.shape
     mp = (msl + 511) // 512
@@ -32,7 +35,7 @@ def run_hip(inp, version, dev, kv_cache_dtype="auto", kv_scale=1.0, query=None):
     es = torch.empty((ns, nh, mp), dtype=torch.float32, device=dev)
     ml = torch.empty_like(es)
     ops.paged_attention_v2(out, es, ml, tmp, q, kc, vc, nkv, inp["scale"], bt, sl, bs, msl, al,
-                           kv_cache_dtype, kv_scale)
+                           kv_cache_dtype, kv_scale, *sp)
     return out.cpu(), (es.cpu(), ml.cpu(), tmp.cpu())
 
 
@@ -178,6 +181,40 @@ def test_paged_attention_golden(gpu_device, name, version):
     out, _ = run_hip(inp, version, gpu_device)
     ref = helpers.from_np(g["out_" + version], torch.bfloat16)
     check(out, ref, atol=1e-3, rtol=1e-2)
+
+
+@pytest.mark.parametrize("name", ["bsa_qslide", "bsa_kvslide_alibi", "bsa_homo"])
+@pytest.mark.parametrize("version", ["v1", "v2"])
+def test_blocksparse_paged_attention_golden(gpu_device, name, version):
+    """block-sparse paged attention (attention_kernels.cu:209-251) against the output of the reference test's own
+    checker (tests/golden/bsa_*.npz, tools/make_golden_blocksparse.py)"""
+    import test_oracle_golden
+    inp, sparse, ref = test_oracle_golden.bsa_case(name)
+    out, _ = run_hip(inp, version, gpu_device, sparse=sparse)
+    check(out, ref, atol=1e-3, rtol=1e-2)
+
+
+@pytest.mark.parametrize("version", ["v1", "v2"])
+@pytest.mark.parametrize("kv_cache_dtype", ["auto", "fp8"])
+@pytest.mark.parametrize("sliding", [0, 2, -1])
+@pytest.mark.parametrize("num_heads,head_size,block_size", [((40, 40), 64, 16), ((64, 8), 112, 32), ((32, 8), 128, 16)])
+def test_blocksparse_paged_attention(gpu_device, version, kv_cache_dtype, sliding, num_heads, head_size, block_size):
+    """the reference's parameter grid (tests/kernels/test_blocksparse_attention.py:33-45: 16 local blocks, vertical
+    stride 8, sparsity blocks of 64 tokens, head sliding 0 / 2 / -1) against the Python checker; contexts long
+    enough that whole 64-token windows and whole v2 partitions are masked for some heads"""
+    sparse = dict(tp_rank=0, local_blocks=16, vert_stride=8, block_size=64, head_sliding_step=sliding)
+    inp = helpers.make_paged_attention_inputs(5, 3, num_heads, head_size, block_size, torch.bfloat16,
+                                              seq_lens=[3000, 1100, 70], num_blocks=512,
+                                              kv_cache_dtype=kv_cache_dtype)
+    kv_scale = 0.5 if kv_cache_dtype == "fp8" else 1.0
+    ref = helpers.ref_paged_attention_torch(inp, kv_scale=kv_scale, blocksparse=sparse)
+    out, _ = run_hip(inp, version, gpu_device, kv_cache_dtype=kv_cache_dtype, kv_scale=kv_scale, sparse=sparse)
+    check(out, ref, atol=2e-3 if kv_cache_dtype == "fp8" else 1e-3, rtol=1e-2)
+    # a small local window: most of a long context is masked, for some heads whole partitions
+    sparse2 = dict(tp_rank=1, local_blocks=1, vert_stride=16, block_size=64, head_sliding_step=sliding)
+    ref2 = helpers.ref_paged_attention_torch(inp, kv_scale=kv_scale, blocksparse=sparse2)
+    out2, _ = run_hip(inp, version, gpu_device, kv_cache_dtype=kv_cache_dtype, kv_scale=kv_scale, sparse=sparse2)
+    check(out2, ref2, atol=2e-3 if kv_cache_dtype == "fp8" else 1e-3, rtol=1e-2)
 
 
 def test_unsupported_configs_raise(gpu_device):

@@ -181,3 +181,34 @@ def test_ref_llama_pinned_to_reference_model(case):
             if float(g["top2_margin"][s][b]) > 4 * float((logits - want).abs().max()):
                 assert int(logits.argmax()) == int(tokens[s][b]), (case, b, s)
             seq.append(int(tokens[s][b]))   # teacher forcing with the reference's tokens
+
+
+BSA_NAMES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLD, "bsa_*.npz")))
+
+
+def bsa_case(name):
+    """inputs (seeded recipe), sparse parameters and the output of the reference's own checker
+    (tools/make_golden_blocksparse.py: ref_single_query_cached_kv_attention of
+    tests/kernels/test_blocksparse_attention.py executed in place)"""
+    g = gold(name)
+    seed, nseq, nq, nkv, hs, bs, alibi = (int(v) for v in g["recipe"])
+    inp = helpers.make_paged_attention_inputs(seed, nseq, (nq, nkv), hs, bs, BF16,
+                                              seq_lens=[int(v) for v in g["seq_lens"]], num_blocks=256,
+                                              use_alibi=bool(alibi))
+    keys = ("tp_rank", "local_blocks", "vert_stride", "block_size", "head_sliding_step")
+    sparse = dict(zip(keys, (int(v) for v in g["sparse"])))
+    return inp, sparse, torch.from_numpy(g["out"]).float()
+
+
+@pytest.mark.parametrize("name", BSA_NAMES)
+def test_blocksparse_checker_vs_reference(name):
+    """the Python checker of block-sparse paged attention (tests/helpers.py) against the reference test's own"""
+    assert len(BSA_NAMES) == 3
+    inp, sparse, ref = bsa_case(name)
+    out = helpers.ref_paged_attention_torch(inp, blocksparse=sparse)
+    # the reference checker rounds the probabilities and the output to bf16 (measured: max abs 3e-4, mean 0.2 %)
+    assert torch.allclose(out, ref, atol=5e-4, rtol=1e-2), (out - ref).abs().max()
+    assert ((out - ref).abs().mean() / ref.abs().mean()).item() < 1e-2
+    # and the mask does something: the dense result is 30-75 % away
+    dense = helpers.ref_paged_attention_torch(inp)
+    assert ((dense - ref).abs().mean() / ref.abs().mean()).item() > 0.1
