@@ -142,7 +142,11 @@ def gemm_roofline(runner, batch, dev, groups=32):
     kern = "w4a16_gemm_tall_kernel"
     return {"bound": "hbm", "kernel": f"{kern} (the 4 GEMM launches of one decoder layer, M={batch})",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+            "frac": round(achieved / HBM_PEAK_GBS, 4),
+            # HBM bytes per launch group from the PMC counters (null when the committed summary has no entry for
+            # this batch size); the per-projection split is in traffic_detail
+            "traffic": traffic["bytes"] if traffic else None, "traffic_unit": "bytes per launch group",
+            "traffic_detail": traffic,
             "algorithmic_bytes_per_launch_group": alg, "avg_us_per_launch_group": round(us, 2),
             "launches_per_group": 4, "timing": "HIP events around a hipGraph replay", "per_gemm": per,
             "in_model": in_model}
