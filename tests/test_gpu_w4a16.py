@@ -216,6 +216,32 @@ def test_marlin_gemm_linearity(gpu_device):
         assert ref_math.compute_max_diff(c1[:, sl], ref) < 6e-3
 
 
+@pytest.mark.parametrize("m", [1, 64])
+def test_marlin_gemm_full_gate_up(gpu_device, m):
+    """the whole Llama-3-8B gate_up projection (K = 4096, N = 28672: 448 chunks, the widest launch of the decode step)
+    at the bench's batch sizes, every column against the dequantise-then-matmul definition
+    (quantize_weights' w_ref = (q - 8) * s rounded to the model dtype, test_marlin_gemm.py:172-179)"""
+    k, n = 4096, 28672
+    g = torch.Generator().manual_seed(40 + m)
+    q_w = torch.randint(0, 16, (k, n), generator=g, dtype=torch.int32)
+    mq = ref_math.marlin_weights(q_w, k, n, 4)
+    s = (torch.rand((k // 128, n), generator=g) * 0.01 + 0.001).to(torch.bfloat16)
+    ms = ref_math.marlin_permute_scales(s, k, n, 128)
+    a = torch.randn((m, k), generator=g).to(torch.bfloat16)
+    e = torch.empty(0, dtype=torch.int32)
+    c = hip_gemm(dict(a=a, marlin_q_w=mq, marlin_s=ms, g_idx=e, sort_indices=e), m, n, k, 4, gpu_device).float()
+    ref = torch.empty((m, n))
+    for c0 in range(0, n, 4096):   # column slabs keep the dense fp32 weight at 64 MB
+        sl = slice(c0, c0 + 4096)
+        w = ((q_w[:, sl] - 8).float() * s.float().repeat_interleave(128, dim=0)[:, sl]).to(torch.bfloat16).float()
+        ref[:, sl] = a.float() @ w
+    assert ref_math.compute_max_diff(c, ref) < 6e-3
+    # no chunk is off by itself (a wrong chunk would drown in the mean over 28672 columns)
+    per_chunk = ((c - ref).abs().view(m, n // 64, 64).mean(dim=(0, 2)) /
+                 ref.abs().view(m, n // 64, 64).mean(dim=(0, 2)).clamp_min(1e-6))
+    assert per_chunk.max().item() < 3e-2, per_chunk.argmax().item()
+
+
 def test_marlin_gemm_deterministic(gpu_device):
     pr = helpers.make_w4a16_problem(5, 16, 4096, 4096, 4, 128, False, torch.bfloat16)
     c1 = hip_gemm(pr, 16, 4096, 4096, 4, gpu_device)
