@@ -183,6 +183,21 @@ def test_paged_attention_golden(gpu_device, name, version):
     check(out, ref, atol=1e-3, rtol=1e-2)
 
 
+@pytest.mark.parametrize("kv_cache_dtype", ["auto", "fp8"])
+def test_paged_attention_bench_size(gpu_device, kv_cache_dtype):
+    """BASELINE.json configs[2] / [3] at full size: 64 sequences around 512 tokens (ragged: every residue of the
+    4-wave x 64-token window split), Llama-3-8B heads (32 q / 8 kv, D = 128), block 16, against the oracle"""
+    lens = [512 + (i * 7) % 130 for i in range(64)]
+    lens[0], lens[1], lens[2] = 512, 513, 641
+    inp = helpers.make_paged_attention_inputs(9, 64, (32, 8), 128, 16, torch.bfloat16, seq_lens=lens,
+                                              num_blocks=64 * 41 + 8, kv_cache_dtype=kv_cache_dtype)
+    kv_scale = 0.5 if kv_cache_dtype == "fp8" else 1.0
+    ref = run_oracle(inp, kv_cache_dtype=kv_cache_dtype, kv_scale=kv_scale)
+    for version in ("v1", "v2"):
+        out, _ = run_hip(inp, version, gpu_device, kv_cache_dtype=kv_cache_dtype, kv_scale=kv_scale)
+        check(out, ref, atol=2e-3 if kv_cache_dtype == "fp8" else 1e-3, rtol=1e-2)
+
+
 @pytest.mark.parametrize("name", ["bsa_qslide", "bsa_kvslide_alibi", "bsa_homo"])
 @pytest.mark.parametrize("version", ["v1", "v2"])
 def test_blocksparse_paged_attention_golden(gpu_device, name, version):
