@@ -22,6 +22,7 @@
 // Staging and flags are allocated uncached / fine-grained when the runtime allows it.
 #include "common.h"
 
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <array>
@@ -444,6 +445,13 @@ static inline bool ar_two_shot(const ArState* st, int64_t bytes) {
 
 using namespace nmv;
 
+// bound of a flag wait: 2 s, or NMV_CUSTOM_AR_TIMEOUT_MS (rehearsals whose ranks time-share one GPU need more)
+static uint64_t ar_default_spin_ticks() {
+  const char* e = getenv("NMV_CUSTOM_AR_TIMEOUT_MS");
+  const long long ms = e ? atoll(e) : 0;
+  return ms > 0 ? (uint64_t)ms * 100000ull : AR_SPIN_TICKS;   // s_memrealtime: 100 MHz
+}
+
 #define AR_HIP(call)                                                                     \
   do {                                                                                   \
     hipError_t e_ = (call);                                                              \
@@ -463,7 +471,7 @@ extern "C" int nmv_ar_create(void** state_out, int rank, int world, int64_t max_
   ArState* st = new ArState();
   std::memset(st, 0, sizeof(ArState));
   st->rank = rank; st->world = world; st->max_bytes = max_bytes;
-  st->spin_ticks = AR_SPIN_TICKS;
+  st->spin_ticks = ar_default_spin_ticks();
   st->alloc_bytes = sizeof(ArComm) + 4 * (size_t)max_bytes;
   hipError_t e = hipExtMallocWithFlags(&st->base, st->alloc_bytes, hipDeviceMallocUncached);
   if (e != hipSuccess) {
@@ -666,7 +674,7 @@ extern "C" int nmv_car_init(void** state_out, void* meta, void* rank_data, int64
             "init_custom_ar: meta / rank_data missing");
   RegState* st = new RegState();
   st->rank = rank; st->world = world; st->full_link = full_link;
-  st->spin_ticks = AR_SPIN_TICKS;
+  st->spin_ticks = ar_default_spin_ticks();
   st->force_algo = 0;
   st->rd_next = (RegPtrs*)rank_data;
   st->rd_end = st->rd_next + rank_data_bytes / (int64_t)sizeof(RegPtrs);

@@ -30,7 +30,13 @@ def _expected(world, numel, dtype, it):
 def _worker(rank, world, port, q, run_model, algo=0):
     try:
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                          HSA_ENABLE_IPC_MODE_LEGACY="0", NMV_CUSTOM_ALLREDUCE="force")
+                          HSA_ENABLE_IPC_MODE_LEGACY="0", NMV_CUSTOM_ALLREDUCE="force",
+                          # the ranks of this test are processes TIME-SHARING one GPU: a kernel spinning on a peer's
+                          # flag waits for the peer process to be scheduled, which has been seen to take longer than
+                          # the 2 s production bound with four processes (a spurious timeout in the start-up
+                          # self-test disables the communicator; one in a later call poisons its output);
+                          # one process per GPU, the deployment, has no such wait.  Read at creation.
+                          NMV_CUSTOM_AR_TIMEOUT_MS="30000")
         import torch.distributed as dist
         from neural_magic_vllm_amd import _lib
         from neural_magic_vllm_amd import distributed as nd
@@ -43,11 +49,6 @@ def _worker(rank, world, port, q, run_model, algo=0):
         assert car is not None and car.enabled, getattr(car, "disabled_reason", "custom all-reduce not created")
         out = {}
         car.set_algo(algo)   # 0 = the reference's size rule, 2 = every call in the two-shot form
-        # the ranks of this test are processes TIME-SHARING one GPU: a kernel spinning on a peer's flag waits
-        # for the peer process to be scheduled, which has been seen to take longer than the 2 s production
-        # bound with four processes (one spurious timeout -> NaN output in ~10 runs); one process per GPU, the
-        # deployment, has no such wait
-        car.set_timeout_ms(30000)
         if run_model == "timeout":
             # rank 1 skips a call: rank 0's flag wait must run out (bound lowered to 0.3 s), its output must
             # be NaN -- not a sum of stale buffers -- and the error must surface on every rank

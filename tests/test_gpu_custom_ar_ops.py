@@ -34,7 +34,9 @@ def _want(world, numel, dtype, it):
 def _worker(rank, world, port, q):
     try:
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                          HSA_ENABLE_IPC_MODE_LEGACY="0")
+                          HSA_ENABLE_IPC_MODE_LEGACY="0",
+                          # ranks time-sharing one GPU: a longer flag-wait bound than the 2 s of a deployment
+                          NMV_CUSTOM_AR_TIMEOUT_MS="30000")
         import torch.distributed as dist
         import neural_magic_vllm_amd  # noqa: F401  (registers torch.ops._C_custom_ar)
         from neural_magic_vllm_amd import _custom_ops as ops
