@@ -170,11 +170,11 @@ int nmv_gptq_marlin_gemm_silu_mul(void* c, const void* a, const int32_t* b_q_wei
                                   int size_m, int size_n, int size_k, int num_groups,
                                   nmv_dtype_t dtype, void* stream);
 /* Deferred split-K reduction: nmv_gptq_marlin_gemm_partial stores the fp32
- * partial tiles slab[splits, size_m, size_n] (splits = nmv_gptq_marlin_gemm_partial_splits(m, n, k),
- * 0 = shape not supported) and skips the ticket / last-arriver pass; the consumer sums the slabs in
+ * partial tiles slab[splits, size_m, size_n] (splits = nmv_gptq_marlin_gemm_partial_splits(m, n, k, num_groups),
+ * num_groups = rows of b_scales; 0 = shape not supported) and skips the ticket / last-arriver pass; the consumer sums the slabs in
  * split order and rounds to the model dtype, bit-identical to nmv_gptq_marlin_gemm's own output.
  * 4-bit symmetric codes, group 128 or channelwise, no act-order, K % 256 == 0. */
-int nmv_gptq_marlin_gemm_partial_splits(int size_m, int size_n, int size_k);
+int nmv_gptq_marlin_gemm_partial_splits(int size_m, int size_n, int size_k, int num_groups);
 int nmv_gptq_marlin_gemm_partial(float* slab, int64_t slab_bytes, const void* a,
                                  const int32_t* b_q_weight, const void* b_scales, int size_m,
                                  int size_n, int size_k, int num_groups, nmv_dtype_t dtype,

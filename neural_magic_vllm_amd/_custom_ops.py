@@ -400,9 +400,9 @@ def w4_native_gemm(a: torch.Tensor, b_native: torch.Tensor, scales: torch.Tensor
     return tb.w4_native_gemm(a, b_native, scales, workspace, size_m, size_n, size_k, mode)
 
 
-def gptq_marlin_gemm_partial_splits(size_m: int, size_n: int, size_k: int) -> int:
+def gptq_marlin_gemm_partial_splits(size_m: int, size_n: int, size_k: int, num_groups=None) -> int:
     from neural_magic_vllm_amd import _torch_bindings as tb
-    return tb.gptq_marlin_gemm_partial_splits(size_m, size_n, size_k)
+    return tb.gptq_marlin_gemm_partial_splits(size_m, size_n, size_k, num_groups)
 
 
 def gptq_marlin_gemm_partial(a: torch.Tensor, b_q_weight: torch.Tensor, b_scales: torch.Tensor,

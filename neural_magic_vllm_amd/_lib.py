@@ -28,6 +28,7 @@ class NmvError(RuntimeError):
 
 
 _lib: Optional[ctypes.CDLL] = None
+ABI_VERSION = 2   # nmv_abi_version() of the library this table describes (csrc/capi_common.hip)
 
 _P = c_void_p
 _I = c_int
@@ -57,7 +58,7 @@ SIGNATURES = {
     "nmv_rotary_embedding_and_cache": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _L, _L, _L, _P, _I, _P, _P,
                                             _P, _I, _I, _I, _F, _P]),
     "nmv_gptq_marlin_gemm_silu_mul": (_I, [_P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _P]),
-    "nmv_gptq_marlin_gemm_partial_splits": (_I, [_I, _I, _I]),
+    "nmv_gptq_marlin_gemm_partial_splits": (_I, [_I, _I, _I, _I]),
     "nmv_gptq_marlin_gemm_partial": (_I, [_P, _L, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "nmv_fused_add_rms_norm_partial": (_I, [_P, _P, _I, _P, _P, _F, _I, _I, _I, _P]),
     "nmv_rotary_embedding_and_cache_partial": (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _I, _I,
@@ -142,6 +143,11 @@ def load() -> ctypes.CDLL:
         fn = getattr(lib, name)  # AttributeError if the .so is stale
         fn.restype = res
         fn.argtypes = args
+    # a stale build that still exports every symbol would be called with shifted arguments: refuse it
+    got = lib.nmv_abi_version()
+    if got != ABI_VERSION:
+        raise ImportError(f"{LIB_PATH} has C ABI version {got}, this package needs {ABI_VERSION}: rebuild it "
+                          "(`make -C neural_magic_vllm_amd/csrc`)")
     _lib = lib
     return lib
 

@@ -727,8 +727,11 @@ def w4_native_gemm(a, b_native, scales, workspace, size_m, size_n, size_k, mode=
     return out
 
 
-def gptq_marlin_gemm_partial_splits(size_m, size_n, size_k) -> int:
-    return int(_lib.load().nmv_gptq_marlin_gemm_partial_splits(size_m, size_n, size_k))
+def gptq_marlin_gemm_partial_splits(size_m, size_n, size_k, num_groups=None) -> int:
+    """slab count of gptq_marlin_gemm_partial (0: unsupported); num_groups = rows of b_scales (default: group 128)"""
+    if num_groups is None:
+        num_groups = max(size_k // 128, 1)
+    return int(_lib.load().nmv_gptq_marlin_gemm_partial_splits(size_m, size_n, size_k, num_groups))
 
 
 def gptq_marlin_gemm_partial(a, b_q_weight, b_scales, size_m, size_n, size_k) -> torch.Tensor:
@@ -740,7 +743,7 @@ def gptq_marlin_gemm_partial(a, b_q_weight, b_scales, size_m, size_n, size_k) ->
     _req(b_scales.dtype == a.dtype and b_scales.is_contiguous() and b_scales.shape[1] == size_n,
          "gemm_partial: scales must be [groups, N] in A's dtype")
     lib = _lib.load()
-    splits = lib.nmv_gptq_marlin_gemm_partial_splits(size_m, size_n, size_k)
+    splits = lib.nmv_gptq_marlin_gemm_partial_splits(size_m, size_n, size_k, b_scales.shape[0])
     _req(splits >= 1, "gemm_partial: shape not supported")
     slab = torch.empty((splits, size_m, size_n), dtype=torch.float32, device=a.device)
     with device_guard(a):
