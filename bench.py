@@ -10,7 +10,7 @@ replayed from a captured hipGraph; inputs (weights, KV cache with `context` toke
 sequence) are resident in HBM before the timed region.
 
 Extra objects on the line:
-  roofline     -- dominant kernel = the W4A16 GEMM (w4a16_gemm_tall_kernel): algorithmic bytes of
+  roofline     -- dominant kernel = the W4A16 GEMM (w4a16_stream_kernel at M <= 64): algorithmic bytes of
                   the 4 GEMMs of a layer / mean device time of those 4 launches, measured live with
                   HIP events around a hipGraph replay of the same kernels (no host launch cost).
   ttft_ms_p50  -- p50 wall time of one 512-token prompt step (BASELINE metric's second half).
@@ -139,7 +139,7 @@ def gemm_roofline(runner, batch, dev, groups=32):
         with open(tpath) as f:
             t = json.load(f)
         traffic = t.get("by_batch", {}).get(str(batch))
-    kern = "w4a16_gemm_tall_kernel"
+    kern = "w4a16_stream_kernel" if os.environ.get("NMV_W4S", "1") != "0" and batch <= 64 else "w4a16_gemm_tall_kernel"
     return {"bound": "hbm", "kernel": f"{kern} (the 4 GEMM launches of one decoder layer, M={batch})",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4),

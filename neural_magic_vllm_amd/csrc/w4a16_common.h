@@ -186,7 +186,8 @@ struct W4StreamPlan {
   int lds_bytes;
 };
 // false: the shape is outside the kernel's domain (the caller takes the tall kernel)
-bool w4s_make_plan(int M, int N, int K, int64_t tickets_len, bool unsplit, W4StreamPlan* out);
+// deferred: the launch leaves its split-K slabs to the next one (nmv_gptq_marlin_gemm_partial)
+bool w4s_make_plan(int M, int N, int K, int64_t tickets_len, bool unsplit, bool deferred, W4StreamPlan* out);
 int w4s_launch(const W4StreamPlan& pl, const GemmParams& p, bool f16, hipStream_t s);
 
 }  // namespace nmv

@@ -1408,7 +1408,8 @@ extern "C" int64_t nmv_gptq_marlin_gemm_scratch_bytes(int size_m, int size_n, in
   // the resident / streamed-activation kernel (w4a16_stream.hip) takes group-128 4-bit launches of up to 64 rows
   if (!has_act_order) {
     W4StreamPlan sp;
-    if (w4s_make_plan(size_m, size_n, size_k, INT64_MAX, false, &sp)) max_splits = std::max(max_splits, sp.splits);
+    if (w4s_make_plan(size_m, size_n, size_k, INT64_MAX, false, false, &sp)) max_splits = std::max(max_splits, sp.splits);
+    if (w4s_make_plan(size_m, size_n, size_k, INT64_MAX, false, true, &sp)) max_splits = std::max(max_splits, sp.splits);
   }
   // ... and of the generic kernel that takes the remaining variants (8-bit groups of 32 / 64, act-order on a K
   // shard): its gathered activations + slabs
@@ -1463,7 +1464,7 @@ static int marlin_gemm_impl(void* c, const void* a, const int32_t* b_q_weight, c
   // decode batches of the prevalent format (4-bit symmetric, group 128, no act-order): w4a16_stream.hip
   if (num_bits == 4 && !has_act_order && group_size == 128 && b_zeros == nullptr && !native) {
     W4StreamPlan sp;
-    if (w4s_make_plan(size_m, size_n, size_k, epi == 2 ? INT64_MAX : (workspace ? workspace_len : 0), epi == 1, &sp) &&
+    if (w4s_make_plan(size_m, size_n, size_k, epi == 2 ? INT64_MAX : (workspace ? workspace_len : 0), epi == 1, epi == 2, &sp) &&
         (epi != 1 || (sp.splits == 1 && size_n % 128 == 0))) {
       const int64_t need = (sp.splits > 1 || epi == 2) ? (int64_t)sp.splits * size_m * size_n * 4 : 0;
       NMV_CHECK(need < (int64_t)1 << 31, "gptq_marlin_gemm: split-K slab too large");
@@ -1565,7 +1566,7 @@ extern "C" int nmv_gptq_marlin_gemm_partial_splits(int size_m, int size_n, int s
   if (size_m <= 0 || size_n <= 0 || size_k <= 0 || size_n % 64 != 0 || size_k % 256 != 0) return 0;
   // the plan (and with it the slab count) depends on the grouping: group 128 takes w4a16_stream.hip
   W4StreamPlan sp;
-  if (num_groups > 1 && size_k / num_groups == 128 && w4s_make_plan(size_m, size_n, size_k, INT64_MAX, false, &sp))
+  if (num_groups > 1 && size_k / num_groups == 128 && w4s_make_plan(size_m, size_n, size_k, INT64_MAX, false, true, &sp))
     return sp.splits;
   const GemmPlan pl = make_plan(size_m, size_n, size_k, INT64_MAX, true, 4, false);
   return pl.tall ? pl.splits : 0;

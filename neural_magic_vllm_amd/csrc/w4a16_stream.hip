@@ -25,6 +25,8 @@
 //     fma per accumulator element and group:  acc += s[group, n] * acc_group.
 // The epilogue forms (model-dtype store, silu(gate) * up, fp32 slabs + ticket + last-arriver sum, deferred slabs)
 // are those of the tall kernel, bit-compatible with its consumers (slabs are summed in split order from +0).
+#include <climits>
+#include <cstdlib>
 #include <type_traits>
 
 #include "common.h"
@@ -636,53 +638,67 @@ static int env_i(const char* name, int dflt) {
   return v ? atoi(v) : dflt;
 }
 
-bool w4s_make_plan(int M, int N, int K, int64_t tickets_len, bool unsplit, W4StreamPlan* out) {
+// Plan (defaults from tools/sweep_stream.py on MI355X in the forms the decode step issues -- deferred reduction for
+// qkv / o / down, silu epilogue for gate_up -- profiles/r03_sweep_stream.txt; NMV_W4S_* override every choice):
+//   wide launches (>= 224 column chunks): one k range per workgroup, no split-K.  M <= 16: 8 waves = 2 chunks x
+//     4 k groups, all of K resident in LDS, ring 2 groups deep; M <= 32: 32-row tile, activations streamed in 256-k
+//     stages; M <= 64: 64-row tile, 128-k stages;
+//   narrow launches: split-K to about 256 workgroups, activations resident.  M <= 16: 4 waves = 2 chunks x 2 k
+//     groups (several workgroups per CU overlap each other's prologue and epilogue); M > 16: 32-row tiles (two row
+//     blocks at M = 64: the second reads the weights from L2), 8 waves = 2 (M <= 32) or 4 chunks per workgroup.
+bool w4s_make_plan(int M, int N, int K, int64_t tickets_len, bool unsplit, bool deferred, W4StreamPlan* out) {
   if (!env_i("NMV_W4S", 1)) return false;
   if (M <= 0 || M > env_i("NMV_W4S_MAX_M", 64) || N % 64 != 0 || K % 128 != 0) return false;
   W4StreamPlan pl;
   const int n_chunks = N / 64, groups = K / 128;
-  const int mt = env_i("NMV_W4S_MT", M <= 16 ? 1 : M <= 32 ? 2 : 4);
+  const bool wide = n_chunks >= 224;
+  // a self-contained narrow launch pays for every split in its own last-arriver pass: 16-row tiles (row blocks
+  // instead of split-K: the later ones read the weights from L2), one chunk x 8 k groups per workgroup, and only
+  // as many splits as LDS demands (K <= 4096: none); the deferred form leaves the slabs to the next launch
+  // (measured -- profiles/r03_sweep_stream.txt -- but OFF by default, NMV_W4S_SOLO=1: a plan that depends on the
+  // mode would break the bit-identity of gemm_partial + consumer with the self-contained op)
+  const bool solo = !wide && !deferred && K <= 8192 && env_i("NMV_W4S_SOLO", 0);
+  const int mt = env_i("NMV_W4S_MT", (M <= 16 || solo) ? 1 : (M <= 32 || !wide) ? 2 : 4);
   if (mt != 1 && mt != 2 && mt != 4) return false;
   pl.mt = mt;
   const int mp = 16 * mt;
   pl.m_blocks = (M + mp - 1) / mp;
-  pl.nw = env_i("NMV_W4S_NW", 8);
-  const int tiles = n_chunks * pl.m_blocks;
-  // MT = 4: activations streamed in 128-k stages (64 rows x the whole k range do not fit in LDS);
-  // MT = 1, 2: the k range of a workgroup stays in LDS (<= 128 KiB of activations)
-  const int gst = env_i("NMV_W4S_GST", mt == 4 ? 1 : 0);
-  const int cpw = env_i("NMV_W4S_CPW", (mt == 4 || tiles >= 384) ? 2 : 1);
+  pl.nw = env_i("NMV_W4S_NW", (!wide && mt == 1 && !solo) ? 4 : 8);
+  const int gst = env_i("NMV_W4S_GST", !wide ? 0 : mt == 4 ? 1 : mt == 2 ? 2 : 0);
+  const int cpw = env_i("NMV_W4S_CPW", solo ? 1 : (!wide && mt == 2 && M > 32) ? 4 : 2);
   if (cpw != 1 && cpw != 2 && cpw != 4) return false;
   if (pl.nw != 4 && pl.nw != 8 && pl.nw != 16) return false;
   if (pl.nw % cpw != 0) return false;
   const int P = pl.nw / cpw;
   pl.cpw = cpw;
   pl.gst = gst;
-  pl.d = env_i("NMV_W4S_D", gst == 0 ? 3 : 1);
+  pl.d = env_i("NMV_W4S_D", gst != 0 ? 1 : (wide || solo) ? 2 : 3);
   if (gst != 0 && gst % pl.d != 0) return false;
   pl.n_blocks = (n_chunks + cpw - 1) / cpw;
   const int base_wgs = pl.n_blocks * pl.m_blocks;
-  // groups per workgroup: a divisor of the group count, whole k groups (and whole stage pairs when streamed),
-  // activations within LDS when resident; among those the fewest splits that reach the target workgroup count
-  const int unit = gst == 0 ? P : P * gst * 2;
+  // groups per workgroup: a divisor of the group count, whole k groups (and whole stages when streamed), activations
+  // within LDS and within the prologue's staging capacity when resident; among those the split count whose workgroup
+  // count is closest to the target (wide launches: no split)
+  const int unit = gst == 0 ? P : P * gst;
   const int max_g_wg = gst == 0 ? (128 * 1024) / (mp * 256) : groups;
-  const int target = env_i("NMV_W4S_WGS", 192);
-  const int forced = unsplit ? 1 : env_i("NMV_W4S_SPLITS", 0);
+  const int target = env_i("NMV_W4S_WGS", solo ? 1 : 256);
+  const int forced = (unsplit || wide) ? (unsplit ? 1 : env_i("NMV_W4S_SPLITS", 1)) : env_i("NMV_W4S_SPLITS", 0);
   int rows_pad = 1;
   while (rows_pad < std::min(mp, M)) rows_pad *= 2;
-  int best_splits = 0;
+  const int nthr = pl.nw * 64;
+  int best_splits = 0, best_dist = INT32_MAX;
   for (int splits = 1; splits <= groups; ++splits) {
     if (groups % splits != 0) continue;
     const int g_wg = groups / splits;
     if (g_wg % unit != 0 || g_wg > max_g_wg) continue;
-    if (gst == 0 && g_wg * rows_pad * 4 > std::min(4, max_g_wg * mp * 4 / (pl.nw * 64)) * (pl.nw * 64)) continue;   // staging: <= UB units per thread
+    if (gst == 0 && g_wg * rows_pad * 4 > std::min(4, max_g_wg * mp * 4 / nthr) * nthr) continue;   // staging: <= UB units per thread
     if (splits > 1 && (int64_t)base_wgs > tickets_len) break;
     if (forced) {
       if (splits == forced) { best_splits = splits; break; }
       continue;
     }
-    best_splits = splits;
-    if (base_wgs * splits >= target) break;
+    const int dist = std::abs(base_wgs * splits - target);
+    if (dist < best_dist) { best_dist = dist; best_splits = splits; }
   }
   if (best_splits == 0) return false;
   pl.splits = best_splits;
@@ -730,11 +746,11 @@ static int w4s_launch_t(const W4StreamPlan& pl, const GemmParams& p, hipStream_t
   NMV_W4S_CASE(NMV_W4S_PROBE_CASE)
 #else
   // resident
-  NMV_W4S_CASE(1, 8, 1, 3, 0) NMV_W4S_CASE(1, 8, 2, 3, 0) NMV_W4S_CASE(1, 8, 4, 3, 0)
-  NMV_W4S_CASE(1, 8, 1, 4, 0) NMV_W4S_CASE(1, 8, 2, 4, 0) NMV_W4S_CASE(1, 8, 1, 2, 0) NMV_W4S_CASE(1, 8, 2, 2, 0)
-  NMV_W4S_CASE(1, 4, 1, 3, 0) NMV_W4S_CASE(1, 4, 2, 3, 0)
-  NMV_W4S_CASE(1, 16, 2, 2, 0) NMV_W4S_CASE(1, 16, 4, 2, 0) NMV_W4S_CASE(1, 16, 2, 3, 0) NMV_W4S_CASE(1, 16, 4, 3, 0)
-  NMV_W4S_CASE(2, 8, 1, 3, 0) NMV_W4S_CASE(2, 8, 2, 3, 0) NMV_W4S_CASE(2, 8, 4, 3, 0)
+  NMV_W4S_CASE(1, 8, 2, 2, 0) NMV_W4S_CASE(1, 8, 2, 3, 0) NMV_W4S_CASE(1, 8, 1, 2, 0) NMV_W4S_CASE(1, 8, 1, 3, 0)
+  NMV_W4S_CASE(1, 8, 4, 3, 0)
+  NMV_W4S_CASE(1, 4, 1, 3, 0) NMV_W4S_CASE(1, 4, 2, 3, 0) NMV_W4S_CASE(1, 4, 2, 2, 0)
+  NMV_W4S_CASE(1, 16, 2, 2, 0) NMV_W4S_CASE(1, 16, 4, 2, 0)
+  NMV_W4S_CASE(2, 8, 1, 3, 0) NMV_W4S_CASE(2, 8, 2, 3, 0) NMV_W4S_CASE(2, 8, 4, 3, 0) NMV_W4S_CASE(2, 8, 2, 2, 0)
   // streamed
   NMV_W4S_CASE(4, 8, 2, 1, 1) NMV_W4S_CASE(4, 8, 4, 1, 1)
   NMV_W4S_CASE(2, 8, 2, 2, 2) NMV_W4S_CASE(2, 8, 2, 1, 2) NMV_W4S_CASE(2, 8, 2, 1, 1)

@@ -43,7 +43,7 @@ if __name__ == "__main__":
             mts = [1] if m <= 16 else ([2, 1] if m <= 32 else [4, 2, 1])
             for mt in mts:
                 gsts = [0] if mt == 1 else ([0, 2] if mt == 2 else [1])
-                for gst, nw, cpw, d, sp in itertools.product(gsts, (8, 16, 4), (1, 2, 4), (1, 2, 3, 4), (1, 2, 4, 7, 8)):
+                for gst, nw, cpw, d, sp in itertools.product(gsts, (8, 16, 4), (1, 2, 4), (1, 2, 3), (1, 2, 4, 7, 8, 14)):
                     if gst and (nw != 8 or d > 2):
                         continue
                     if nw == 16 and (mt != 1 or cpw == 1 and d > 3):

@@ -22,7 +22,7 @@ def per_dispatch(path, counter):
     """[(dispatch order, kernel name, value)] for the GEMM kernels, in launch order"""
     rows = []
     for r in csv.DictReader(open(path)):
-        if r["Counter_Name"] != counter or not re.search(r"w4a16_gemm", r["Kernel_Name"]):
+        if r["Counter_Name"] != counter or not re.search(r"w4a16_(gemm|stream)", r["Kernel_Name"]):
             continue
         rows.append((int(r["Dispatch_Id"]), r["Kernel_Name"], float(r["Counter_Value"])))
     rows.sort()
