@@ -275,6 +275,31 @@ def cpu_baseline(arch, batch, context, budget_s=12.0):
                               "note": "oracle.c's clarity-first dequant+GEMM (the parity checker), one call"}}
 
 
+EXIT_CAPTURE_FAILED = 75   # EX_TEMPFAIL: the ranks ask to be restarted with --no-graph
+
+
+def _capture_marker(env) -> str:
+    """file a rank leaves behind when it exits because of a failed capture (torch.distributed.run does not pass the
+    workers' exit code through); the parent of launch_ranks() names it through the environment"""
+    return env.get("NMV_BENCH_CAPTURE_MARKER", "")
+
+
+def weights_fit(arch, quant: str, world: int, batch: int, max_context: int, kv_dtype: str) -> dict:
+    """bytes one rank holds for `arch` under tensor parallelism `world`: quantised decoder weights (int4 + group-128
+    scales, int8 + channel scales, or bf16), bf16 embedding / lm_head shards, and the KV cache of `batch` sequences
+    of `max_context` tokens -- against the 288 GB of an MI355X (BASELINE.json configs[4]: Llama-3-70B w4a16 at TP=8
+    is 4.4 GB of weights per rank)"""
+    h, inter, layers = arch.hidden_size, arch.intermediate_size, arch.num_hidden_layers
+    kvh = max(arch.num_key_value_heads // world, 1)
+    qkv = h * (arch.num_attention_heads // world + 2 * kvh) * arch.head_dim
+    per_layer = qkv + (arch.num_attention_heads // world) * arch.head_dim * h + 3 * h * inter // world
+    bytes_per_w = {"w4a16": 0.5 + 2 / 128, "w8a8": 1.0, "bf16": 2.0}[quant]
+    weights = layers * per_layer * bytes_per_w + 2 * (arch.vocab_size // world) * h * 2 + (2 * layers + 1) * h * 2
+    kv = 2 * layers * batch * max_context * kvh * arch.head_dim * (1 if kv_dtype.startswith("fp8") else 2)
+    total = weights + kv
+    return {"weights_gb": weights / 1e9, "kv_gb": kv / 1e9, "total_gb": total / 1e9, "fits": total < 0.9 * 288e9}
+
+
 def _free_port():
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
@@ -287,9 +312,22 @@ def launch_ranks(args) -> int:
     will.  The ranks inherit stdout, so rank 0's JSON line is this command's JSON line."""
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
-           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
-    return subprocess.call(cmd, env=env)
+    env["NMV_BENCH_CAPTURE_MARKER"] = os.path.join("/tmp", f"nmv_bench_capture_failed_{os.getpid()}")
+    if os.path.exists(env["NMV_BENCH_CAPTURE_MARKER"]):
+        os.remove(env["NMV_BENCH_CAPTURE_MARKER"])
+    def cmd(extra):
+        return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+                "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + \
+            sys.argv[1:] + extra
+    rc = subprocess.call(cmd([]), env=env)
+    if rc != 0 and not args.no_graph and os.path.exists(_capture_marker(env)):
+        # a rank's hipGraph capture failed: the ranks agreed, left a marker and exited (they never continue eagerly in
+        # the same processes).  This process has not touched the GPU: start FRESH ranks without the graph.
+        os.remove(_capture_marker(env))
+        print("bench.py: hipGraph capture failed in the tensor-parallel ranks; starting fresh ranks with --no-graph",
+              file=sys.stderr)
+        rc = subprocess.call(cmd(["--no-graph"]), env=env)
+    return rc
 
 
 def main():
@@ -322,7 +360,12 @@ def main():
             dist.init_process_group(backend=backend)
         nd.initialize_model_parallel(world, backend=backend, local_rank=local_rank)
     from neural_magic_vllm_amd.worker import decode_runner as dr
-    arch = {"llama3-8b": dr.LLAMA3_8B, "llama3-70b": dr.LLAMA3_70B, "tiny": dr.TINY}[args.model]
+    arch = {"llama3-8b": dr.LLAMA3_8B, "llama3-70b": dr.LLAMA3_70B, "tiny": dr.TINY, "tiny-70b": dr.TINY_70B}[args.model]
+    fit = weights_fit(arch, args.quant, world, args.batch, args.context + args.steps + args.warmup + 8, args.kv_cache_dtype)
+    if not fit["fits"]:
+        print(f"bench.py: {args.model} {args.quant} at TP={world} needs {fit['total_gb']:.1f} GB per rank "
+              f"(weights {fit['weights_gb']:.1f} + KV {fit['kv_gb']:.1f}), more than the 288 GB of an MI355X", file=sys.stderr)
+        sys.exit(2)
     quant = {"w4a16": dict(method="gptq_marlin", bits=4, group_size=128),
              "w8a8": dict(method="w8a8", bits=8, group_size=-1), "bf16": None}[args.quant]
     runner = dr.DecodeRunner(arch, dev, torch.bfloat16, quant,
@@ -344,7 +387,15 @@ def main():
         runner.fill_context()
         # capture() decides graph-or-eager for the whole group (a step that holds collectives of a
         # non-capturable backend is never offered to the graph) and checks the P2P error word
-        graphed = False if args.no_graph else runner.capture()
+        try:
+            graphed = False if args.no_graph else runner.capture()
+        except dr.CaptureFailedError as e:
+            # agreed by every rank: leave the processes (no eager continuation after a failed capture under TP)
+            print(f"bench.py rank {rank}: {e}", file=sys.stderr, flush=True)
+            marker = _capture_marker(os.environ)
+            if marker and rank == 0:
+                open(marker, "w").close()
+            os._exit(EXIT_CAPTURE_FAILED)
         for _ in range(warmup):
             runner.decode_step()
         torch.cuda.synchronize(dev)
@@ -397,6 +448,24 @@ def main():
         out["sustained"] = {"steps": long_steps, "timed_region_s": round(d2, 4),
                             "value": round(args.batch * long_steps / d2, 1),
                             "ms_per_step": round(d2 / long_steps * 1e3, 4)}
+    out["config"]["weights_gb_per_rank"] = round(fit["weights_gb"], 2)
+    if world > 1:
+        # what a reader needs to audit a multi-GPU line from its own content: how many ranks took part, which
+        # device each one bound, whether its P2P start-up self-test passed, and the collective library's version
+        tp = nd.get_tp_group()
+        car = tp.custom_ar
+        mine = {"rank": rank, "local_rank": local_rank, "device": torch.cuda.current_device(),
+                "device_name": torch.cuda.get_device_name(dev),
+                "p2p_selftest": ("passed" if car is not None else "disabled or failed: process-group collectives")}
+        seen = [None] * world
+        dist.all_gather_object(seen, mine, group=tp.cpu_group)
+        out["config"]["ranks_seen"] = len([x for x in seen if x is not None])
+        out["config"]["ranks"] = seen
+        try:
+            out["config"]["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception as e:   # a build without the binding: say so rather than fail the line
+            out["config"]["rccl_version"] = f"unavailable ({type(e).__name__})"
+        out["config"]["dist_backend"] = backend
     if world > 1:
         # which path carries the row-parallel all-reduces: the P2P kernels over HIP IPC (after their
         # start-up self-test on these devices) or the process group (RCCL)

@@ -155,10 +155,13 @@ class GroupCoordinator:
             self.custom_ar.check_error(collective)
 
     def destroy(self):
+        pending = None
         if getattr(self, "custom_ar", None) is not None:
             try:
                 # a timeout that nobody looked at must not pass silently; peers may already be gone
                 self.custom_ar.check_error(collective=False)
+            except Exception as e:   # finish the teardown first: the process groups must not leak
+                pending = e
             finally:
                 self.custom_ar.close()
                 self.custom_ar = None
@@ -168,6 +171,8 @@ class GroupCoordinator:
         if self.cpu_group is not None:
             dist.destroy_process_group(self.cpu_group)
             self.cpu_group = None
+        if pending is not None:
+            raise pending
 
 
 _TP: Optional[GroupCoordinator] = None

@@ -54,6 +54,31 @@ class LlamaArch:
 LLAMA3_8B = LlamaArch(4096, 14336, 32, 32, 8, 128256)
 LLAMA3_70B = LlamaArch(8192, 28672, 80, 64, 8, 128256)
 TINY = LlamaArch(512, 1024, 2, 8, 2, 2048)
+# the per-rank geometry of Llama-3-70B at TP = 8 (8 query heads + 1 KV head per rank, BASELINE.json configs[4])
+# at TP = 2 and toy widths: what the one-GPU rehearsal of `bench.py --model llama3-70b --gpus 8` runs
+TINY_70B = LlamaArch(1024, 3584, 2, 16, 2, 2048)
+
+
+class CaptureFailedError(RuntimeError):
+    """hipGraph capture of the decode step failed on at least one rank of a tensor-parallel group.  The process
+    must not go on issuing collectives: round 1's SIGSEGV was exactly "capture fails, the process keeps going
+    eagerly".  The caller exits non-zero; a parent that never touched the GPU may start fresh ranks with
+    --no-graph (bench.py does)."""
+
+
+def agree_on_capture(ok: bool, world: int, cpu_group) -> bool:
+    """every rank replays a graph, or none does: gathers the ranks' capture verdicts over the CPU group (no device
+    collective right after a capture).  Raises CaptureFailedError on EVERY rank when any rank's capture failed."""
+    if world <= 1:
+        return ok
+    import torch.distributed as dist
+    flags = [None] * world
+    dist.all_gather_object(flags, bool(ok), group=cpu_group)
+    if not all(flags):
+        bad = [r for r, f in enumerate(flags) if not f]
+        raise CaptureFailedError(f"hipGraph capture of the decode step failed on rank(s) {bad}; a tensor-parallel "
+                                 "group does not continue eagerly in the same processes -- rerun with --no-graph")
+    return True
 
 
 @dataclass
@@ -336,9 +361,18 @@ class DecodeRunner:
         if self.tp_size == 1:
             return True
         tp = get_tp_group()
-        if tp.custom_ar is not None and self.fused_step_tail:
+        if tp.backend == "nccl":
             return True
-        return tp.backend == "nccl"
+        # every collective of THIS step must take the P2P path -- a message it declines (larger than its buffers,
+        # not a multiple of 16 bytes, or the communicator disabled after an error) would fall back to the process
+        # group inside the capture: the [batch, hidden] activations of the row-parallel layers and the sampler's
+        # (value, index) records
+        car = tp.custom_ar
+        if car is None or not self.fused_step_tail or not car.enabled:
+            return False
+        act_bytes = getattr(self, "batch", 1) * self.arch.hidden_size * 2
+        rec_bytes = getattr(self, "batch", 1) * 8
+        return 0 < act_bytes <= car.max_bytes and act_bytes % 16 == 0 and rec_bytes <= car.max_bytes
 
     @torch.inference_mode()
     def capture(self, warmup: int = 2) -> bool:
@@ -364,6 +398,8 @@ class DecodeRunner:
             torch.cuda.synchronize(self.device)
             get_tp_group().barrier()
         try:
+            if os.environ.get("NMV_TEST_FAIL_CAPTURE_RANK") == str(self.tp_rank):   # tests: inject a capture failure
+                raise RuntimeError("injected capture failure (NMV_TEST_FAIL_CAPTURE_RANK)")
             s = torch.cuda.Stream(device=self.device)
             s.wait_stream(prev_stream)
             with torch.cuda.stream(s):
@@ -398,14 +434,14 @@ class DecodeRunner:
             dst.copy_(src)
         torch.cuda.synchronize(self.device)
         if self.tp_size > 1:
-            # every rank replays a graph, or none does (agreed over the CPU group: no device collective
-            # right after a capture), and a P2P flag wait that ran out during the warm-up is fatal
-            flags = [None] * self.tp_size
-            import torch.distributed as dist
-            dist.all_gather_object(flags, bool(ok), group=get_tp_group().cpu_group)
-            if not all(flags):
+            # every rank replays a graph, or none does, and a failed capture is fatal for the whole group (agreed
+            # over the CPU group: no device collective right after a capture); so is a P2P flag wait that ran out
+            # during the warm-up
+            try:
+                agree_on_capture(ok, self.tp_size, get_tp_group().cpu_group)
+            except CaptureFailedError:
                 self.graph = None
-                ok = False
+                raise
             get_tp_group().check_custom_ar_error()
         return ok
 

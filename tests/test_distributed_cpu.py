@@ -125,7 +125,31 @@ def _worker_layers(rank, world, port, q):
         q.put((rank, traceback.format_exc()))
 
 
-@pytest.mark.parametrize("worker", [_worker_comm, _worker_layers], ids=["collectives", "tp_layers"])
+def _worker_capture_failure(rank, world, port, q):
+    """rank 1's hipGraph capture 'fails': the agreement over the CPU group must raise on EVERY rank (no rank goes
+    on eagerly in the same process; round 1's SIGSEGV)"""
+    try:
+        import torch.distributed as dist
+        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+        from neural_magic_vllm_amd.worker.decode_runner import CaptureFailedError, agree_on_capture
+        grp = dist.new_group(list(range(world)), backend="gloo")
+        assert agree_on_capture(True, world, grp) is True            # everybody captured: fine
+        try:
+            agree_on_capture(rank != 1, world, grp)
+            q.put((rank, "no exception"))
+            return
+        except CaptureFailedError as e:
+            assert "rank(s) [1]" in str(e), str(e)
+        assert agree_on_capture(False, 1, None) is False              # TP = 1 keeps its eager fallback
+        dist.destroy_process_group()
+        q.put((rank, "ok"))
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put((rank, traceback.format_exc()))
+
+
+@pytest.mark.parametrize("worker", [_worker_comm, _worker_layers, _worker_capture_failure],
+                         ids=["collectives", "tp_layers", "capture_failure"])
 def test_world_size_2_gloo(worker):
     world = 2
     port = _free_port()

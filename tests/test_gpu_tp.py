@@ -156,3 +156,41 @@ def test_bench_py_starts_its_own_ranks(gpu_device):
     bad = subprocess.run([sys.executable] + _bench_cmd(root, []), env=dict(env, WORLD_SIZE="1", RANK="0"),
                          capture_output=True, text=True, timeout=120)
     assert bad.returncode != 0 and "WORLD_SIZE" in bad.stderr and not bad.stdout.strip()
+
+
+def test_bench_py_llama70b_tp8_geometry_rehearsal(gpu_device):
+    """`bench.py --model llama3-70b --gpus 8` as a tested code path: the same script and launch contract with the
+    TP = 8 per-rank head geometry of Llama-3-70B (8 query heads + 1 KV head per rank) at toy widths and two ranks on
+    this box's one GPU; the line carries what an auditor of a multi-GPU run needs (ranks seen, device per rank, P2P
+    self-test verdict, collective library version, weight bytes per rank)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NMV_BENCH_DIST_BACKEND="gloo", NMV_BENCH_SINGLE_DEVICE="1",
+               NMV_CUSTOM_ALLREDUCE="force", NMV_CUSTOM_AR_TIMEOUT_MS="30000")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(root, "bench.py"),
+           "--gpus", "2", "--steps", "4", "--warmup", "2", "--model", "tiny-70b", "--batch", "4", "--context", "40"]
+    out = _one_json_line(subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600))
+    cfg = out["config"]
+    assert out["n_gpus"] == 2 and cfg["parallelism"] == "tp2" and cfg["hip_graph"] is True
+    assert cfg["ranks_seen"] == 2 and [r["rank"] for r in cfg["ranks"]] == [0, 1]
+    assert all(r["p2p_selftest"] == "passed" and "device_name" in r for r in cfg["ranks"])
+    assert "rccl_version" in cfg and cfg["dist_backend"] == "gloo" and cfg["weights_gb_per_rank"] > 0
+
+
+def test_bench_py_failed_capture_restarts_fresh_ranks(gpu_device):
+    """a hipGraph capture that fails on one rank (injected) is fatal for the whole group -- no rank continues
+    eagerly in the same process -- and the self-launching parent, which never touched the GPU, starts fresh ranks
+    with --no-graph: one JSON line, hip_graph false"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(NMV_BENCH_DIST_BACKEND="gloo", NMV_BENCH_SINGLE_DEVICE="1", NMV_CUSTOM_ALLREDUCE="force",
+               NMV_CUSTOM_AR_TIMEOUT_MS="30000", NMV_TEST_FAIL_CAPTURE_RANK="1")
+    res = subprocess.run([sys.executable] + _bench_cmd(root, ["--no-sweep"]), env=env, capture_output=True, text=True,
+                         timeout=900)
+    out = _one_json_line(res)
+    assert out["config"]["hip_graph"] is False and out["n_gpus"] == 2
+    assert "starting fresh ranks with --no-graph" in res.stderr and "capture of the decode step failed on rank(s) [1]" in res.stderr
