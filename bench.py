@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sweep", action="store_true")
+    ap.add_argument("--e2e", action="store_true",
+                    help="add `e2e`: prompt 512 -> 128 greedy tokens for batch 1..64, 3 + 10 runs (SURVEY 8d); ~1 min more")
     ap.add_argument("--kv-cache-dtype", default="auto")
     ap.add_argument("--quant", default="w4a16", choices=["w4a16", "w8a8", "bf16"],
                     help="w4a16 = the BASELINE metric (configs[2]); w8a8 = configs[3]; bf16 = configs[1] "
@@ -166,6 +168,44 @@ def ttft(runner, dev, prompt_len, runs=5):
         ts.append((time.perf_counter() - t0) * 1e3)
     ts = sorted(ts[1:])
     return round(ts[len(ts) // 2], 3)
+
+
+@torch.inference_mode()
+def e2e_latency(runner, dev, prompt_len=512, output_len=128, batches=(1, 2, 4, 8, 16, 32, 64), warm=3, timed=10):
+    """SURVEY.md section 8(d) / the reference's benchmarks/benchmark_latency.py: `batch` prompts of `prompt_len` tokens,
+    `output_len` greedy tokens each; 3 warm-up + 10 timed runs per batch size.  TTFT = wall time of the prompt step
+    (p50 over the runs); decode tokens/s = batch * (output_len - 1) / (wall time of the output_len - 1 decode steps,
+    replayed from a hipGraph captured once per batch size)."""
+    out = {}
+    for b in batches:
+        runner.setup_batch(b, prompt_len, output_len + 8)
+        graphed = runner.capture()
+        state = [t.clone() for t in (runner.input_ids, runner.positions, runner.seq_lens, runner.slot_mapping)]
+        steps_left = runner._steps_left
+        ttfts, decs = [], []
+        for i in range(warm + timed):
+            for dst, src in zip((runner.input_ids, runner.positions, runner.seq_lens, runner.slot_mapping), state):
+                dst.copy_(src)
+            runner._steps_left = steps_left
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            first = runner.prefill(prompt_len, seed=i)
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            runner.input_ids.copy_(first.view(-1))
+            for _ in range(output_len - 1):
+                runner.decode_step()
+            torch.cuda.synchronize(dev)
+            t2 = time.perf_counter()
+            if i >= warm:
+                ttfts.append((t1 - t0) * 1e3)
+                decs.append(t2 - t1)
+        ttfts.sort()
+        out[str(b)] = {"ttft_ms_p50": round(ttfts[len(ttfts) // 2], 3),
+                       "decode_tokens_per_s": round(b * (output_len - 1) * len(decs) / sum(decs), 1),
+                       "decode_ms_per_step": round(sum(decs) / len(decs) / (output_len - 1) * 1e3, 4),
+                       "hip_graph": graphed, "runs": len(decs)}
+    return {"prompt_len": prompt_len, "output_len": output_len, "warmup_runs": warm, "timed_runs": timed, "by_batch": out}
 
 
 def usable_cores() -> int:
@@ -502,6 +542,8 @@ def main():
     if rank == 0 and world == 1 and not args.no_sweep:
         out["ttft_ms_p50"] = {"prompt_tokens": args.context, "batch": 1,
                               "value": ttft(runner, dev, args.context)}
+    if rank == 0 and world == 1 and args.e2e:
+        out["e2e"] = e2e_latency(runner, dev, prompt_len=args.context)
     if world == 1 and not args.no_sweep:
         sweep = {}
         for b in (1, 8, 32):

@@ -1,16 +1,28 @@
-"""The reference's `CustomAllreduce` communicator (vllm/distributed/device_communicators/custom_all_reduce.py
-:36-276) on the `_C_custom_ar` ops of this package: registered IPC buffers, an eager path that copies into
-the pre-registered buffer (all_reduce_unreg), a graph path that records the graph-private inputs and
-registers them after the capture (capture() -> register_graph_buffers), one-shot / two-shot by size.
+"""`CustomAllreduce`: the communicator class an unmodified engine instantiates on the `_C_custom_ar` ops
+(interface: reference vllm/distributed/device_communicators/custom_all_reduce.py:36-276 -- constructor arguments,
+`disabled`, `capture()`, `custom_all_reduce()` returning None when it declines, `close()`).
 
-This is the drop-in form for an unmodified engine.  The decode harness of this repo uses the staging-buffer
-communicator in ../custom_all_reduce.py instead (fused with residual-add + RMSNorm, no registration step).
+How it works here.  Every rank owns three device tensors: `meta` (the kernel's flag block + the two-shot scratch),
+`buffer` (an IPC-registered staging area for eager calls) and `rank_data` (pointer tables the kernel reads).  A
+registration = "all-gather the IPC handle and offset of one of my tensors, hand the W handles to the kernel
+library".  A call then runs in one of three modes:
+  EAGER     copy the input into `buffer`, reduce out of the peers' buffers            (all_reduce_unreg)
+  WARM-UP   inside `capture()` before the stream records: allocate the output only, so that the allocator sees the
+            pattern the recorded step will have
+  RECORDING inside `capture()` while the stream records: reduce straight out of the peers' INPUT tensors; their
+            addresses are collected by the library and registered when the context closes (register_graph_buffers)
+The decode harness of this repository does not use this class (it has the staging-buffer communicator of
+../custom_all_reduce.py, fused with residual-add + RMSNorm); this is the drop-in form.
 
-Differences from the reference, all forced by the platform: the topology test asks the HIP runtime for peer
-access between every pair of devices (xGMI is a full mesh on an MI355X node) where the reference asks NVML
-for NVLink; IPC handles are carried as latin-1 strings."""
+Platform notes.  Peer reachability comes from the HIP runtime (xGMI is a full mesh inside an MI355X node), not from
+NVML.  IPC handles travel as latin-1 strings.  The flag block lives in ordinary device memory: cross-device
+visibility of the flags relies on the kernels' system-scope release / acquire, and -- unlike the staging
+communicator, whose block is allocated uncached -- HAS ONLY RUN WITH ALL RANKS ON ONE DEVICE so far.  The
+constructor therefore runs a self-test (eager one-shot and two-shot sizes against the rank-order sum computed on the
+CPU, verdict agreed over the group) and disables itself on any mismatch: the caller then keeps the process group."""
+import enum
 from contextlib import contextmanager
-from typing import Any, List, Optional, Union
+from typing import Any, List, Optional, Sequence, Tuple, Union
 
 import torch
 import torch.distributed as dist
@@ -19,13 +31,13 @@ from torch.distributed import ProcessGroup
 from ... import _custom_ops as ops
 
 
-def _full_peer_access(device_ids: List[int]) -> bool:
-    """every pair of the group's devices can map each other's memory (is_full_nvlink, :22-33)"""
-    for i in device_ids:
-        for j in device_ids:
-            if i != j and not torch.cuda.can_device_access_peer(i, j):
-                return False
-    return True
+def _mesh_is_full(devices: Sequence[int]) -> bool:
+    return all(a == b or torch.cuda.can_device_access_peer(a, b) for a in devices for b in devices)
+
+
+class _Mode(enum.Enum):
+    EAGER = 0
+    CAPTURE_CONTEXT = 1     # warm-up or recording, told apart by the stream's state
 
 
 class CustomAllreduce:
@@ -33,100 +45,122 @@ class CustomAllreduce:
     _SUPPORTED_WORLD_SIZES = [2, 4, 6, 8]
 
     def __init__(self, group: ProcessGroup, device: Union[int, str, torch.device], max_size: int = 8192 * 1024) -> None:
-        self._IS_CAPTURING = False
         self.disabled = True
+        self.disabled_reason = "single rank or unsupported world size"
+        self._mode = _Mode.EAGER
+        self._ptr = 0
         self.group = group
         assert dist.get_backend(group) != dist.Backend.NCCL, "CustomAllreduce should be attached to a non-NCCL group."
-        rank = dist.get_rank(group=self.group)
-        world_size = dist.get_world_size(group=self.group)
-        if world_size == 1 or world_size not in self._SUPPORTED_WORLD_SIZES:
+        self.rank, self.world_size = dist.get_rank(group=group), dist.get_world_size(group=group)
+        if self.world_size not in self._SUPPORTED_WORLD_SIZES:
             return
-        if isinstance(device, int):
-            device = torch.device(f"cuda:{device}")
-        elif isinstance(device, str):
-            device = torch.device(device)
-        self.device = device
-        ids: List[Any] = [None] * world_size
-        dist.all_gather_object(ids, device.index, group=self.group)
-        full_link = _full_peer_access([i for i in ids if i is not None])
-        if world_size > 2 and not full_link:
-            return
-        self.disabled = False
-        # synchronisation words + scratch of the two-shot form; the pre-registered eager buffer; pointer tables
-        self.meta = torch.zeros(ops.meta_size() + max_size, dtype=torch.uint8, device=self.device)
-        self.buffer = torch.empty(max_size, dtype=torch.uint8, device=self.device)
-        self.rank_data = torch.empty(8 * 1024 * 1024, dtype=torch.uint8, device=self.device)
+        self.device = torch.device(f"cuda:{device}") if isinstance(device, int) else torch.device(device)
         self.max_size = max_size
-        self.rank = rank
-        self.world_size = world_size
-        self.full_nvlink = full_link
-        torch.cuda.synchronize(self.device)     # meta is zero before any peer maps it
-        handles, offsets = self._get_ipc_meta(self.meta)
-        self._ptr = ops.init_custom_ar(self.meta, self.rank_data, handles, offsets, rank, self.full_nvlink)
+        self.full_nvlink = _mesh_is_full(self._everyones(self.device.index))
+        if self.world_size > 2 and not self.full_nvlink:
+            self.disabled_reason = "no peer access between every pair of devices"
+            return
+        def raw(nbytes: int, zeroed: bool = False) -> torch.Tensor:
+            make = torch.zeros if zeroed else torch.empty
+            return make(nbytes, dtype=torch.uint8, device=self.device)
+
+        self.meta = raw(ops.meta_size() + max_size, zeroed=True)      # flag block + two-shot scratch
+        self.buffer = raw(max_size)                                   # registered staging area of the eager path
+        self.rank_data = raw(8 << 20)                                 # pointer tables
+        torch.cuda.synchronize(self.device)              # the flag block is zero before a peer can map it
+        handles, offsets = self._exchange(self._ipc_of(self.meta))
+        self._ptr = ops.init_custom_ar(self.meta, self.rank_data, handles, offsets, self.rank, self.full_nvlink)
+        self.disabled, self.disabled_reason = False, ""
         self.register_buffer(self.buffer)
+        if not self._self_test():
+            self.disabled = True
 
-    @contextmanager
-    def capture(self):
-        """graph capture: inputs seen inside are recorded and registered when the context ends (:183-197)"""
-        try:
-            self._IS_CAPTURING = True
-            yield
-        finally:
-            self._IS_CAPTURING = False
-            if not self.disabled:
-                self.register_graph_buffers()
+    # ---- IPC plumbing -------------------------------------------------------------------------------------
+    def _everyones(self, mine: Any) -> List[Any]:
+        out: List[Any] = [None] * self.world_size
+        dist.all_gather_object(out, mine, group=self.group)
+        return out
 
-    def _get_ipc_meta(self, inp: torch.Tensor):
-        data = inp.untyped_storage()._share_cuda_()
-        return self._gather_ipc_meta((bytes(data[1]).decode("latin-1"), int(data[3])))
+    @staticmethod
+    def _ipc_of(t: torch.Tensor) -> Tuple[str, int]:
+        shared = t.untyped_storage()._share_cuda_()
+        return bytes(shared[1]).decode("latin-1"), int(shared[3])
 
-    def _gather_ipc_meta(self, shard_data):
-        all_data: List[Any] = [None] * self.world_size
-        dist.all_gather_object(all_data, shard_data, group=self.group)
-        return [d[0] for d in all_data], [d[1] for d in all_data]
+    def _exchange(self, mine: Tuple[Any, Any]) -> Tuple[List[Any], List[Any]]:
+        pairs = self._everyones(mine)
+        return [p[0] for p in pairs], [p[1] for p in pairs]
 
     def register_buffer(self, inp: torch.Tensor):
-        handles, offsets = self._get_ipc_meta(inp)
-        ops.register_buffer(self._ptr, inp, handles, offsets)
+        ops.register_buffer(self._ptr, inp, *self._exchange(self._ipc_of(inp)))
 
     def register_graph_buffers(self):
-        handle, offset = ops.get_graph_buffer_ipc_meta(self._ptr)
-        handles, offsets = self._gather_ipc_meta((bytes(handle.numpy().tobytes()).decode("latin-1"), list(offset)))
-        ops.register_graph_buffers(self._ptr, handles, offsets)
+        handle, offsets = ops.get_graph_buffer_ipc_meta(self._ptr)
+        ops.register_graph_buffers(self._ptr, *self._exchange((bytes(handle.numpy().tobytes()).decode("latin-1"),
+                                                               list(offsets))))
+
+    # ---- start-up self-test (see the module docstring) ------------------------------------------------------
+    def _self_test(self) -> bool:
+        ok = True
+        try:
+            for numel in (2048, 512 * 1024):     # 4 KB: one-shot; 1 MB: two-shot from 4 ranks on
+                g = torch.Generator().manual_seed(1234 + numel)
+                parts = [torch.randn(numel, generator=g).to(torch.bfloat16) for _ in range(self.world_size)]
+                want = torch.stack([p.float() for p in parts]).sum(0).to(torch.bfloat16)    # rank order, one rounding
+                got = self.all_reduce_unreg(parts[self.rank].to(self.device))
+                torch.cuda.synchronize(self.device)
+                ok = ok and torch.equal(got.cpu(), want)
+        except Exception as e:   # a refused mapping, a timeout ...: never fatal, the process group carries on
+            self.disabled_reason = f"self-test raised {type(e).__name__}: {e}"
+            ok = False
+        verdicts = self._everyones(bool(ok))
+        if not all(verdicts):
+            self.disabled_reason = self.disabled_reason or f"self-test mismatch on rank(s) {[r for r, v in enumerate(verdicts) if not v]}"
+            return False
+        return True
+
+    # ---- the reference's public surface -----------------------------------------------------------------------
+    @contextmanager
+    def capture(self):
+        self._mode = _Mode.CAPTURE_CONTEXT
+        try:
+            yield
+        finally:
+            self._mode = _Mode.EAGER
+            if not self.disabled:
+                self.register_graph_buffers()
 
     def should_custom_ar(self, inp: torch.Tensor):
         return ops.should_custom_ar(inp, self.max_size, self.world_size, self.full_nvlink)
 
+    def _reduce(self, inp: torch.Tensor, out: Optional[torch.Tensor], via_staging: bool) -> torch.Tensor:
+        result = out if out is not None else torch.empty_like(inp)
+        if via_staging:
+            ops.all_reduce_unreg(self._ptr, inp, self.buffer, result)
+        else:
+            ops.all_reduce_reg(self._ptr, inp, result)
+        return result
+
     def all_reduce_reg(self, inp: torch.Tensor, out: Optional[torch.Tensor] = None):
-        """inp is IPC-registered (register_buffer, or register_graph_buffers after a capture)"""
-        if out is None:
-            out = torch.empty_like(inp)
-        ops.all_reduce_reg(self._ptr, inp, out)
-        return out
+        """`inp` is registered with the peers (register_buffer, or register_graph_buffers after a capture)"""
+        return self._reduce(inp, out, via_staging=False)
 
     def all_reduce_unreg(self, inp: torch.Tensor, out: Optional[torch.Tensor] = None):
-        if out is None:
-            out = torch.empty_like(inp)
-        ops.all_reduce_unreg(self._ptr, inp, self.buffer, out)
-        return out
+        """any tensor: it is copied into the registered staging buffer first"""
+        return self._reduce(inp, out, via_staging=True)
 
     def custom_all_reduce(self, input: torch.Tensor) -> Optional[torch.Tensor]:
-        """None when the message is not taken (disabled, too large, not 16-byte sized): the caller falls back
-        to the process group (:249-270)"""
-        if self.disabled:
+        """the reduced tensor, or None when this communicator does not take the message (disabled, too large, not a
+        multiple of 16 bytes): the caller then uses the process group"""
+        if self.disabled or not self.should_custom_ar(input):
             return None
-        if self._IS_CAPTURING:
-            if torch.cuda.is_current_stream_capturing():
-                if self.should_custom_ar(input):
-                    return self.all_reduce_reg(input)
-            elif self.should_custom_ar(input):
-                return torch.empty_like(input)    # warm-up: mimic the allocation pattern
-        elif self.should_custom_ar(input):
+        if self._mode is _Mode.EAGER:
             return self.all_reduce_unreg(input)
-        return None
+        if torch.cuda.is_current_stream_capturing():
+            return self.all_reduce_reg(input)
+        return torch.empty_like(input)           # warm-up inside capture(): the allocation pattern only
 
     def close(self):
-        if not self.disabled and getattr(self, "_ptr", 0):
+        if self._ptr:
             ops.dispose(self._ptr)
             self._ptr = 0
 

@@ -29,24 +29,71 @@ def divide(numerator: int, denominator: int) -> int:
     return numerator // denominator
 
 
-def adjust_marlin_shard(param, shard_size, shard_offset):
-    marlin_tile_size = getattr(param, "marlin_tile_size", None)
-    if marlin_tile_size is None:
-        return shard_size, shard_offset
-    return shard_size * marlin_tile_size, shard_offset * marlin_tile_size
+# ---- checkpoint tensors -> (fused, sharded, maybe packed) parameters ------------------------------------
+# Every parallel linear describes its parameter's output dimension as a list of LOGICAL shards (one for a
+# plain layer, gate | up for the merged MLP projection, q | k | v for attention) and loads through ONE routine,
+# `_place`.  A parameter states its own geometry through attributes set by the quantisation method
+# (reference contract, linear.py:29-66, 268-287, 404-491, 567-699, 765-782): output_dim / input_dim, packed_dim +
+# pack_factor (several logical columns per stored element), marlin_tile_size (a Marlin tensor stores tile_size
+# logical columns per unit of its packed dimension the other way round), needs_scalar_to_array (one scalar per
+# logical shard of a fused module).
+class _Shard:
+    """one logical sub-matrix of a fused output dimension: where it sits in this rank's parameter (`local`), in
+    the un-sharded checkpoint tensor (`whole`), and which slice of a per-matrix checkpoint tensor this rank takes
+    (`source`: the rank, or the KV-head group when KV heads are replicated)"""
+    __slots__ = ("key", "index", "local_offset", "local_size", "whole_offset", "whole_size", "source")
+
+    def __init__(self, key, index, local_offset, local_size, whole_offset, whole_size, source):
+        self.key, self.index = key, index
+        self.local_offset, self.local_size = local_offset, local_size
+        self.whole_offset, self.whole_size = whole_offset, whole_size
+        self.source = source
 
 
-def adjust_scalar_to_fused_array(param, loaded_weight, shard_id):
-    """per-shard scalar scales of fused QKV / MLP modules (linear.py:49-66)"""
-    qkv_idxs = {"q": 0, "k": 1, "v": 2}
-    if isinstance(shard_id, str):
-        shard_id = qkv_idxs[shard_id]
-    elif not isinstance(shard_id, int):
-        raise ValueError(f"Unknown Shard Id {shard_id}")
-    if len(loaded_weight.shape) != 0:
-        assert loaded_weight.shape[0] == 1
-        loaded_weight = loaded_weight[0]
-    return param[shard_id], loaded_weight
+def _stored_units(param, columns: int) -> int:
+    """logical output columns -> units of the parameter's output dimension"""
+    if getattr(param, "packed_dim", None) == getattr(param, "output_dim", None):
+        columns //= param.pack_factor
+        tile = getattr(param, "marlin_tile_size", None)
+        if tile is not None:
+            columns *= tile
+    return columns
+
+
+def _copy_checked(dst: torch.Tensor, src: torch.Tensor) -> None:
+    if src.dim() == 0:
+        src = src.reshape(1)
+    assert dst.shape == src.shape, f"checkpoint tensor {tuple(src.shape)} does not fit parameter {tuple(dst.shape)}"
+    dst.copy_(src)
+
+
+def _place(param: Parameter, loaded: torch.Tensor, shard: "_Shard") -> None:
+    """one per-matrix checkpoint tensor (q_proj.weight, gate_proj.qweight, a scalar weight_scale ...) into its
+    place in the fused parameter"""
+    axis = getattr(param, "output_dim", None)
+    if axis is not None:
+        size = _stored_units(param, shard.local_size)
+        dst = param.data.narrow(axis, _stored_units(param, shard.local_offset), size)
+        _copy_checked(dst, loaded.narrow(axis, shard.source * size, size))
+    elif getattr(param, "needs_scalar_to_array", None) is not None:
+        if loaded.dim() != 0:            # [1] -> scalar
+            assert loaded.shape[0] == 1
+            loaded = loaded[0]
+        _copy_checked(param.data[shard.index], loaded)
+    else:
+        _copy_checked(param.data, loaded)
+
+
+def _place_fused(layer, param: Parameter, loaded: torch.Tensor, shards) -> None:
+    """an already-fused checkpoint tensor (qkv_proj / gate_up_proj saved as one): cut it at the shards' positions
+    in the WHOLE output dimension and place the pieces one by one"""
+    axis = getattr(param, "output_dim", None)
+    if axis is None:
+        _copy_checked(param.data, loaded)
+        return
+    for sh in shards:
+        piece = loaded.narrow(axis, _stored_units(param, sh.whole_offset), _stored_units(param, sh.whole_size))
+        layer.weight_loader(param, piece, sh.key)
 
 
 class UnquantizedLinearMethod(LinearMethodBase):
@@ -72,21 +119,30 @@ class UnquantizedLinearMethod(LinearMethodBase):
 
 
 class LinearBase(torch.nn.Module):
+    """common state of every linear layer: sizes, dtype, and the quantisation method that owns the weights
+    (quant_config.get_quant_method(self); the plain library GEMM without a config)"""
 
     def __init__(self, input_size: int, output_size: int, skip_bias_add: bool = False,
                  params_dtype: Optional[torch.dtype] = None,
                  quant_config: Optional[QuantizationConfig] = None):
         super().__init__()
-        self.input_size = input_size
-        self.output_size = output_size
+        self.input_size, self.output_size = input_size, output_size
         self.skip_bias_add = skip_bias_add
-        if params_dtype is None:
-            params_dtype = torch.get_default_dtype()
-        self.params_dtype = params_dtype
-        if quant_config is None:
-            self.quant_method: Optional[QuantizeMethodBase] = UnquantizedLinearMethod()
-        else:
-            self.quant_method = quant_config.get_quant_method(self)
+        self.params_dtype = params_dtype if params_dtype is not None else torch.get_default_dtype()
+        self.quant_method: Optional[QuantizeMethodBase] = (
+            UnquantizedLinearMethod() if quant_config is None else quant_config.get_quant_method(self))
+
+    def _own_bias(self, wanted: bool, width: int, loader=None) -> None:
+        """`bias` [width] in the model dtype (sharded like the output dimension), or a registered None"""
+        if not wanted:
+            self.register_parameter("bias", None)
+            return
+        self.bias = Parameter(torch.empty(width, dtype=self.params_dtype))
+        set_weight_attrs(self.bias, {"output_dim": 0} if loader is None else {"output_dim": 0, "weight_loader": loader})
+
+    def _split_bias(self):
+        """(bias for the GEMM epilogue, bias handed back to the caller) under skip_bias_add"""
+        return (None, self.bias) if self.skip_bias_add else (self.bias, None)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         raise NotImplementedError
@@ -98,18 +154,12 @@ class ReplicatedLinear(LinearBase):
                  quant_config=None):
         super().__init__(input_size, output_size, skip_bias_add, params_dtype, quant_config)
         assert self.quant_method is not None
-        self.quant_method.create_weights(self, self.input_size, [self.output_size],
-                                         self.input_size, self.output_size, self.params_dtype)
-        if bias:
-            self.bias = Parameter(torch.empty(self.output_size, dtype=self.params_dtype))
-            set_weight_attrs(self.bias, {"output_dim": 0})
-        else:
-            self.register_parameter("bias", None)
+        self.quant_method.create_weights(self, input_size, [output_size], input_size, output_size, self.params_dtype)
+        self._own_bias(bias, output_size)
 
     def forward(self, x):
-        bias = self.bias if not self.skip_bias_add else None
-        output = self.quant_method.apply(self, x, bias)
-        return output, (self.bias if self.skip_bias_add else None)
+        fused_bias, returned_bias = self._split_bias()
+        return self.quant_method.apply(self, x, fused_bias), returned_bias
 
 
 class ColumnParallelLinear(LinearBase):
@@ -119,35 +169,20 @@ class ColumnParallelLinear(LinearBase):
                  skip_bias_add=False, params_dtype=None, quant_config=None,
                  output_sizes: Optional[List[int]] = None):
         super().__init__(input_size, output_size, skip_bias_add, params_dtype, quant_config)
-        self.gather_output = gather_output
-        tp_size = get_tensor_model_parallel_world_size()
         assert self.quant_method is not None
-        self.output_size_per_partition = divide(self.output_size, tp_size)
-        self.output_partition_sizes = [self.output_size_per_partition]
-        if hasattr(self, "output_sizes"):
-            self.output_partition_sizes = [divide(s, tp_size) for s in self.output_sizes]
-        if output_sizes is None:
-            output_sizes = [output_size]
-        self.quant_method.create_weights(self, self.input_size, self.output_partition_sizes,
-                                         self.input_size, self.output_size, self.params_dtype,
-                                         weight_loader=self.weight_loader)
-        if bias:
-            self.bias = Parameter(torch.empty(self.output_size_per_partition, dtype=params_dtype))
-            set_weight_attrs(self.bias, {"output_dim": 0, "weight_loader": self.weight_loader})
-        else:
-            self.register_parameter("bias", None)
+        self.gather_output = gather_output
+        tp = get_tensor_model_parallel_world_size()
+        # a fused subclass has set self.output_sizes (the logical matrices) before calling up
+        logical = getattr(self, "output_sizes", None) or [self.output_size]
+        self.output_partition_sizes = [divide(n, tp) for n in logical]
+        self.output_size_per_partition = divide(self.output_size, tp)
+        self.quant_method.create_weights(self, self.input_size, self.output_partition_sizes, self.input_size,
+                                         self.output_size, self.params_dtype, weight_loader=self.weight_loader)
+        self._own_bias(bias, self.output_size_per_partition, self.weight_loader)
 
     def weight_loader(self, param: Parameter, loaded_weight: torch.Tensor):
-        tp_rank = get_tensor_model_parallel_rank()
-        output_dim = getattr(param, "output_dim", None)
-        param_data = param.data
-        if output_dim is not None:
-            shard_size = param_data.shape[output_dim]
-            loaded_weight = loaded_weight.narrow(output_dim, tp_rank * shard_size, shard_size)
-        if len(loaded_weight.shape) == 0:
-            loaded_weight = loaded_weight.reshape(1)
-        assert param_data.shape == loaded_weight.shape
-        param_data.copy_(loaded_weight)
+        width = self.output_size_per_partition
+        _place(param, loaded_weight, _Shard(None, 0, 0, width, 0, self.output_size, get_tensor_model_parallel_rank()))
 
     def forward_partial(self, input_):
         """Deferred split-K (not in the reference): the fp32 slabs [splits, T, N_partition] of X A for
@@ -163,11 +198,9 @@ class ColumnParallelLinear(LinearBase):
         return qm.apply_partial(self, input_)
 
     def forward(self, input_):
-        bias = self.bias if not self.skip_bias_add else None
-        output_parallel = self.quant_method.apply(self, input_, bias)
-        output = tensor_model_parallel_all_gather(output_parallel) if self.gather_output \
-            else output_parallel
-        return output, (self.bias if self.skip_bias_add else None)
+        fused_bias, returned_bias = self._split_bias()
+        y = self.quant_method.apply(self, input_, fused_bias)
+        return (tensor_model_parallel_all_gather(y) if self.gather_output else y), returned_bias
 
 
 class MergedColumnParallelLinear(ColumnParallelLinear):
@@ -182,46 +215,22 @@ class MergedColumnParallelLinear(ColumnParallelLinear):
                          gather_output=gather_output, skip_bias_add=skip_bias_add,
                          params_dtype=params_dtype, quant_config=quant_config)
 
+    def _shards(self):
+        tp, rank = get_tensor_model_parallel_world_size(), get_tensor_model_parallel_rank()
+        out, local, whole = [], 0, 0
+        for i, n in enumerate(self.output_sizes):
+            out.append(_Shard(i, i, local, n // tp, whole, n, rank))
+            local, whole = local + n // tp, whole + n
+        return out
+
     def weight_loader(self, param: Parameter, loaded_weight: torch.Tensor,
                       loaded_shard_id: Optional[int] = None):
-        param_data = param.data
-        output_dim = getattr(param, "output_dim", None)
-        needs_scalar_to_array = getattr(param, "needs_scalar_to_array", None)
+        shards = self._shards()
         if loaded_shard_id is None:
-            # already-fused checkpoint tensor: load it shard by shard (linear.py:404-431)
-            if output_dim is None:
-                assert param_data.shape == loaded_weight.shape
-                param_data.copy_(loaded_weight)
-                return
-            current = 0
-            packed_dim = getattr(param, "packed_dim", None)
-            for i, output_size in enumerate(self.output_sizes):
-                shard_offset, shard_size = current, output_size
-                current += output_size
-                if packed_dim == output_dim:
-                    shard_size //= param.pack_factor
-                    shard_offset //= param.pack_factor
-                    shard_size, shard_offset = adjust_marlin_shard(param, shard_size, shard_offset)
-                self.weight_loader(param, loaded_weight.narrow(output_dim, shard_offset, shard_size), i)
+            _place_fused(self, param, loaded_weight, shards)
             return
-        assert loaded_shard_id < len(self.output_sizes)
-        tp_rank = get_tensor_model_parallel_rank()
-        tp_size = get_tensor_model_parallel_world_size()
-        if output_dim is not None:
-            shard_offset = sum(self.output_sizes[:loaded_shard_id]) // tp_size
-            shard_size = self.output_sizes[loaded_shard_id] // tp_size
-            packed_dim = getattr(param, "packed_dim", None)
-            if packed_dim == output_dim:
-                shard_size //= param.pack_factor
-                shard_offset //= param.pack_factor
-                shard_size, shard_offset = adjust_marlin_shard(param, shard_size, shard_offset)
-            param_data = param_data.narrow(output_dim, shard_offset, shard_size)
-            loaded_weight = loaded_weight.narrow(output_dim, tp_rank * shard_size, shard_size)
-        elif needs_scalar_to_array is not None:
-            param_data, loaded_weight = adjust_scalar_to_fused_array(param_data, loaded_weight,
-                                                                     loaded_shard_id)
-        assert param_data.shape == loaded_weight.shape
-        param_data.copy_(loaded_weight)
+        assert loaded_shard_id < len(shards)
+        _place(param, loaded_weight, shards[loaded_shard_id])
 
 
 class QKVParallelLinear(ColumnParallelLinear):
@@ -229,81 +238,42 @@ class QKVParallelLinear(ColumnParallelLinear):
 
     def __init__(self, hidden_size, head_size, total_num_heads, total_num_kv_heads=None, bias=True,
                  skip_bias_add=False, params_dtype=None, quant_config=None):
-        self.hidden_size = hidden_size
-        self.head_size = head_size
+        tp = get_tensor_model_parallel_world_size()
+        self.hidden_size, self.head_size = hidden_size, head_size
         self.total_num_heads = total_num_heads
-        if total_num_kv_heads is None:
-            total_num_kv_heads = total_num_heads
-        self.total_num_kv_heads = total_num_kv_heads
-        tp_size = get_tensor_model_parallel_world_size()
-        self.num_heads = divide(self.total_num_heads, tp_size)
-        if tp_size >= self.total_num_kv_heads:
-            self.num_kv_heads = 1
-            self.num_kv_head_replicas = divide(tp_size, self.total_num_kv_heads)
-        else:
-            self.num_kv_heads = divide(self.total_num_kv_heads, tp_size)
-            self.num_kv_head_replicas = 1
-        input_size = self.hidden_size
-        output_size = (self.num_heads + 2 * self.num_kv_heads) * tp_size * self.head_size
-        self.output_sizes = [
-            self.num_heads * self.head_size * tp_size,  # q_proj
-            self.num_kv_heads * self.head_size * tp_size,  # k_proj
-            self.num_kv_heads * self.head_size * tp_size,  # v_proj
-        ]
-        super().__init__(input_size=input_size, output_size=output_size, bias=bias,
-                         gather_output=False, skip_bias_add=skip_bias_add,
-                         params_dtype=params_dtype, quant_config=quant_config)
+        self.total_num_kv_heads = total_num_heads if total_num_kv_heads is None else total_num_kv_heads
+        self.num_heads = divide(total_num_heads, tp)
+        # KV heads: split over the ranks while there are enough of them, else one per rank, each shared by
+        # tp / total_num_kv_heads consecutive ranks
+        replicated = tp >= self.total_num_kv_heads
+        self.num_kv_heads = 1 if replicated else divide(self.total_num_kv_heads, tp)
+        self.num_kv_head_replicas = divide(tp, self.total_num_kv_heads) if replicated else 1
+        q_width = self.num_heads * head_size * tp
+        kv_width = self.num_kv_heads * head_size * tp      # counts a replicated head once per rank
+        self.output_sizes = [q_width, kv_width, kv_width]
+        super().__init__(input_size=hidden_size, output_size=q_width + 2 * kv_width, bias=bias, gather_output=False,
+                         skip_bias_add=skip_bias_add, params_dtype=params_dtype, quant_config=quant_config)
+
+    def _shards(self):
+        """q | k | v: a rank owns num_heads query heads and num_kv_heads KV heads; with more ranks than KV heads a
+        KV head is replicated over num_kv_head_replicas consecutive ranks, which all read the same slice"""
+        rank = get_tensor_model_parallel_rank()
+        d = self.head_size
+        q_local, kv_local = self.num_heads * d, self.num_kv_heads * d
+        q_whole, kv_whole = self.total_num_heads * d, self.total_num_kv_heads * d
+        kv_source = rank // self.num_kv_head_replicas
+        return {"q": _Shard("q", 0, 0, q_local, 0, q_whole, rank),
+                "k": _Shard("k", 1, q_local, kv_local, q_whole, kv_whole, kv_source),
+                "v": _Shard("v", 2, q_local + kv_local, kv_local, q_whole + kv_whole, kv_whole, kv_source)}
 
     def weight_loader(self, param: Parameter, loaded_weight: torch.Tensor,
                       loaded_shard_id: Optional[str] = None):
-        param_data = param.data
-        output_dim = getattr(param, "output_dim", None)
-        needs_scalar_to_array = getattr(param, "needs_scalar_to_array", None)
+        shards = self._shards()
         if loaded_shard_id is None:
-            if output_dim is None:
-                assert param_data.shape == loaded_weight.shape
-                param_data.copy_(loaded_weight)
-                return
-            shard_offsets = [
-                ("q", 0, self.total_num_heads * self.head_size),
-                ("k", self.total_num_heads * self.head_size, self.total_num_kv_heads * self.head_size),
-                ("v", (self.total_num_heads + self.total_num_kv_heads) * self.head_size,
-                 self.total_num_kv_heads * self.head_size),
-            ]
-            packed_dim = getattr(param, "packed_dim", None)
-            for shard_id, shard_offset, shard_size in shard_offsets:
-                if packed_dim == output_dim:
-                    shard_size //= param.pack_factor
-                    shard_offset //= param.pack_factor
-                    shard_size, shard_offset = adjust_marlin_shard(param, shard_size, shard_offset)
-                self.weight_loader(param, loaded_weight.narrow(output_dim, shard_offset, shard_size),
-                                   shard_id)
+            _place_fused(self, param, loaded_weight, shards.values())
             return
-        tp_rank = get_tensor_model_parallel_rank()
-        assert loaded_shard_id in ["q", "k", "v"]
-        if output_dim is not None:
-            if loaded_shard_id == "q":
-                shard_offset = 0
-                shard_size = self.num_heads * self.head_size
-            elif loaded_shard_id == "k":
-                shard_offset = self.num_heads * self.head_size
-                shard_size = self.num_kv_heads * self.head_size
-            else:
-                shard_offset = (self.num_heads + self.num_kv_heads) * self.head_size
-                shard_size = self.num_kv_heads * self.head_size
-            packed_dim = getattr(param, "packed_dim", None)
-            if packed_dim == output_dim:
-                shard_size //= param.pack_factor
-                shard_offset //= param.pack_factor
-                shard_size, shard_offset = adjust_marlin_shard(param, shard_size, shard_offset)
-            param_data = param_data.narrow(output_dim, shard_offset, shard_size)
-            shard_id = tp_rank if loaded_shard_id == "q" else tp_rank // self.num_kv_head_replicas
-            loaded_weight = loaded_weight.narrow(output_dim, shard_id * shard_size, shard_size)
-        elif needs_scalar_to_array is not None:
-            param_data, loaded_weight = adjust_scalar_to_fused_array(param_data, loaded_weight,
-                                                                     loaded_shard_id)
-        assert param_data.shape == loaded_weight.shape
-        param_data.copy_(loaded_weight)
+        assert loaded_shard_id in shards, f"Unknown Shard Id {loaded_shard_id}"
+        _place(param, loaded_weight, shards[loaded_shard_id])
 
 
 class RowParallelLinear(LinearBase):
@@ -312,35 +282,24 @@ class RowParallelLinear(LinearBase):
     def __init__(self, input_size, output_size, bias=True, input_is_parallel=True,
                  skip_bias_add=False, params_dtype=None, reduce_results=True, quant_config=None):
         super().__init__(input_size, output_size, skip_bias_add, params_dtype, quant_config)
-        self.input_is_parallel = input_is_parallel
-        self.reduce_results = reduce_results
+        assert self.quant_method is not None
+        if bias and not skip_bias_add and not reduce_results:
+            raise ValueError("When not reduce the results, adding bias to the results can lead "
+                             "to incorrect results")
+        self.input_is_parallel, self.reduce_results = input_is_parallel, reduce_results
         self.defer_into_all_reduce = os.environ.get("NMV_FUSED_GLUE", "1") != "0"
         self.tp_size = get_tensor_model_parallel_world_size()
         self.input_size_per_partition = divide(input_size, self.tp_size)
-        assert self.quant_method is not None
-        self.quant_method.create_weights(self, self.input_size_per_partition, [self.output_size],
-                                         self.input_size, self.output_size, self.params_dtype,
-                                         weight_loader=self.weight_loader)
-        if not reduce_results and (bias and not skip_bias_add):
-            raise ValueError("When not reduce the results, adding bias to the results can lead "
-                             "to incorrect results")
-        if bias:
-            self.bias = Parameter(torch.empty(self.output_size, dtype=params_dtype))
-            set_weight_attrs(self.bias, {"output_dim": 0, "weight_loader": self.weight_loader})
-        else:
-            self.register_parameter("bias", None)
+        self.quant_method.create_weights(self, self.input_size_per_partition, [output_size], input_size, output_size,
+                                         self.params_dtype, weight_loader=self.weight_loader)
+        self._own_bias(bias, output_size, self.weight_loader)
 
     def weight_loader(self, param: Parameter, loaded_weight: torch.Tensor):
-        tp_rank = get_tensor_model_parallel_rank()
-        input_dim = getattr(param, "input_dim", None)
-        param_data = param.data
-        if input_dim is not None:
-            shard_size = param_data.shape[input_dim]
-            loaded_weight = loaded_weight.narrow(input_dim, tp_rank * shard_size, shard_size)
-        if len(loaded_weight.shape) == 0:
-            loaded_weight = loaded_weight.reshape(1)
-        assert param_data.shape == loaded_weight.shape
-        param_data.copy_(loaded_weight)
+        axis = getattr(param, "input_dim", None)
+        if axis is not None:       # this rank's slice of the input dimension (packed parameters are cut in their own units)
+            rows = param.data.shape[axis]
+            loaded_weight = loaded_weight.narrow(axis, get_tensor_model_parallel_rank() * rows, rows)
+        _copy_checked(param.data, loaded_weight)
 
     def forward_partial(self, input_):
         """Deferred split-K (not in the reference): the fp32 slabs [splits, T, N] of X A, for a
@@ -383,15 +342,9 @@ class RowParallelLinear(LinearBase):
                 output_ = car.all_reduce_partial(slab, input_parallel.dtype).reshape(
                     input_parallel.shape[:-1] + (self.output_size, ))
                 return output_, None
-        output_parallel = self.quant_method.apply(self, input_parallel)
+        y = self.quant_method.apply(self, input_parallel)
         if self.reduce_results and self.tp_size > 1:
-            output_ = tensor_model_parallel_all_reduce(output_parallel)  # RCCL over xGMI
-        else:
-            output_ = output_parallel
-        if not self.skip_bias_add:
-            output = output_ + self.bias if self.bias is not None else output_
-            output_bias = None
-        else:
-            output = output_
-            output_bias = self.bias
-        return output, output_bias
+            y = tensor_model_parallel_all_reduce(y)   # RCCL over xGMI (or the P2P kernels)
+        # the bias is added once, after the reduction (every rank holds the whole bias)
+        added, returned_bias = self._split_bias()
+        return (y if added is None else y + added), returned_bias

@@ -225,3 +225,41 @@ def test_from_pretrained_safetensors_round_trip(gpu_device, tmp_path, quant):
         r.fill_context()
         outs.append(torch.stack([r.decode_step().clone() for _ in range(4)]).cpu())
     assert torch.equal(outs[0], outs[1])
+
+
+def test_full_size_llama3_8b_layer_decode_step(gpu_device):
+    """ONE decoder layer at Llama-3-8B's real dimensions (hidden 4096, 32 query / 8 KV heads, MLP 14336; w4a16 g128),
+    64 sequences with 512 tokens of context: prompt step + one decode step through the HIP path -- the headline
+    configuration's kernels at their real shapes (stream GEMM at M = 64 in the deferred / silu forms, fused rope +
+    cache write + paged attention, slab-summing norms) -- against the plain fp32 reference of the same math on the
+    same weights and tokens (RefLlama, pinned to the reference's own model code by tests/test_oracle_golden.py).
+    Stated tolerance: mean|dlogit| / mean|logit| < 3e-2 (bf16 activations, fp32 reference), greedy token equal
+    wherever the reference's top-2 margin exceeds twice that."""
+    from neural_magic_vllm_amd.worker import decode_runner as dr
+    arch = dr.LlamaArch(4096, 14336, 1, 32, 8, 2048)
+    quant = dict(method="gptq_marlin", bits=4, group_size=128)
+    weights = list(dr.synthetic_llama_weights(arch, torch.bfloat16, "cpu", quant, seed=0))
+    runner = dr.DecodeRunner(arch, gpu_device, torch.bfloat16, quant, dr.CacheConfig(16, "auto"),
+                             weights=[(n, t.clone()) for n, t in weights])
+    ref = RefLlama(arch, {n: t.to(gpu_device) for n, t in weights})
+    batch, ctx = 64, 512
+    runner.setup_batch(batch, ctx, 8)
+    seed = 3
+    g = torch.Generator().manual_seed(seed)       # the ids DecodeRunner.prefill draws for this seed
+    prompts = torch.randint(0, arch.vocab_size, (batch * ctx, ), generator=g).view(batch, ctx)
+    first = runner.prefill(ctx, seed=seed).view(-1).cpu()
+    ref_prompt_last = torch.stack([ref.forward(prompts[b].to(gpu_device))[-1] for b in range(batch)]).float().cpu()
+    tol = 3e-2 * ref_prompt_last.abs().mean()
+    top2 = ref_prompt_last.topk(2, dim=-1).values
+    sure = (top2[:, 0] - top2[:, 1]) > 2 * tol
+    assert sure.sum() > batch // 2, "the test needs decisive reference tokens"
+    assert torch.equal(first[sure], ref_prompt_last.argmax(-1)[sure])
+    # the decode step on the tokens the HIP path drew (context 512 + 1)
+    runner.keep_logits = True
+    runner.input_ids.copy_(first.to(gpu_device))
+    runner.decode_step()
+    got = runner.last_logits.float().cpu()
+    seqs = torch.cat([prompts, first.view(-1, 1)], dim=1)
+    want = torch.stack([ref.forward(seqs[b].to(gpu_device))[-1] for b in range(batch)]).float().cpu()
+    rel = ((got - want).abs().mean() / want.abs().mean()).item()
+    assert rel < 3e-2, f"decode-step logits of the full-size layer: relative error {rel}"
