@@ -187,6 +187,8 @@ class device_guard:
     """at::cuda::OptionalCUDAGuard analogue: only switches when the tensor is elsewhere."""
 
     def __init__(self, t: torch.Tensor):
+        if t.device.type != "cuda":   # a host pointer handed to a kernel is a GPU fault, not an exception
+            raise NmvError(f"expected a tensor on the GPU, got one on {t.device} (there is no CPU path)")
         self.idx = t.device.index
         self.prev = None
 

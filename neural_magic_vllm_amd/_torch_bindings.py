@@ -1139,10 +1139,39 @@ def _op_name(schema: str) -> str:
     return schema.split("(", 1)[0]
 
 
+binding = None   # "cpp" (the _C extension, csrc/torch_bindings.cpp) or "python" (this module) once register() ran
+
+
+def _load_cpp_extension() -> bool:
+    """`import neural_magic_vllm_amd._C`: its static TORCH_LIBRARY blocks register all four namespaces.  Skipped when
+    NMV_BINDING=python, when the extension has not been built, or when NMV_HIP_LIB selects a development build of the
+    C ABI (the extension is linked against the product libnmvllm_hip.so beside it).  NMV_BINDING=cpp makes its
+    absence an error."""
+    import importlib
+    import os
+    want = os.environ.get("NMV_BINDING", "auto")
+    if want == "python" or (want == "auto" and os.environ.get("NMV_HIP_LIB")):
+        return False
+    try:
+        ext = importlib.import_module(__package__ + "._C")
+    except ImportError as e:
+        if want == "cpp":
+            raise ImportError(f"NMV_BINDING=cpp but the _C extension does not load ({e}); build it with "
+                              "`python neural_magic_vllm_amd/csrc/setup_C.py build_ext --inplace`") from e
+        return False
+    if ext.abi_version() != _lib.ABI_VERSION:
+        raise ImportError(f"_C was linked against C ABI version {ext.abi_version()}, this package needs "
+                          f"{_lib.ABI_VERSION}: rebuild libnmvllm_hip.so and the _C extension")
+    return True
+
+
 def register() -> None:
-    """Define the three namespaces and attach the impls (idempotent)."""
-    global _registered
+    """Register the four namespaces (idempotent): from the C++ extension when it is there, else from this module."""
+    global _registered, binding
     if _registered:
+        return
+    if _load_cpp_extension():
+        binding, _registered = "cpp", True
         return
     for ns, table in (("_C", _C_OPS), ("_C_cache_ops", _CACHE_OPS)):
         lib = torch.library.Library(ns, "DEF")
@@ -1167,7 +1196,7 @@ def register() -> None:
         lib.define(schema)
         lib.impl(_op_name(schema), fn, key)
     _libs.append(lib)
-    _registered = True
+    binding, _registered = "python", True
 
 
 def all_schemas():

@@ -27,6 +27,7 @@
 // HBM-bound by construction: algorithmic bytes = 2 * L * D * sizeof(cache_t) per (seq, kv head).
 #include "common.h"
 #include "cache_write.h"
+#include "fp32_path.h"
 
 namespace nmv {
 
@@ -52,6 +53,9 @@ struct PAGeom {
 #define NMV_PA_VG 4
 #endif
   static constexpr int KG = NKC < NMV_PA_KG ? NKC : NMV_PA_KG;  // K chunks in flight per lane
+  // register budget: two waves per SIMD (256 VGPRs each) unless the fp32 accumulators alone take 48 of them --
+  // without the hint the 4-wave forms may use 512 and the block-sparse one did (414 registers, one wave per SIMD)
+  static constexpr int MIN_WAVES = (HG * NVL >= 48) ? 1 : 2;
   static_assert(HEAD_SIZE % EPC == 0, "head size must be a multiple of x");
   static_assert(PA_WIN % BLOCK_SIZE == 0, "block size must divide the window");
 };
@@ -98,7 +102,7 @@ struct PASparse {
 // the same KV run is then split over twice the waves and the per-wave chain of dependent windows
 // halves (B=1, L=530: 14.7 -> 10.9 us; at B=64 the 4-wave form is 15 % faster).
 template <typename T, bool FP8, int HEAD_SIZE, int BLOCK_SIZE, int HG, int NW, bool SPARSE = false>
-__global__ __launch_bounds__(NW * WAVE) void paged_attention_kernel(
+__global__ __launch_bounds__(NW * WAVE, (PAGeom<HEAD_SIZE, BLOCK_SIZE, HG, FP8>::MIN_WAVES)) void paged_attention_kernel(
     float* __restrict__ exp_sums,    // [num_seqs, num_heads, max_num_partitions] (partitioned only)
     float* __restrict__ max_logits,  // same
     uint16_t* __restrict__ out,      // [num_seqs, num_heads, (max_num_partitions,) head_size]
@@ -148,18 +152,30 @@ __global__ __launch_bounds__(NW * WAVE) void paged_attention_kernel(
     const uint16_t* row16 = f.qkv + (int64_t)seq_idx * f.row_elems;
     const uint16_t* cos_ptr = f.cos_sin + pos * HEAD_SIZE;
     const uint16_t* sin_ptr = cos_ptr + EMBED;
-    auto slab_sum4 = [&](int col, float (&o)[4]) {
+    // sums of the split-K slabs at `col` and (PAIR) at `col + EMBED`: one loop, both loads of a slab in flight
+    // together (two calls = two dependent round trips per rotary pair; r03)
+    auto slab_sum4 = [&](int col, float (&o)[4], float (&o2)[4], auto pair) {
+      constexpr bool PAIR = decltype(pair)::value;
       if (f.slab == nullptr) {  // uniform: finished row in the model dtype
         const uint2 w = *reinterpret_cast<const uint2*>(row16 + col);
         o[0] = lo_f<T>(w.x), o[1] = hi_f<T>(w.x), o[2] = lo_f<T>(w.y), o[3] = hi_f<T>(w.y);
+        if constexpr (PAIR) {
+          const uint2 w2 = *reinterpret_cast<const uint2*>(row16 + col + EMBED);
+          o2[0] = lo_f<T>(w2.x), o2[1] = hi_f<T>(w2.x), o2[2] = lo_f<T>(w2.y), o2[3] = hi_f<T>(w2.y);
+        }
         return;
       }
-      f32x4_t acc4 = {0.f, 0.f, 0.f, 0.f};
+      f32x4_t acc4 = {0.f, 0.f, 0.f, 0.f}, acc4b = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 4
-      for (int sp = 0; sp < f.splits; ++sp)
+      for (int sp = 0; sp < f.splits; ++sp) {
         acc4 += *reinterpret_cast<const f32x4_t*>(row + sp * f.slab_stride + col);
+        if constexpr (PAIR) acc4b += *reinterpret_cast<const f32x4_t*>(row + sp * f.slab_stride + col + EMBED);
+      }
 #pragma unroll
-      for (int i = 0; i < 4; ++i) o[i] = round_trip<T>(acc4[i]);  // the GEMM's output rounding
+      for (int i = 0; i < 4; ++i) {
+        o[i] = round_trip<T>(acc4[i]);  // the GEMM's output rounding
+        if constexpr (PAIR) o2[i] = round_trip<T>(acc4b[i]);
+      }
     };
     constexpr int N_Q = HG * QUADS, N_K = QUADS, N_V = HEAD_SIZE / 4;
     for (int it = threadIdx.x; it < N_Q + N_K + N_V; it += (NW * WAVE)) {
@@ -169,10 +185,9 @@ __global__ __launch_bounds__(NW * WAVE) void paged_attention_kernel(
         const int d0 = ((is_k ? it - N_Q : it) % QUADS) * 4;
         const int col = (is_k ? num_heads + kv_head : head0 + h) * HEAD_SIZE + d0;
         float x[4], y[4];
-        slab_sum4(col, x);
-        slab_sum4(col + EMBED, y);
         const uint2 cw = *reinterpret_cast<const uint2*>(cos_ptr + d0);
         const uint2 sw = *reinterpret_cast<const uint2*>(sin_ptr + d0);
+        slab_sum4(col, x, y, std::true_type{});
         const uint32_t cs[2] = {cw.x, cw.y}, sn[2] = {sw.x, sw.y};
         uint16_t xo[4], yo[4];
 #pragma unroll
@@ -201,7 +216,7 @@ __global__ __launch_bounds__(NW * WAVE) void paged_attention_kernel(
       } else {
         const int e0 = (it - N_Q - N_K) * 4;
         float v[4];
-        slab_sum4((num_heads + num_kv_heads + kv_head) * HEAD_SIZE + e0, v);
+        slab_sum4((num_heads + num_kv_heads + kv_head) * HEAD_SIZE + e0, v, v, std::false_type{});
         if (cached) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
@@ -236,11 +251,25 @@ __global__ __launch_bounds__(NW * WAVE) void paged_attention_kernel(
   // (start_tok is block aligned: partitions are multiples of the block size).  Dealing 64-token
   // windows round-robin instead leaves 9 windows as 3+2+2+2: the first wave then sets the time of
   // the workgroup, +25..50 % just past every multiple of 256 tokens.
-  const int n_blk = (end_tok - start_tok + BLOCK_SIZE - 1) / BLOCK_SIZE;
+  // block-sparse with sparsity blocks of whole windows (the usual 64 tokens): the runs are dealt in windows, so that
+  // a window lies inside ONE sparsity block and "does head h attend to it" is a per-window scalar -- no per-lane
+  // integer divisions, and unattended windows are skipped before their K / V are loaded (below)
+  bool sp_u = false;
+  int sp_off[HG], sp_last = 0;
+  if constexpr (SPARSE) {
+    sp_u = sp.block_size % PA_WIN == 0;
+    sp_last = (seq_len - 1) / sp.block_size - sp.local_blocks;
+#pragma unroll
+    for (int h = 0; h < HG; ++h)
+      sp_off[h] = sp.head_sliding_step >= 0 ? (sp.tp_rank * num_heads + head0 + h) * sp.head_sliding_step + 1
+                                            : (sp.tp_rank * num_kv_heads + kv_head) * (-sp.head_sliding_step) + 1;
+  }
+  const int unit = sp_u ? PA_WIN : BLOCK_SIZE;
+  const int n_blk = (end_tok - start_tok + unit - 1) / unit;
   const int blk_lo = (n_blk / NW) * wave + min(wave, n_blk % NW);
   const int blk_cnt = n_blk / NW + (wave < n_blk % NW ? 1 : 0);
-  const int w_tok0 = start_tok + blk_lo * BLOCK_SIZE;                       // this wave's tokens:
-  const int w_tok1 = min(w_tok0 + blk_cnt * BLOCK_SIZE, end_tok);           // [w_tok0, w_tok1)
+  const int w_tok0 = start_tok + blk_lo * unit;                             // this wave's tokens:
+  const int w_tok1 = min(w_tok0 + blk_cnt * unit, end_tok);                 // [w_tok0, w_tok1)
   const float qk_scale = FP8 ? scale * kv_scale : scale;
   const int64_t head_off_bytes = (int64_t)kv_head * kv_head_stride * G::CB;
   const int64_t block_stride_bytes = kv_block_stride * G::CB;
@@ -262,6 +291,34 @@ __global__ __launch_bounds__(NW * WAVE) void paged_attention_kernel(
     const int boff = tok_c % BLOCK_SIZE;
     // block-table lookup of the NEXT window issued before this window's loads are consumed
     const int phys_next = (wstart + PA_WIN < w_tok1) ? phys_of(wstart + PA_WIN) : 0;
+
+    // block-sparse: a window none of whose tokens any head of the group attends to is skipped before its K / V are
+    // loaded (the reference skips masked blocks the same way, attention_kernels.cu:209-251).  Exact: such a window
+    // would contribute p = 0 and rescale by alpha = 1.
+    bool att_u[HG];   // sp_u: per-window, per-head scalars
+    if constexpr (SPARSE) {
+      bool any;
+      if (sp_u) {
+        const int kb_u = __builtin_amdgcn_readfirstlane(wstart / sp.block_size);
+        const bool local_u = kb_u > sp_last;
+        any = false;
+#pragma unroll
+        for (int h = 0; h < HG; ++h) {
+          att_u[h] = local_u || (kb_u + sp_off[h]) % sp.vert_stride == 0;
+          any = any || att_u[h];
+        }
+      } else {
+        const int kb_w = (tok_c / BLOCK_SIZE) * BLOCK_SIZE / sp.block_size;
+        bool lane_any = kb_w > sp_last;
+#pragma unroll
+        for (int h = 0; h < HG; ++h) lane_any = lane_any || (kb_w + sp_off[h]) % sp.vert_stride == 0;
+        any = __ballot(valid && lane_any) != 0;
+      }
+      if (!any) {   // wave-uniform
+        phys = phys_next;
+        continue;
+      }
+    }
 
     // ================= Q.K^T : lane = token =================
     const uint8_t* kp = k_cache + (int64_t)phys * block_stride_bytes + head_off_bytes + boff * 16;
@@ -310,6 +367,17 @@ __global__ __launch_bounds__(NW * WAVE) void paged_attention_kernel(
             s[h] = a;
           }
         }
+        // block-sparse form: left alone, the LDS reads of the queries of ALL chunks are issued first (256 VGPRs, then
+        // spills); the empty asm pins the dot products of a pair of chunks before the next pair's reads
+#ifndef NMV_PA_PIN
+#define NMV_PA_PIN 0
+#endif
+        if constexpr (SPARSE || NMV_PA_PIN) {
+          if ((j & 1) == 1) {
+#pragma unroll
+            for (int h = 0; h < HG; ++h) asm volatile("" : "+v"(s[h]));
+          }
+        }
       }
     }
 
@@ -345,20 +413,18 @@ __global__ __launch_bounds__(NW * WAVE) void paged_attention_kernel(
     int kb = 0;
     bool kb_local = false;
     if constexpr (SPARSE) {
-      kb = (tok_c / BLOCK_SIZE) * BLOCK_SIZE / sp.block_size;
-      kb_local = kb > (seq_len - 1) / sp.block_size - sp.local_blocks;
+      if (!sp_u) {
+        kb = (tok_c / BLOCK_SIZE) * BLOCK_SIZE / sp.block_size;
+        kb_local = kb > sp_last;
+      }
     }
 #pragma unroll
     for (int h = 0; h < HG; ++h) {
       float sv = s[h] * qk_scale;
       sv += (slope[h] != 0.f) ? slope[h] * (float)(tok - seq_len + 1) : 0.f;
       bool attend = valid;
-      if constexpr (SPARSE) {
-        const int off = sp.head_sliding_step >= 0
-                            ? (sp.tp_rank * num_heads + head0 + h) * sp.head_sliding_step + 1
-                            : (sp.tp_rank * num_kv_heads + kv_head) * (-sp.head_sliding_step) + 1;
-        attend = valid && (kb_local || (kb + off) % sp.vert_stride == 0);
-      }
+      if constexpr (SPARSE)
+        attend = valid && (sp_u ? att_u[h] : (kb_local || (kb + sp_off[h]) % sp.vert_stride == 0));
       sv = attend ? sv : -INFINITY;
       const float m_new = fmaxf(m_run[h], wave_max(sv));
       // exp(-inf) = 0 on the first window; a window in which this head attends to nothing (block-sparse) leaves
@@ -568,7 +634,8 @@ static void launch_pa(const PAArgs& a) {
   const int parts = a.partitioned ? (a.max_seq_len + PA_PARTITION - 1) / PA_PARTITION : 1;
   dim3 grid(a.num_heads / HG, a.num_seqs, parts);
   // no more workgroups than CUs: 8 waves each
-  const bool wide = (int64_t)grid.x * grid.y * grid.z <= 256;
+  bool wide = (int64_t)grid.x * grid.y * grid.z <= 256;
+  if (const char* e = getenv("NMV_PA_NW")) wide = atoi(e) == 8;   // experiments
 #define NMV_PA_LAUNCH(NW_) NMV_PA_LAUNCH_S(NW_, false)
 #define NMV_PA_LAUNCH_S(NW_, SP_)                                                                 \
   hipLaunchKernelGGL((paged_attention_kernel<T, FP8, HEAD_SIZE, BLOCK_SIZE, HG, NW_, SP_>), grid,  \
@@ -644,18 +711,32 @@ extern template int pa_dispatch_head<256>(const PAArgs&, nmv_dtype_t, nmv_kv_dty
 }
 
 static int pa_entry(PAArgs& a, nmv_dtype_t dtype, nmv_kv_dtype_t kv_dtype, const char* name) {
-  NMV_CHECK(dtype == NMV_F16 || dtype == NMV_BF16, "%s: unsupported data type %d", name, (int)dtype);
+  NMV_CHECK(dtype == NMV_F16 || dtype == NMV_BF16 || dtype == NMV_F32, "%s: unsupported data type %d", name, (int)dtype);
   NMV_CHECK(kv_dtype == NMV_KV_AUTO || kv_dtype == NMV_KV_FP8_E4M3,
             "%s: unsupported kv cache dtype %d", name, (int)kv_dtype);
+  NMV_CHECK(dtype != NMV_F32 || (a.fused.slab == nullptr && a.fused.qkv == nullptr),
+            "%s: the fused decode prologue exists for 16-bit models only", name);
   NMV_CHECK(a.num_kv_heads > 0 && a.num_heads % a.num_kv_heads == 0,
             "%s: num_heads %d not divisible by num_kv_heads %d", name, a.num_heads, a.num_kv_heads);
   NMV_CHECK(a.block_size == 8 || a.block_size == 16 || a.block_size == 32,
             "%s: Unsupported block size: %d", name, a.block_size);
-  NMV_CHECK(a.q_stride % 2 == 0, "%s: query row stride must be even", name);
+  NMV_CHECK(dtype == NMV_F32 || a.q_stride % 2 == 0, "%s: query row stride must be even", name);
   NMV_CHECK((int64_t)a.max_num_blocks_per_seq * a.block_size >= a.max_seq_len,
             "%s: block_tables hold %d blocks of %d tokens per sequence, max_seq_len is %d", name,
             a.max_num_blocks_per_seq, a.block_size, a.max_seq_len);
   if (a.num_seqs == 0) return NMV_OK;
+  if (dtype == NMV_F32) {   // float models: fp32_path.hip
+    F32AttnArgs f{a.exp_sums, a.max_logits, (float*)a.out, (float*)a.tmp_out, (const float*)a.query, a.key_cache,
+                  a.value_cache, a.num_seqs, a.num_heads, a.head_size, a.num_kv_heads, a.scale, a.block_tables,
+                  a.seq_lens, a.block_size, a.max_seq_len, a.max_num_blocks_per_seq, a.alibi_slopes, a.q_stride,
+                  a.kv_block_stride, a.kv_head_stride, a.kv_scale, a.partitioned, a.stream,
+                  F32Sparse{a.sparse.tp_rank, a.sparse.local_blocks, a.sparse.vert_stride, a.sparse.block_size,
+                            a.sparse.head_sliding_step}};
+    const int frc = f32_paged_attention(f, kv_dtype == NMV_KV_FP8_E4M3);
+    if (frc != NMV_OK) return frc;
+    NMV_LAUNCH_CHECK();
+    return NMV_OK;
+  }
   int rc;
   switch (a.head_size) {
     case 64: rc = pa_dispatch_head<64>(a, dtype, kv_dtype); break;

@@ -4,6 +4,7 @@
 // here moves 16-byte vectors wherever the paged layout has 16 contiguous bytes.
 #include "common.h"
 #include "cache_write.h"
+#include "fp32_path.h"
 
 namespace nmv {
 
@@ -95,15 +96,22 @@ extern "C" int nmv_reshape_and_cache(const void* key, const void* value, void* k
                                      int block_size, int64_t key_stride, int64_t value_stride,
                                      nmv_dtype_t dtype, nmv_kv_dtype_t kv_dtype, float kv_scale,
                                      void* stream) {
-  NMV_CHECK(dtype == NMV_F16 || dtype == NMV_BF16, "reshape_and_cache: unsupported dtype %d",
+  NMV_CHECK(dtype == NMV_F16 || dtype == NMV_BF16 || dtype == NMV_F32, "reshape_and_cache: unsupported dtype %d",
             (int)dtype);
   NMV_CHECK(kv_dtype == NMV_KV_AUTO || kv_dtype == NMV_KV_FP8_E4M3,
             "reshape_and_cache: unsupported kv cache dtype %d", (int)kv_dtype);
-  const int x = kv_dtype == NMV_KV_AUTO ? 8 : 16;
+  const int x = kv_dtype == NMV_KV_AUTO ? (dtype == NMV_F32 ? 4 : 8) : 16;
   NMV_CHECK(head_size % x == 0, "reshape_and_cache: head_size %d not a multiple of x=%d",
             head_size, x);
   NMV_CHECK(block_size > 0 && num_kv_heads > 0, "reshape_and_cache: bad shape");
   if (num_tokens == 0) return NMV_OK;
+  if (dtype == NMV_F32) {   // float models: fp32_path.hip
+    f32_reshape_and_cache(key, value, key_cache, value_cache, slot_mapping, num_tokens, num_kv_heads, head_size,
+                          block_size, key_stride, value_stride, kv_dtype == NMV_KV_FP8_E4M3, kv_scale,
+                          (hipStream_t)stream);
+    NMV_LAUNCH_CHECK();
+    return NMV_OK;
+  }
   dim3 grid(num_tokens);
   dim3 block(std::min(num_kv_heads * head_size, 512));
   hipStream_t s = (hipStream_t)stream;
@@ -178,9 +186,14 @@ extern "C" int nmv_swap_blocks(const void* src, void* dst, const int64_t* block_
 extern "C" int nmv_convert_fp8(void* dst, const void* src, int64_t num_blocks,
                                int64_t block_stride, nmv_dtype_t dtype, int to_fp8, float scale,
                                void* stream) {
-  NMV_CHECK(dtype == NMV_F16 || dtype == NMV_BF16, "convert_fp8: unsupported dtype %d",
+  NMV_CHECK(dtype == NMV_F16 || dtype == NMV_BF16 || dtype == NMV_F32, "convert_fp8: unsupported dtype %d",
             (int)dtype);
   if (num_blocks == 0) return NMV_OK;
+  if (dtype == NMV_F32) {
+    f32_convert_fp8(dst, src, num_blocks, block_stride, to_fp8 != 0, scale, (hipStream_t)stream);
+    NMV_LAUNCH_CHECK();
+    return NMV_OK;
+  }
   dim3 grid(num_blocks);
   dim3 block((unsigned)std::min<int64_t>(block_stride, 512));
   hipStream_t s = (hipStream_t)stream;

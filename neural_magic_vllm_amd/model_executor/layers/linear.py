@@ -61,8 +61,8 @@ def _stored_units(param, columns: int) -> int:
 
 
 def _copy_checked(dst: torch.Tensor, src: torch.Tensor) -> None:
-    if src.dim() == 0:
-        src = src.reshape(1)
+    if src.numel() == 1 and dst.numel() == 1:    # a scalar saved as [] or [1] into a [] or [1] slot
+        src = src.reshape(dst.shape)
     assert dst.shape == src.shape, f"checkpoint tensor {tuple(src.shape)} does not fit parameter {tuple(dst.shape)}"
     dst.copy_(src)
 

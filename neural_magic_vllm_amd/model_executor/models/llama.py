@@ -8,6 +8,7 @@ carried through fused_add_rms_norm.  Checkpoint name mapping, LoRA, pipeline par
 rope scaling are outside the hot-path scope.
 """
 import os
+import warnings
 from typing import Any, Iterable, List, NamedTuple, Optional, Tuple
 
 import torch
@@ -49,6 +50,15 @@ def _add_norm(norm: RMSNorm, hidden_states, residual: torch.Tensor):
         return ops.fused_add_rms_norm_partial(hidden_states.slab, residual, norm.weight.data,
                                               norm.variance_epsilon), residual
     return norm(hidden_states, residual)
+
+
+_warned = set()
+
+
+def _warn_once(msg: str) -> None:
+    if msg.split("(e.g.")[0] not in _warned:
+        _warned.add(msg.split("(e.g.")[0])
+        warnings.warn(msg, stacklevel=3)
 
 
 class LlamaMLP(nn.Module):
@@ -295,8 +305,8 @@ class LlamaForCausalLM(nn.Module):
         params = dict(self.named_parameters())
         written = {}
         for name, loaded in weights:
-            if "rotary_emb.inv_freq" in name:
-                continue
+            if "rotary_emb.inv_freq" in name or "rotary_emb.cos_cached" in name or "rotary_emb.sin_cached" in name:
+                continue   # buffers some exporters serialise (llama.py:431-437 skips all three)
             if self.tie_word_embeddings and name == "lm_head.weight":
                 continue   # tied: the embedding's tensor is the head's
             for pname, wname, shard_id in stacked:
@@ -318,8 +328,10 @@ class LlamaForCausalLM(nn.Module):
                     # fp8 checkpoints: the KV-cache scaling factor lives on the Attention layer
                     remapped = name.replace(".kv_scale", ".attn.kv_scale")
                     if remapped not in params:
-                        raise ValueError(f"checkpoint carries {name} but the model has no {remapped}: "
-                                         "load it with an fp8 quantisation config (Fp8KVCacheMethod)")
+                        # llama.py:470-481: warn once and carry on with a scale of 1.0
+                        _warn_once(f"Found kv scale in the checkpoint (e.g. {name}), but not found the expected name "
+                                   f"in the model (e.g. {remapped}). kv-scale is not loaded.")
+                        continue
                     name = remapped
                 if name not in params:
                     raise ValueError(f"checkpoint tensor {name} has no parameter in the model")

@@ -65,7 +65,7 @@ def make_paged_attention_inputs(seed: int, num_seqs: int, num_heads: Tuple[int, 
         [[rnd.randint(0, num_blocks - 1) for _ in range(max_blocks)] for _ in range(num_seqs)],
         dtype=torch.int32)
     kshape, vshape = kv_cache_shapes(num_blocks, block_size, nkv, head_size,
-                                     1 if kv_cache_dtype != "auto" else 2)
+                                     1 if kv_cache_dtype != "auto" else torch.empty(0, dtype=dtype).element_size())
     kf = (torch.rand(kshape, generator=g) * 2 - 1).mul_(scale)
     vf = (torch.rand(vshape, generator=g) * 2 - 1).mul_(scale)
     if kv_cache_dtype == "auto":
@@ -143,7 +143,8 @@ def make_reshape_and_cache_inputs(seed, num_tokens, num_heads, head_size, block_
     qkv = torch.randn((num_tokens, 3, num_heads, head_size), generator=g).to(dtype)
     _, key, value = qkv.unbind(dim=1)
     scale = head_size**-0.5
-    kshape, vshape = kv_cache_shapes(num_blocks, block_size, num_heads, head_size, 2)
+    kshape, vshape = kv_cache_shapes(num_blocks, block_size, num_heads, head_size,
+                                     torch.empty(0, dtype=dtype).element_size())
     key_cache = (torch.rand(kshape, generator=g) * 2 - 1).mul_(scale).to(dtype)
     value_cache = (torch.rand(vshape, generator=g) * 2 - 1).mul_(scale).to(dtype)
     return dict(key=key, value=value, key_cache=key_cache, value_cache=value_cache,

@@ -321,3 +321,34 @@ def test_paged_attention_rope_partial_matches_separate_launches(gpu_device, head
     assert torch.equal(kc2.view(torch.uint8), ref_kc2.view(torch.uint8))
     assert torch.equal(vc2.view(torch.uint8), ref_vc2.view(torch.uint8))
     assert torch.equal(got2.view(torch.int16), ref2.view(torch.int16))
+
+
+@pytest.mark.parametrize("version", ["v1", "v2"])
+@pytest.mark.parametrize("kv_cache_dtype", ["auto", "fp8"])
+@pytest.mark.parametrize("num_heads,head_size,block_size,use_alibi", [((32, 8), 128, 16, False), ((40, 40), 80, 32, True),
+                                                                      ((8, 2), 256, 8, False)])
+def test_paged_attention_float32(gpu_device, version, kv_cache_dtype, num_heads, head_size, block_size, use_alibi):
+    """float models (the reference instantiates `float` beside half / bfloat16: attention_kernels.cu:738-766, with a
+    float or an fp8 cache): query / output fp32, K cache [.., head / x, block, x] with x = 4 (float) or 16 (fp8);
+    against the fp32 torch restatement of the op.  Stated tolerance: 1e-5 abs (fp32 arithmetic in a different
+    summation order), 2e-3 with the fp8 cache's scale of 0.5 folded in."""
+    inp = helpers.make_paged_attention_inputs(5, 7, num_heads, head_size, block_size, torch.float32,
+                                              max_seq_len=1300, num_blocks=256, use_alibi=use_alibi,
+                                              kv_cache_dtype=kv_cache_dtype)
+    assert inp["key_cache"].shape[-1] == (4 if kv_cache_dtype == "auto" else 16)
+    kv_scale = 1.0 if kv_cache_dtype == "auto" else 0.5
+    ref = helpers.ref_paged_attention_torch(inp, kv_scale=kv_scale)
+    out, parts = run_hip(inp, version, gpu_device, kv_cache_dtype=kv_cache_dtype, kv_scale=kv_scale)
+    assert out.dtype == torch.float32
+    check(out, ref, atol=2e-5 if kv_cache_dtype == "auto" else 2e-3, rtol=1e-5)
+    if parts is not None:
+        assert parts[2].dtype == torch.float32
+
+
+def test_paged_attention_float32_blocksparse(gpu_device):
+    inp = helpers.make_paged_attention_inputs(6, 5, (16, 4), 64, 16, torch.float32, max_seq_len=2100, num_blocks=256)
+    sparse = dict(tp_rank=0, local_blocks=4, vert_stride=8, block_size=64, head_sliding_step=1)
+    ref = helpers.ref_paged_attention_torch(inp, blocksparse=sparse)
+    for version in ("v1", "v2"):
+        out, _ = run_hip(inp, version, gpu_device, sparse=sparse)
+        check(out, ref, atol=2e-5, rtol=1e-5)

@@ -166,3 +166,26 @@ def test_convert_fp8_round_trip(gpu_device, dtype):
     exp = (oracle.fp8_decode(f8.cpu()) * 0.5).to(dtype)
     assert torch.equal(back.cpu(), exp)
     assert torch.allclose(back.cpu().float(), x.float(), atol=1e-3, rtol=0.07)  # e4m3: 3 mantissa bits
+
+
+@pytest.mark.parametrize("head_size,block_size", [(128, 16), (80, 32), (64, 8)])
+def test_reshape_and_cache_and_convert_fp8_float32(gpu_device, head_size, block_size):
+    """float models (cache_kernels.cu:253-278, :339-389 are instantiated for float): K cache chunks of x = 4 floats;
+    bit-exact against the oracle's scatter; fp8 cache from float key / value; convert_fp8 float <-> fp8 round trip"""
+    from neural_magic_vllm_amd import _custom_ops as ops
+    inp = helpers.make_reshape_and_cache_inputs(3, 29, 4, head_size, block_size, 64, torch.float32)
+    assert inp["key_cache"].shape[-1] == 4
+    slots = inp["slot_mapping"].clone()
+    slots[::7] = -1
+    kc, vc = inp["key_cache"].to(gpu_device), inp["value_cache"].to(gpu_device)
+    ops.reshape_and_cache(inp["key"].to(gpu_device), inp["value"].to(gpu_device), kc, vc, slots.to(gpu_device), "auto", 1.0)
+    kr, vr = inp["key_cache"].clone(), inp["value_cache"].clone()
+    oracle.reshape_and_cache(inp["key"], inp["value"], kr, vr, slots)
+    assert torch.equal(kc.cpu(), kr) and torch.equal(vc.cpu(), vr)
+    # float -> fp8 -> float: the round trip is the fp8 rounding of x / scale, times scale
+    f8 = torch.empty(kc.shape, dtype=torch.uint8, device=gpu_device)
+    ops.convert_fp8(f8, kc, 0.25, "fp8")
+    back = torch.empty_like(kc)
+    ops.convert_fp8(back, f8, 0.25, "fp8")
+    want = (kr / 0.25).to(torch.float8_e4m3fn).float() * 0.25
+    assert torch.equal(back.cpu(), want)

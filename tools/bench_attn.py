@@ -13,9 +13,10 @@ from neural_magic_vllm_amd import _custom_ops as ops  # noqa: E402
 from neural_magic_vllm_amd.attention.ops.paged_attn import PagedAttention  # noqa: E402
 
 
-def bench(b, L, dev, kv, iters=20, nq=32, nkv=8, d=128, bs=16, fused=0):
+def bench(b, L, dev, kv, iters=20, nq=32, nkv=8, d=128, bs=16, fused=0, sparse=None):
     """fused = S > 0: the decode step's form -- the kernel starts from S fp32 split-K slabs of the qkv projection
-    (slab sums + rotary + cache store of the new token in its prologue; L counts the new token)"""
+    (slab sums + rotary + cache store of the new token in its prologue; L counts the new token);
+    sparse = (local_blocks, vert_stride, block_size, head_sliding_step): block-sparse attention"""
     blocks_per_seq = (L + bs - 1) // bs
     nb = max(b * blocks_per_seq * 2, (640 << 20) // (2 * nkv * d * bs * (1 if kv == "fp8" else 2)))
     cdt = torch.uint8 if kv == "fp8" else torch.bfloat16
@@ -46,6 +47,9 @@ def bench(b, L, dev, kv, iters=20, nq=32, nkv=8, d=128, bs=16, fused=0):
         if fused:
             ops.paged_attention_rope_partial(out, slab, positions, cos_sin, slots[i], kc, vc, nq, nkv, d, d**-0.5,
                                              tables[i], seq_lens, bs, L, "fp8" if kv == "fp8" else "auto", 1.0)
+        elif sparse:
+            ops.paged_attention_v1(out, q, kc, vc, nkv, d**-0.5, tables[i], seq_lens, bs, L, None,
+                                   "fp8" if kv == "fp8" else "auto", 1.0, 0, sparse[0], sparse[1], sparse[2], sparse[3])
         else:
             ops.paged_attention_v1(out, q, kc, vc, nkv, d**-0.5, tables[i], seq_lens, bs, L, None,
                                    "fp8" if kv == "fp8" else "auto", 1.0)
@@ -79,15 +83,20 @@ if __name__ == "__main__":
     ap.add_argument("--kv", default="auto")
     ap.add_argument("--fused", type=int, default=0, help="also time the fused rope + cache + attention form from "
                     "this many fp32 qkv slabs")
+    ap.add_argument("--sparse", default="", help="local_blocks,vert_stride,block_size,head_sliding_step: also time "
+                    "block-sparse attention (masked windows are skipped before their K / V are loaded)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     for c in args.cases.split(","):
         b, L = (int(v) for v in c.split(":"))
         us, gbs = bench(b, L, dev, args.kv)
         extra = ""
+        if args.sparse:
+            su, _ = bench(b, L, dev, args.kv, sparse=tuple(int(v) for v in args.sparse.split(",")))
+            extra += f"   block-sparse ({args.sparse}) {su:8.1f} us"
         if args.fused:
             fu, fg = bench(b, L, dev, args.kv, fused=args.fused)
-            extra = f"   fused prologue ({args.fused} slabs) {fu:8.1f} us {fg:7.0f} GB/s"
+            extra += f"   fused prologue ({args.fused} slabs) {fu:8.1f} us {fg:7.0f} GB/s"
         print(f"attn v1 B={b:3d} L={L:5d} kv={args.kv}  {us:8.1f} us  {gbs:7.0f} GB/s{extra}", flush=True)
 
 
