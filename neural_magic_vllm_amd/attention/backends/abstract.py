@@ -1,88 +1,88 @@
-"""Attention backend ABCs (reference: vllm/attention/backends/abstract.py:9-132)."""
-from abc import ABC, abstractmethod
-from dataclasses import dataclass, fields
+"""The three classes an attention backend plugs in through (interface: reference
+vllm/attention/backends/abstract.py:9-132 -- names, signatures and the prefill / decode split of the metadata are the
+reference's, so that `Attention` layers and model code written against it work unchanged):
+
+  AttentionBackend   stateless description: name, impl class, metadata factory, KV-cache geometry and block moves
+  AttentionMetadata  what one batch (prompt tokens first, then one decode token per sequence) tells the layers
+  AttentionImpl      one layer's attention, constructed once, called per step
+"""
+import abc
+import dataclasses
 from typing import Any, Dict, Generic, List, Optional, Set, Tuple, Type, TypeVar
 
 import torch
 
 
-class AttentionBackend(ABC):
-    """Abstract class for attention backends."""
+def _required_static(fn):
+    """an abstract static method whose body is never the implementation"""
+    return staticmethod(abc.abstractmethod(fn))
 
-    @staticmethod
-    @abstractmethod
+
+class AttentionBackend(abc.ABC):
+
+    @_required_static
     def get_name() -> str:
-        raise NotImplementedError
+        ...
 
-    @staticmethod
-    @abstractmethod
+    @_required_static
     def get_impl_cls() -> Type["AttentionImpl"]:
-        raise NotImplementedError
+        ...
 
-    @staticmethod
-    @abstractmethod
+    @_required_static
     def make_metadata(*args, **kwargs) -> "AttentionMetadata":
-        raise NotImplementedError
+        ...
 
-    @staticmethod
-    @abstractmethod
-    def get_kv_cache_shape(num_blocks: int, block_size: int, num_kv_heads: int,
-                           head_size: int) -> Tuple[int, ...]:
-        raise NotImplementedError
+    @_required_static
+    def get_kv_cache_shape(num_blocks: int, block_size: int, num_kv_heads: int, head_size: int) -> Tuple[int, ...]:
+        ...
 
-    @staticmethod
-    @abstractmethod
-    def swap_blocks(src_kv_cache: torch.Tensor, dst_kv_cache: torch.Tensor,
-                    src_to_dst: torch.Tensor) -> None:
-        raise NotImplementedError
+    @_required_static
+    def swap_blocks(src_kv_cache: torch.Tensor, dst_kv_cache: torch.Tensor, src_to_dst: torch.Tensor) -> None:
+        ...
 
-    @staticmethod
-    @abstractmethod
+    @_required_static
     def copy_blocks(kv_caches: List[torch.Tensor], src_to_dists: torch.Tensor) -> None:
-        raise NotImplementedError
+        ...
 
 
-@dataclass
+@dataclasses.dataclass
 class AttentionMetadata:
-    """Attention metadata for prefill and decode batched together."""
-    # Total number of prefill requests.
+    """One batch: `num_prefills` prompts contributing `num_prefill_tokens` tokens, followed by `num_decode_tokens`
+    sequences contributing one token each; `slot_mapping[t]` = block * block_size + offset is where token t's key and
+    value go in the paged cache (negative: padding)."""
     num_prefills: int
-    # Number of prefill tokens.
     num_prefill_tokens: int
-    # Number of decode tokens (= number of decode requests: one token each).
     num_decode_tokens: int
-    # (num_tokens,) slot each token's K/V is written to: block_number * block_size + offset
     slot_mapping: torch.Tensor
 
     @property
-    @abstractmethod
+    @abc.abstractmethod
     def prefill_metadata(self) -> Optional["AttentionMetadata"]:
-        pass
+        """the prompt part of the batch as its own metadata object (None when there is none)"""
 
     @property
-    @abstractmethod
+    @abc.abstractmethod
     def decode_metadata(self) -> Optional["AttentionMetadata"]:
-        pass
+        """the decode part of the batch (None when there is none)"""
 
     def asdict_zerocopy(self, skip_fields: Optional[Set[str]] = None) -> Dict[str, Any]:
-        if skip_fields is None:
-            skip_fields = set()
-        return {f.name: getattr(self, f.name) for f in fields(self) if f.name not in skip_fields}
+        """field name -> the field's own object (no copies: tensors are shared), minus `skip_fields`"""
+        skip = skip_fields or ()
+        return {f.name: getattr(self, f.name) for f in dataclasses.fields(self) if f.name not in skip}
 
 
 T = TypeVar("T", bound=AttentionMetadata)
 
 
-class AttentionImpl(ABC, Generic[T]):
+class AttentionImpl(abc.ABC, Generic[T]):
 
-    @abstractmethod
-    def __init__(self, num_heads: int, head_size: int, scale: float,
-                 num_kv_heads: Optional[int] = None, alibi_slopes: Optional[List[float]] = None,
-                 sliding_window: Optional[int] = None, kv_cache_dtype: str = "auto",
-                 blocksparse_params: Optional[Dict[str, Any]] = None) -> None:
-        raise NotImplementedError
+    @abc.abstractmethod
+    def __init__(self, num_heads: int, head_size: int, scale: float, num_kv_heads: Optional[int] = None,
+                 alibi_slopes: Optional[List[float]] = None, sliding_window: Optional[int] = None,
+                 kv_cache_dtype: str = "auto", blocksparse_params: Optional[Dict[str, Any]] = None) -> None:
+        ...
 
-    @abstractmethod
-    def forward(self, query: torch.Tensor, key: torch.Tensor, value: torch.Tensor,
-                kv_cache: torch.Tensor, attn_metadata: T, kv_scale: float = 1.0) -> torch.Tensor:
-        raise NotImplementedError
+    @abc.abstractmethod
+    def forward(self, query: torch.Tensor, key: torch.Tensor, value: torch.Tensor, kv_cache: torch.Tensor,
+                attn_metadata: T, kv_scale: float = 1.0) -> torch.Tensor:
+        ...

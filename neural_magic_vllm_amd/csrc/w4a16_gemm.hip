@@ -728,28 +728,37 @@ __global__ __launch_bounds__(GT, 2) void w4a16_gemm_tall_kernel(const GemmParams
 
   // ---- prologue ----
   uint4 w0[KSS * WV], w1[KSS * WV], w2[KSS * WV], w3[KSS * WV];
-  uint4 ar[APT];
+  // activations travel global -> registers -> LDS TWO stages ahead of their use (round 3: with one stage, a
+  // 128-row stage is ~1000 cycles of work against ~2000 of L2 latency and every stage began by waiting for its
+  // own activations -- PMC at M = 512: 45 % of the wave cycles in s_waitcnt, profiles/r03_prefill_gemm_pmc.txt)
+  // Only the prompt-sized tiles that have the registers for a second set (64 / 128 rows, 4-bit, no zero points, at
+  // most two k groups); the others keep one stage of distance (A2 false: ar1 is ar0's alias in the code below).
+  constexpr bool A2 = MT >= 4 && WK <= 2 && BITS == 4 && !ZP && (MT < 8 || std::is_same<T, BF16>::value);   // fp16 at 128 rows: spills
+  uint4 ar0[APT], ar1[APT];
   uint4 scr = make_uint4(0, 0, 0, 0);
-  load_a(0, ar);
+  load_a(0, ar0);
   scr = load_sc(0);
   load_w(0, w0);
   load_w(1, w1);
   load_w(2, w2);
-  store_a(0, ar);
+  if constexpr (A2) load_a(1, ar1);
+  store_a(0, ar0);
   store_sc(0, scr);
   __syncthreads();
   const uint4 ones = make_uint4(W4<T>::ONES, W4<T>::ONES, W4<T>::ONES, W4<T>::ONES);
 
   // one stage (U = position in the ring: buffer parity and the scale-group schedule are static):
-  // fetch the activations of stage st+1 and the weights of stage st+3 (into the slot stage st-1
-  // just released), multiply stage st, park stage st+1's activations, barrier
+  // fetch the activations of stage st+2 and the weights of stage st+3 (into the slots stage st-1
+  // just released), multiply stage st, park stage st+1's activations (fetched one stage ago), barrier
   auto stage = [&](auto u_tag, int st, const uint4 (&wc)[KSS * WV], uint4 (&wfree)[KSS * WV]) {
     constexpr int U = decltype(u_tag)::value;
     constexpr int buf = U & 1;
     constexpr bool closes = (U + 1) % SPG == 0;   // last stage of a scale group
     // scale buffer of this stage's group: static for 2 groups per ring, else by ring parity
     const int gbuf = SPG == 2 ? ((U >> 1) & 1) : ((st >> 2) & 1);
-    load_a(st + 1, ar);
+    if constexpr (!A2) load_a(st + 1, ar0);
+    else if constexpr ((U & 1) == 0) load_a(st + 2, ar0);
+    else load_a(st + 2, ar1);
     if constexpr (closes) scr = load_sc(st + 1);  // the next stage opens a group
     load_w(st + 3, wfree);
     __builtin_amdgcn_sched_barrier(0);
@@ -835,7 +844,8 @@ __global__ __launch_bounds__(GT, 2) void w4a16_gemm_tall_kernel(const GemmParams
       }
     }
     __builtin_amdgcn_sched_barrier(0);
-    store_a(buf ^ 1, ar);
+    if constexpr (!A2 || (U & 1) == 1) store_a(buf ^ 1, ar0);
+    else store_a(buf ^ 1, ar1);
     if constexpr (closes) store_sc(gbuf ^ 1, scr);
     __syncthreads();
   };

@@ -1,33 +1,33 @@
-"""vllm/distributed/communication_op.py:1-33: thin wrappers over the TP group."""
+"""The collectives model code calls (interface: reference vllm/distributed/communication_op.py:1-33): each forwards to
+the tensor-parallel group's method of the same meaning -- RCCL over xGMI, or the P2P path of ../custom_all_reduce.py --
+and is the identity when no group exists (a single-GPU run never initialises one)."""
 from typing import Any, Dict, Optional, Union
 
 import torch
 
-from .parallel_state import get_tp_group, model_parallel_is_initialized
+from . import parallel_state as _ps
+
+
+def _group_or_none():
+    return _ps.get_tp_group() if _ps.model_parallel_is_initialized() else None
 
 
 def tensor_model_parallel_all_reduce(input_: torch.Tensor) -> torch.Tensor:
-    """All-reduce the input tensor across the tensor-parallel group (RCCL over xGMI)."""
-    if not model_parallel_is_initialized():
-        return input_
-    return get_tp_group().all_reduce(input_)
+    group = _group_or_none()
+    return input_ if group is None else group.all_reduce(input_)
 
 
 def tensor_model_parallel_all_gather(input_: torch.Tensor, dim: int = -1) -> torch.Tensor:
-    if not model_parallel_is_initialized():
-        return input_
-    return get_tp_group().all_gather(input_, dim)
+    group = _group_or_none()
+    return input_ if group is None else group.all_gather(input_, dim)
 
 
-def tensor_model_parallel_gather(input_: torch.Tensor, dst: int = 0,
-                                 dim: int = -1) -> Optional[torch.Tensor]:
-    if not model_parallel_is_initialized():
-        return input_
-    return get_tp_group().gather(input_, dst, dim)
+def tensor_model_parallel_gather(input_: torch.Tensor, dst: int = 0, dim: int = -1) -> Optional[torch.Tensor]:
+    """rank `dst` receives the concatenation along `dim`, every other rank None"""
+    group = _group_or_none()
+    return input_ if group is None else group.gather(input_, dst, dim)
 
 
-def broadcast_tensor_dict(tensor_dict: Optional[Dict[Any, Union[torch.Tensor, Any]]] = None,
-                          src: int = 0):
-    if not model_parallel_is_initialized():
-        return tensor_dict
-    return get_tp_group().broadcast_tensor_dict(tensor_dict, src)
+def broadcast_tensor_dict(tensor_dict: Optional[Dict[Any, Union[torch.Tensor, Any]]] = None, src: int = 0):
+    group = _group_or_none()
+    return tensor_dict if group is None else group.broadcast_tensor_dict(tensor_dict, src)

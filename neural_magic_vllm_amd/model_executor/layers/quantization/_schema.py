@@ -21,10 +21,20 @@ class Geometry:
     k: int                    # input features on this rank
     parts: Tuple[int, ...]    # output features of each logical matrix on this rank
     dtype: torch.dtype        # model dtype
+    k_total: Optional[int] = None   # input features across all ranks (None: same as k)
 
     @property
     def n(self) -> int:
         return sum(self.parts)
+
+    @property
+    def k_all(self) -> int:
+        return self.k if self.k_total is None else self.k_total
+
+    @property
+    def row_sharded(self) -> bool:
+        """this rank holds a slice of the input dimension (a row-parallel layer under TP > 1)"""
+        return self.k_all != self.k
 
 
 @dataclass(frozen=True)
@@ -42,6 +52,8 @@ class Slot:
     dtype: Union[torch.dtype, Callable[[Geometry], torch.dtype]]
     attrs: Callable[[Geometry], Dict[str, Any]] = lambda g: {}
     fill: Optional[Union[str, float]] = None      # None: uninitialised, "zeros", or a value
+    init: Optional[Callable[[Geometry], torch.Tensor]] = None   # the initial contents, when they are not a constant
+    device: Optional[str] = None                  # "meta": declared for the loader's sake, never materialised
 
 
 def build(layer: torch.nn.Module, geometry: Geometry, requires: List[Require], slots: List[Slot],
@@ -52,9 +64,14 @@ def build(layer: torch.nn.Module, geometry: Geometry, requires: List[Require], s
     for s in slots:
         dt = s.dtype(geometry) if callable(s.dtype) else s.dtype
         shape = tuple(s.shape(geometry))
-        data = torch.zeros(shape, dtype=dt) if s.fill == "zeros" else torch.empty(shape, dtype=dt)
-        if s.fill is not None and s.fill != "zeros":
-            data[...] = s.fill
+        if s.init is not None:
+            data = s.init(geometry).to(dt)
+            assert tuple(data.shape) == shape, (s.name, tuple(data.shape), shape)
+        else:
+            data = (torch.zeros(shape, dtype=dt, device=s.device) if s.fill == "zeros"
+                    else torch.empty(shape, dtype=dt, device=s.device))
+            if s.fill is not None and s.fill != "zeros":
+                data[...] = s.fill
         p = Parameter(data, requires_grad=False)
         layer.register_parameter(s.name, p)
         set_weight_attrs(p, s.attrs(geometry))

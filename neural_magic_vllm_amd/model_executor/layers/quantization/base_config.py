@@ -1,101 +1,101 @@
-"""The quantization plugin surface (reference: vllm/model_executor/layers/quantization/
-base_config.py:8-118).  Same abstract methods, so a config / linear method written against the
-reference plugs in unchanged."""
-from abc import ABC, abstractmethod
+"""The quantisation plugin surface (interface: reference vllm/model_executor/layers/quantization/base_config.py:8-118
+and the `LinearMethodBase` of linear.py:69-100).  A format is two objects:
+
+  QuantizationConfig   parsed from the checkpoint's quantisation json; says which layers it takes and with what method
+  QuantizeMethodBase   per layer: declares the parameters a checkpoint fills (`create_weights`), optionally rewrites
+                       them once after loading (`process_weights_after_loading`), and runs the layer (`apply`)
+
+Method names, arguments and the meaning of every return value are the reference's, so a config / method pair written
+against it plugs in here unchanged (tests/golden/linear_method_params.json pins the parameter tables of the eleven
+pairs this package ships)."""
+import abc
 from typing import Any, Dict, List, Optional
 
 import torch
 from torch import nn
 
+_MISSING = object()
 
-class QuantizeMethodBase(ABC):
-    """Base class for different quantized methods."""
 
-    @abstractmethod
+class QuantizeMethodBase(abc.ABC):
+
+    @abc.abstractmethod
     def create_weights(self, layer: torch.nn.Module, *weight_args, **extra_weight_attrs):
-        """Create weights for a layer; they are set as attributes of the layer."""
-        raise NotImplementedError
+        """register the layer's parameters on `layer` (attributes named as the checkpoint names them)"""
 
-    @abstractmethod
+    @abc.abstractmethod
     def apply(self, layer: torch.nn.Module, *args, **kwargs) -> torch.Tensor:
-        """Apply the weights in layer to the input tensor."""
-        raise NotImplementedError
+        """the layer's forward on the parameters `create_weights` registered"""
 
     def process_weights_after_loading(self, layer: nn.Module) -> None:
-        """Hook run once the checkpoint is loaded (transposes, requantisation, ...)."""
-        return
+        """once per layer after the checkpoint is in: repacks, transposes, requantisation.  Default: nothing."""
 
 
 class LinearMethodBase(QuantizeMethodBase):
-    """Base class for (maybe quantized) linear methods (reference: linear.py:69-100; it lives
-    here so that quantisation modules can subclass it without importing linear.py)."""
+    """methods of a linear layer (lives here, not in linear.py, so that a format module never imports linear.py)"""
 
-    @abstractmethod
-    def create_weights(self, layer: torch.nn.Module, input_size_per_partition: int,
-                       output_partition_sizes: List[int], input_size: int, output_size: int,
-                       params_dtype: torch.dtype, **extra_weight_attrs):
-        """Create the layer's parameters.
+    @abc.abstractmethod
+    def create_weights(self, layer: torch.nn.Module, input_size_per_partition: int, output_partition_sizes: List[int],
+                       input_size: int, output_size: int, params_dtype: torch.dtype, **extra_weight_attrs):
+        """`input_size_per_partition`: K on this rank; `output_partition_sizes`: this rank's width of every logical
+        matrix fused into the layer ([q, k, v] for QKVParallelLinear, [gate, up] for the MLP, one entry otherwise);
+        `input_size` / `output_size`: the unsharded dimensions; `extra_weight_attrs`: attributes (the weight loader
+        among them) to set on every parameter"""
 
-        input_size_per_partition: weight input dim on this rank; output_partition_sizes: output
-        dim of each logical matrix on this rank (e.g. [q, k, v] widths for QKVParallelLinear);
-        input_size / output_size: dims across all ranks."""
-        raise NotImplementedError
-
-    @abstractmethod
-    def apply(self, layer: torch.nn.Module, x: torch.Tensor,
-              bias: Optional[torch.Tensor] = None) -> torch.Tensor:
-        raise NotImplementedError
+    @abc.abstractmethod
+    def apply(self, layer: torch.nn.Module, x: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """x [..., K] -> [..., sum(output_partition_sizes)] (+ bias)"""
 
 
-class QuantizationConfig(ABC):
-    """Base class for quantization configs."""
+class QuantizationConfig(abc.ABC):
 
-    @abstractmethod
+    # ---- identity and admission ---------------------------------------------------------------------------
+    @abc.abstractmethod
     def get_name(self) -> str:
-        raise NotImplementedError
+        """the `quantization=` / `quant_method` string"""
 
-    @abstractmethod
+    @abc.abstractmethod
     def get_supported_act_dtypes(self) -> List[torch.dtype]:
-        raise NotImplementedError
+        ...
 
     @classmethod
-    @abstractmethod
+    @abc.abstractmethod
     def get_min_capability(cls) -> int:
-        """Minimum device capability (gfx950 reports 95, see platforms.py)."""
-        raise NotImplementedError
+        """lowest device capability (major * 10 + minor) that may run it; gfx950 reports 95 (platforms.py)"""
 
     @staticmethod
-    @abstractmethod
+    @abc.abstractmethod
     def get_config_filenames() -> List[str]:
-        raise NotImplementedError
+        """files of a checkpoint directory to search for the quantisation json when config.json carries none"""
 
+    # ---- construction -----------------------------------------------------------------------------------------
     @classmethod
-    @abstractmethod
+    @abc.abstractmethod
     def from_config(cls, config: Dict[str, Any]) -> "QuantizationConfig":
-        raise NotImplementedError
+        ...
 
     @classmethod
     def override_quantization_method(cls, hf_quant_cfg, user_quant) -> Optional[str]:
+        """a format may claim a checkpoint written for another one (gptq -> gptq_marlin): its name, or None"""
         return None
 
     @staticmethod
     def get_from_keys(config: Dict[str, Any], keys: List[str]) -> Any:
-        for key in keys:
-            if key in config:
-                return config[key]
-        raise ValueError(f"Cannot find any of {keys} in the model's quantization config.")
+        """the value of the first of `keys` the json has"""
+        found = next((config[k] for k in keys if k in config), _MISSING)
+        if found is _MISSING:
+            raise ValueError(f"Cannot find any of {keys} in the model's quantization config.")
+        return found
 
     @staticmethod
     def get_from_keys_or(config: Dict[str, Any], keys: List[str], default: Any) -> Any:
-        try:
-            return QuantizationConfig.get_from_keys(config, keys)
-        except ValueError:
-            return default
+        return next((config[k] for k in keys if k in config), default)
 
-    @abstractmethod
+    # ---- per layer ------------------------------------------------------------------------------------------------
+    @abc.abstractmethod
     def get_quant_method(self, layer: torch.nn.Module) -> Optional[QuantizeMethodBase]:
-        raise NotImplementedError
+        """the method for `layer`, or None when this format leaves the layer alone"""
 
-    @abstractmethod
+    @abc.abstractmethod
     def get_scaled_act_names(self) -> List[str]:
-        raise NotImplementedError
+        """activation functions that need a learned post-scale under this format"""

@@ -1,14 +1,21 @@
-"""GPTQ-Marlin (W4A16 / W8A16) quantisation method on the gfx950 kernels.
+"""GPTQ checkpoints on the Marlin kernel: W4A16 / W8A16, symmetric, group 32 / 64 / 128 or channelwise, with or
+without act-order -- the method of the headline path (interface and checkpoint contract: reference
+vllm/model_executor/layers/quantization/gptq_marlin.py:59-184 config, :192-466 linear method; parameter table pinned
+by tests/golden/linear_method_params.json["gptq_marlin"]).
 
-Plugin-surface mirror of vllm/model_executor/layers/quantization/gptq_marlin.py: GPTQMarlinConfig
-(:59-184), GPTQMarlinLinearMethod (:192-466) -- same parameter names / shapes / sharding
-attributes (qweight int32 [K/pack, N], g_idx int32 [K], scales [K/g, N], qzeros on `meta`,
-workspace int32 [N/64*16]) and the same lazy REPACK -> READY state machine on the first apply().
-The two native ops it calls, ops.gptq_marlin_repack and ops.gptq_marlin_gemm, are the HIP
-kernels of csrc/w4a16_gemm.hip.
-"""
+Life of a layer
+  create_weights   the GPTQ checkpoint tensors: qweight int32 [K / pack, N], scales [K / g, N], g_idx int32 [K], qzeros
+                   (declared on `meta`: symmetric checkpoints carry them, nobody reads them), a ticket array `workspace`
+  first call       state REPACK -> READY: act-order sort of g_idx, `gptq_marlin_repack` of the codes into the Marlin
+                   interchange tensor (in place, the parameter keeps its storage), `marlin_permute_scales`
+  every call       `gptq_marlin_gemm` (csrc/w4a16_stream.hip up to 64 rows, csrc/w4a16_gemm.hip beyond)
+
+Beyond the reference's LinearMethod (used by the decode harness, each bit-identical to `apply` + the op it absorbs;
+DESIGN.md 3.2): `apply_partial` leaves the split-K reduction to the next launch, `apply_silu_mul` folds silu_and_mul
+into the gate_up GEMM's epilogue on column-interleaved weights, and an optional MFMA-native copy of the codes
+(NMV_W4_NATIVE=1) serves decode-sized calls."""
 import enum
-from enum import Enum
+import os
 from typing import Any, Dict, List, Optional
 
 import torch
@@ -16,9 +23,10 @@ from torch.nn.parameter import Parameter
 
 from .... import _custom_ops as ops
 from ....platforms import current_platform
-from ...utils import set_weight_attrs
+from ._schema import Geometry, Require, Slot, build
 from .base_config import LinearMethodBase, QuantizationConfig
 
+# geometry of the Marlin interchange format (gptq_marlin.py:14-23)
 GPTQ_MARLIN_TILE = 16
 GPTQ_MARLIN_MIN_THREAD_N = 64
 GPTQ_MARLIN_MIN_THREAD_K = 128
@@ -30,10 +38,11 @@ GPTQ_MARLIN_SUPPORTED_SYM = [True]
 
 
 def get_scale_perms(num_bits: int):
-    """gptq_marlin.py:26-35: where each output column's scale sits inside a 64- / 32-wide run"""
-    scale_perm = [i + 8 * j for i in range(8) for j in range(8)]
-    scale_perm_single = [2 * i + j for i in range(4) for j in [0, 1, 8, 9, 16, 17, 24, 25]]
-    return scale_perm, scale_perm_single
+    """column orders of `marlin_permute_scales` (gptq_marlin.py:26-35): inside a run of 64 columns for grouped scales,
+    of 32 for channelwise ones -- the 8 columns an MMA lane needs end up contiguous"""
+    grouped = [i + 8 * j for i in range(8) for j in range(8)]
+    single = [2 * i + j for i in range(4) for j in (0, 1, 8, 9, 16, 17, 24, 25)]
+    return grouped, single
 
 
 def get_pack_factor(num_bits: int):
@@ -41,44 +50,36 @@ def get_pack_factor(num_bits: int):
     return 32 // num_bits
 
 
-def marlin_permute_scales(s: torch.Tensor, size_k: int, size_n: int, group_size: int,
-                          num_bits: int):
-    """gptq_marlin.py:47-56"""
-    scale_perm, scale_perm_single = get_scale_perms(num_bits)
-    if group_size < size_k and group_size != -1:
-        s = s.reshape((-1, len(scale_perm)))[:, scale_perm]
-    else:
-        s = s.reshape((-1, len(scale_perm_single)))[:, scale_perm_single]
-    return s.reshape((-1, size_n)).contiguous()
+def marlin_permute_scales(s: torch.Tensor, size_k: int, size_n: int, group_size: int, num_bits: int):
+    """[groups, N] scales in natural column order -> the order the kernel reads (gptq_marlin.py:47-56)"""
+    grouped, single = get_scale_perms(num_bits)
+    order = grouped if (group_size != -1 and group_size < size_k) else single
+    return s.reshape(-1, len(order))[:, order].reshape(-1, size_n).contiguous()
+
+
+_SUPPORT = (   # (json key, attribute, admitted values) -- one table for the constructor and `is_marlin_compatible`
+    ("bits", "weight_bits", GPTQ_MARLIN_SUPPORTED_NUM_BITS),
+    ("group_size", "group_size", GPTQ_MARLIN_SUPPORTED_GROUP_SIZES),
+    ("sym", "is_sym", GPTQ_MARLIN_SUPPORTED_SYM),
+)
 
 
 class GPTQMarlinConfig(QuantizationConfig):
-    """Config class for GPTQ Marlin"""
+    """`quantize_config.json`: {"bits": 4|8, "group_size": -1|32|64|128, "desc_act": bool, "sym": true, "lm_head": bool}"""
 
-    def __init__(self, weight_bits: int, group_size: int, desc_act: bool, is_sym: bool,
-                 lm_head_quantized: bool) -> None:
-        if desc_act and group_size == -1:
-            # one group per output channel: act_order is a no-op
-            desc_act = False
-        self.weight_bits = weight_bits
-        self.group_size = group_size
-        self.desc_act = desc_act
-        self.is_sym = is_sym
+    def __init__(self, weight_bits: int, group_size: int, desc_act: bool, is_sym: bool, lm_head_quantized: bool) -> None:
+        self.weight_bits, self.group_size, self.is_sym = weight_bits, group_size, is_sym
+        self.desc_act = desc_act and group_size != -1      # one group per column: act-order is the identity
         self.lm_head_quantized = lm_head_quantized
-        if self.weight_bits not in GPTQ_MARLIN_SUPPORTED_NUM_BITS:
-            raise ValueError(f"Marlin does not support weight_bits = {self.weight_bits}. "
-                             f"Only weight_bits = {GPTQ_MARLIN_SUPPORTED_NUM_BITS} are supported.")
-        if self.group_size not in GPTQ_MARLIN_SUPPORTED_GROUP_SIZES:
-            raise ValueError(f"Marlin does not support group_size = {self.group_size}. "
-                             f"Only group_sizes = {GPTQ_MARLIN_SUPPORTED_GROUP_SIZES} are supported.")
-        if self.is_sym not in GPTQ_MARLIN_SUPPORTED_SYM:
-            raise ValueError(f"Marlin does not support is_sym = {self.is_sym}. "
-                             f"Only sym = {GPTQ_MARLIN_SUPPORTED_SYM} are supported.")
+        messages = {"weight_bits": "Marlin does not support weight_bits = {v}. Only weight_bits = {ok} are supported.",
+                    "group_size": "Marlin does not support group_size = {v}. Only group_sizes = {ok} are supported.",
+                    "is_sym": "Marlin does not support is_sym = {v}. Only sym = {ok} are supported."}
+        for _, attr, admitted in _SUPPORT:
+            if getattr(self, attr) not in admitted:
+                raise ValueError(messages[attr].format(v=getattr(self, attr), ok=admitted))
         self.pack_factor = get_pack_factor(weight_bits)
-        self.tile_size = GPTQ_MARLIN_TILE
-        self.min_thread_n = GPTQ_MARLIN_MIN_THREAD_N
-        self.min_thread_k = GPTQ_MARLIN_MIN_THREAD_K
-        self.max_parallel = GPTQ_MARLIN_MAX_PARALLEL
+        self.tile_size, self.max_parallel = GPTQ_MARLIN_TILE, GPTQ_MARLIN_MAX_PARALLEL
+        self.min_thread_n, self.min_thread_k = GPTQ_MARLIN_MIN_THREAD_N, GPTQ_MARLIN_MIN_THREAD_K
 
     def __repr__(self) -> str:
         return (f"GPTQMarlinConfig(weight_bits={self.weight_bits}, group_size={self.group_size}, "
@@ -94,7 +95,7 @@ class GPTQMarlinConfig(QuantizationConfig):
 
     @classmethod
     def get_min_capability(cls) -> int:
-        return 80  # gfx950 reports 95
+        return 80   # gfx950 reports 95
 
     @classmethod
     def get_config_filenames(cls) -> List[str]:
@@ -102,211 +103,207 @@ class GPTQMarlinConfig(QuantizationConfig):
 
     @classmethod
     def from_config(cls, config: Dict[str, Any]) -> "GPTQMarlinConfig":
-        weight_bits = cls.get_from_keys(config, ["bits"])
-        group_size = cls.get_from_keys(config, ["group_size"])
-        desc_act = cls.get_from_keys(config, ["desc_act"])
-        is_sym = cls.get_from_keys(config, ["sym"])
-        lm_head_quantized = cls.get_from_keys_or(config, ["lm_head"], default=False)
-        return cls(weight_bits, group_size, desc_act, is_sym, lm_head_quantized)
-
-    @classmethod
-    def override_quantization_method(cls, hf_quant_cfg, user_quant) -> Optional[str]:
-        can_convert = cls.is_marlin_compatible(hf_quant_cfg)
-        is_valid_user_quant = (user_quant is None or user_quant == "marlin")
-        if can_convert and is_valid_user_quant:
-            return cls.get_name()
-        return None
-
-    def get_quant_method(self, layer: torch.nn.Module) -> Optional["GPTQMarlinLinearMethod"]:
-        from ..linear import LinearBase
-        from ..vocab_parallel_embedding import ParallelLMHead
-        if isinstance(layer, LinearBase) or (isinstance(layer, ParallelLMHead)
-                                             and self.lm_head_quantized):
-            return GPTQMarlinLinearMethod(self)
-        return None
-
-    def get_scaled_act_names(self) -> List[str]:
-        return []
+        required = {k: cls.get_from_keys(config, [k]) for k in ("bits", "group_size", "desc_act", "sym")}
+        return cls(required["bits"], required["group_size"], required["desc_act"], required["sym"],
+                   cls.get_from_keys_or(config, ["lm_head"], default=False))
 
     @classmethod
     def is_marlin_compatible(cls, quant_config: Dict[str, Any]):
-        num_bits = quant_config.get("bits", None)
-        group_size = quant_config.get("group_size", None)
-        sym = quant_config.get("sym", None)
-        desc_act = quant_config.get("desc_act", None)
-        if num_bits is None or group_size is None or sym is None or desc_act is None:
+        """can a checkpoint written for plain GPTQ run here (gptq_marlin.py:160-184)"""
+        if any(quant_config.get(key) is None for key in ("bits", "group_size", "sym", "desc_act")):
             return False
         major, minor = current_platform.get_device_capability()
         if major * 10 + minor < cls.get_min_capability():
             return False
-        return (num_bits in GPTQ_MARLIN_SUPPORTED_NUM_BITS
-                and group_size in GPTQ_MARLIN_SUPPORTED_GROUP_SIZES
-                and sym in GPTQ_MARLIN_SUPPORTED_SYM)
+        return all(quant_config[key] in admitted for key, _, admitted in _SUPPORT)
+
+    @classmethod
+    def override_quantization_method(cls, hf_quant_cfg, user_quant) -> Optional[str]:
+        """a `gptq` checkpoint is claimed when it is compatible and the user did not insist on something else"""
+        user_agrees = user_quant in (None, "marlin")
+        return cls.get_name() if cls.is_marlin_compatible(hf_quant_cfg) and user_agrees else None
+
+    def get_quant_method(self, layer: torch.nn.Module) -> Optional["GPTQMarlinLinearMethod"]:
+        from ..linear import LinearBase
+        from ..vocab_parallel_embedding import ParallelLMHead
+        takes = isinstance(layer, LinearBase) or (self.lm_head_quantized and isinstance(layer, ParallelLMHead))
+        return GPTQMarlinLinearMethod(self) if takes else None
+
+    def get_scaled_act_names(self) -> List[str]:
+        return []
+
+    # ---- the schema -----------------------------------------------------------------------------------------
+    def _group(self, g: Geometry) -> int:
+        return g.k_all if self.group_size == -1 else self.group_size
+
+    def _groups_sliced(self, g: Geometry) -> bool:
+        """a row-parallel shard keeps only its own groups -- unless act-order, whose g_idx may name any group"""
+        return g.row_sharded and self.group_size != -1 and not self.desc_act
+
+    def is_k_full(self, g: Geometry) -> bool:
+        return not (self.desc_act and g.row_sharded)
+
+    def requirements(self) -> List[Require]:
+        def divisible(what: str, value, unit_name: str, unit, spaces: str = " ") -> Require:
+            return Require(lambda g: value(g) % unit(g) == 0,
+                           lambda g: f"Weight {what} = {value(g)} is not divisible by{spaces}{unit_name} = {unit(g)}.")
+
+        return [
+            Require(lambda g: g.dtype in (torch.float16, torch.bfloat16),
+                    lambda g: f"The params dtype must be float16 or bfloat16, but got {g.dtype}"),
+            divisible("output_size_per_partition", lambda g: g.n, "min_thread_n", lambda g: self.min_thread_n, "  "),
+            divisible("input_size_per_partition", lambda g: g.k, "min_thread_k", lambda g: self.min_thread_k),
+            Require(lambda g: self._group(g) >= g.k_all or g.k % self._group(g) == 0,
+                    lambda g: f"Weight input_size_per_partition = {g.k} is not divisible by group_size = {self._group(g)}."),
+        ]
+
+    def slots(self) -> List[Slot]:
+        pack = self.pack_factor
+
+        def groups(g: Geometry) -> int:
+            return (g.k if self._groups_sliced(g) else g.k_all) // self._group(g)
+
+        def group_axis(g: Geometry) -> Optional[int]:
+            return 0 if self._groups_sliced(g) else None
+
+        return [
+            Slot("qweight", lambda g: (g.k // pack, g.n), torch.int32,
+                 lambda g: {"input_dim": 0, "output_dim": 1, "packed_dim": 0, "pack_factor": pack}),
+            Slot("g_idx", lambda g: (g.k, ), torch.int32, lambda g: {"input_dim": 0, "ignore_warning": True}),
+            Slot("scales", lambda g: (groups(g), g.n), lambda g: g.dtype,
+                 lambda g: {"input_dim": group_axis(g), "output_dim": 1}),
+            Slot("qzeros", lambda g: (groups(g), g.n // pack), torch.int32,
+                 lambda g: {"input_dim": group_axis(g), "output_dim": 1, "packed_dim": 1, "pack_factor": pack},
+                 device="meta"),
+        ]
 
 
-class GPTQMarlinState(Enum):
-    REPACK = enum.auto()
-    READY = enum.auto()
+class GPTQMarlinState(enum.Enum):
+    REPACK = enum.auto()    # parameters still hold the GPTQ checkpoint layout
+    READY = enum.auto()     # parameters hold the Marlin interchange layout
+
+
+def _overwrite(param: torch.Tensor, new: torch.Tensor) -> None:
+    """new contents and shape, same registered parameter (its storage is resized, not replaced)"""
+    param.resize_(new.shape)
+    param.copy_(new)
+
+
+def _empty_index(device) -> Parameter:
+    return Parameter(torch.empty(0, dtype=torch.int, device=device), requires_grad=False)
 
 
 class GPTQMarlinLinearMethod(LinearMethodBase):
-    """Linear method for GPTQ Marlin."""
+
+    NATIVE_MAX_M = 64   # rows per call up to which the MFMA-native copy is used (its M tiles end at 64 rows)
 
     def __init__(self, quant_config: GPTQMarlinConfig) -> None:
         self.quant_config = quant_config
 
-    def create_weights(self, layer: torch.nn.Module, input_size_per_partition: int,
-                       output_partition_sizes: List[int], input_size: int, output_size: int,
-                       params_dtype: torch.dtype, **extra_weight_attrs) -> None:
-        del output_size
+    def create_weights(self, layer: torch.nn.Module, input_size_per_partition: int, output_partition_sizes: List[int],
+                       input_size: int, output_size: int, params_dtype: torch.dtype, **extra_weight_attrs) -> None:
         cfg = self.quant_config
-        group_size = cfg.group_size if cfg.group_size != -1 else input_size
-        if params_dtype not in [torch.float16, torch.bfloat16]:
-            raise ValueError(f"The params dtype must be float16 or bfloat16, but got {params_dtype}")
-        output_size_per_partition = sum(output_partition_sizes)
-        if output_size_per_partition % cfg.min_thread_n != 0:
-            raise ValueError(f"Weight output_size_per_partition = {output_size_per_partition} is "
-                             f"not divisible by  min_thread_n = {cfg.min_thread_n}.")
-        if input_size_per_partition % cfg.min_thread_k != 0:
-            raise ValueError(f"Weight input_size_per_partition = {input_size_per_partition} is "
-                             f"not divisible by min_thread_k = {cfg.min_thread_k}.")
-        if group_size < input_size and input_size_per_partition % group_size != 0:
-            raise ValueError(f"Weight input_size_per_partition = {input_size_per_partition} is "
-                             f"not divisible by group_size = {group_size}.")
-        # sharding of scales / zero points over the input dim (gptq_marlin.py:246-269)
-        scales_and_zp_size = input_size // group_size
-        scales_and_zp_input_dim = None
-        if cfg.desc_act:
-            assert cfg.group_size != -1
-            is_k_full = input_size_per_partition == input_size
-        else:
-            is_k_full = True
-            if input_size != input_size_per_partition and cfg.group_size != -1:
-                scales_and_zp_size = input_size_per_partition // group_size
-                scales_and_zp_input_dim = 0
-
-        qweight = Parameter(torch.empty(input_size_per_partition // cfg.pack_factor,
-                                        output_size_per_partition, dtype=torch.int32),
-                            requires_grad=False)
-        set_weight_attrs(qweight, {**extra_weight_attrs, "input_dim": 0, "output_dim": 1,
-                                   "packed_dim": 0, "pack_factor": cfg.pack_factor})
-        g_idx = Parameter(torch.empty(input_size_per_partition, dtype=torch.int32),
-                          requires_grad=False)
-        set_weight_attrs(g_idx, {**extra_weight_attrs, "input_dim": 0, "ignore_warning": True})
-        g_idx_sort_indices = torch.empty(g_idx.shape, dtype=torch.int32)
-        scales = Parameter(torch.empty(scales_and_zp_size, output_size_per_partition,
-                                       dtype=params_dtype), requires_grad=False)
-        set_weight_attrs(scales, {**extra_weight_attrs, "input_dim": scales_and_zp_input_dim,
-                                  "output_dim": 1})
-        qzeros = Parameter(torch.empty(scales_and_zp_size,
-                                       output_size_per_partition // cfg.pack_factor,
-                                       dtype=torch.int32, device="meta"), requires_grad=False)
-        set_weight_attrs(qzeros, {**extra_weight_attrs, "input_dim": scales_and_zp_input_dim,
-                                  "output_dim": 1, "packed_dim": 1,
-                                  "pack_factor": cfg.pack_factor})
-        max_workspace_size = (output_size_per_partition // cfg.min_thread_n) * cfg.max_parallel
-        workspace = torch.zeros(max_workspace_size, dtype=torch.int, requires_grad=False)
-
-        layer.register_parameter("qweight", qweight)
-        layer.register_parameter("g_idx", g_idx)
-        layer.register_parameter("scales", scales)
-        layer.register_parameter("qzeros", qzeros)
-        layer.g_idx_sort_indices = g_idx_sort_indices
-        layer.workspace = workspace
-        layer.input_size_per_partition = input_size_per_partition
-        layer.output_size_per_partition = output_size_per_partition
-        layer.input_size = input_size
-        layer.is_k_full = is_k_full
+        g = Geometry(input_size_per_partition, tuple(output_partition_sizes), params_dtype, k_total=input_size)
+        build(layer, g, cfg.requirements(), cfg.slots(), extra_weight_attrs)
+        assert not cfg.desc_act or cfg.group_size != -1
+        # plain attributes (not checkpoint tensors): the act-order permutation, the split-K tickets, the geometry
+        layer.g_idx_sort_indices = torch.empty(g.k, dtype=torch.int32)
+        layer.workspace = torch.zeros((g.n // cfg.min_thread_n) * cfg.max_parallel, dtype=torch.int)
+        layer.input_size_per_partition, layer.output_size_per_partition, layer.input_size = g.k, g.n, g.k_all
+        layer.is_k_full = cfg.is_k_full(g)
         layer.marlin_state = GPTQMarlinState.REPACK
 
+    # ---- first call: GPTQ layout -> Marlin layout (gptq_marlin.py:389-447) ------------------------------------------
     def _repack(self, layer: torch.nn.Module) -> None:
-        """first-touch GPTQ -> Marlin conversion (gptq_marlin.py:389-447)"""
         cfg = self.quant_config
-        part_size_n = layer.output_size_per_partition
-        part_size_k = layer.input_size_per_partition
-
-        def replace_tensor(name, new_t):
-            # resize_ + copy_ keep the registered parameter's storage
-            getattr(layer, name).resize_(new_t.shape)
-            getattr(layer, name).copy_(new_t)
-            del new_t
-
-        cur_device = layer.qweight.device
-        if layer.workspace.device != cur_device:
-            layer.workspace = layer.workspace.to(cur_device)
-        if cfg.desc_act:
-            g_idx_sort_indices = torch.argsort(layer.g_idx).to(torch.int)
-            sorted_g_idx = layer.g_idx[g_idx_sort_indices]
-            layer.g_idx_sort_indices = layer.g_idx_sort_indices.to(cur_device)
-            replace_tensor("g_idx", sorted_g_idx)
-            replace_tensor("g_idx_sort_indices", g_idx_sort_indices)
+        k, n = layer.input_size_per_partition, layer.output_size_per_partition
+        dev = layer.qweight.device
+        layer.workspace = layer.workspace.to(dev)
+        if cfg.desc_act:    # rows sorted by group: the kernel walks whole groups, `perm` gathers the activations
+            order = torch.argsort(layer.g_idx).to(torch.int)
+            layer.g_idx_sort_indices = layer.g_idx_sort_indices.to(dev)
+            _overwrite(layer.g_idx, layer.g_idx[order])
+            _overwrite(layer.g_idx_sort_indices, order)
         else:
-            layer.g_idx = Parameter(torch.empty(0, dtype=torch.int, device=cur_device),
-                                    requires_grad=False)
-            layer.g_idx_sort_indices = Parameter(torch.empty(0, dtype=torch.int, device=cur_device),
-                                                 requires_grad=False)
-        # decode-sized calls run on the MFMA-native tensor (csrc/w4a16_gemm.hip): built here from the same GPTQ
-        # words, beside the Marlin tensor that the reference's op (and prefill) consumes
-        if self.native_eligible(layer):
-            layer.qweight_native = ops.w4_native_repack(layer.qweight.data, None, part_size_k, part_size_n)
+            layer.g_idx, layer.g_idx_sort_indices = _empty_index(dev), _empty_index(dev)
+        if self.native_eligible(layer):   # built from the same GPTQ words, beside the Marlin tensor
+            layer.qweight_native = ops.w4_native_repack(layer.qweight.data, None, k, n)
             layer.scales_native = layer.scales.data.clone()      # natural [groups, N]
-        marlin_qweight = ops.gptq_marlin_repack(layer.qweight, layer.g_idx_sort_indices,
-                                                part_size_k, part_size_n, cfg.weight_bits)
-        replace_tensor("qweight", marlin_qweight)
-        scales_size_k = layer.input_size if cfg.desc_act else part_size_k
-        marlin_scales = marlin_permute_scales(layer.scales, scales_size_k, part_size_n,
-                                              cfg.group_size, cfg.weight_bits)
-        replace_tensor("scales", marlin_scales)
+        _overwrite(layer.qweight, ops.gptq_marlin_repack(layer.qweight, layer.g_idx_sort_indices, k, n, cfg.weight_bits))
+        scales_k = layer.input_size if cfg.desc_act else k
+        _overwrite(layer.scales, marlin_permute_scales(layer.scales, scales_k, n, cfg.group_size, cfg.weight_bits))
 
-    NATIVE_MAX_M = 64   # rows per call up to which the native kernel is used (its M tiles end at 64 rows)
+    def _ready(self, layer: torch.nn.Module, interleave_gate_up: bool = False) -> None:
+        if layer.marlin_state is not GPTQMarlinState.REPACK:
+            return
+        if interleave_gate_up:
+            assert self.can_fuse_silu_mul(layer)
+        layer.marlin_state = GPTQMarlinState.READY
+        if interleave_gate_up:
+            layer.qweight.data = self._interleave_gate_up(layer.qweight.data)
+            layer.scales.data = self._interleave_gate_up(layer.scales.data)
+            layer.gate_up_interleaved = True
+        self._repack(layer)
 
-    def native_eligible(self, layer: torch.nn.Module) -> bool:
-        import os
-        cfg = self.quant_config
-        return (os.environ.get("NMV_W4_NATIVE", "0") == "1" and cfg.weight_bits == 4 and not cfg.desc_act
-                and cfg.group_size in (-1, 128) and layer.input_size_per_partition % 256 == 0
-                and layer.output_size_per_partition % 64 == 0 and layer.is_k_full and layer.qweight.is_cuda)
+    def process_weights_after_loading(self, layer: torch.nn.Module) -> None:
+        return   # the conversion is lazy (first call), as in the reference: the loader may still be writing shards
 
-    @staticmethod
-    def _native(layer, size_m: int) -> bool:
-        return size_m <= GPTQMarlinLinearMethod.NATIVE_MAX_M and getattr(layer, "qweight_native", None) is not None
+    # ---- the reference's forward ---------------------------------------------------------------------------------
+    def apply(self, layer: torch.nn.Module, x: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+        assert not getattr(layer, "gate_up_interleaved", False), "this layer's columns are interleaved for apply_silu_mul()"
+        self._ready(layer)
+        rows = x.reshape(-1, x.shape[-1])
+        m, n, k = rows.shape[0], layer.output_size_per_partition, layer.input_size_per_partition
+        if self._native(layer, m):
+            y = ops.w4_native_gemm(rows, layer.qweight_native, layer.scales_native, layer.workspace, m, n, k, mode=0)
+        else:
+            y = ops.gptq_marlin_gemm(rows, layer.qweight, layer.scales, layer.g_idx, layer.g_idx_sort_indices,
+                                     layer.workspace, self.quant_config.weight_bits, m, n, k, layer.is_k_full)
+        if bias is not None:
+            y.add_(bias)
+        return y.reshape(x.shape[:-1] + (n, ))
 
-    # ---- deferred split-K: the GEMM leaves fp32 slabs, the following fused_add_rms_norm sums them
-    # (ops.gptq_marlin_gemm_partial; not part of the reference's LinearMethod) ----
-    def can_defer_reduce(self, layer: torch.nn.Module) -> bool:
+    # ---- MFMA-native copy of the codes (optional) -------------------------------------------------------------------
+    def _plain_w4(self, layer: torch.nn.Module) -> bool:
+        """4-bit, group 128 or channelwise, no act-order, whole K on this rank in 256-k rings: what the fused forms
+        and the native copy are written for"""
         cfg = self.quant_config
         return (cfg.weight_bits == 4 and not cfg.desc_act and cfg.group_size in (-1, 128)
-                and layer.input_size_per_partition % 256 == 0 and layer.is_k_full
-                and not getattr(layer, "gate_up_interleaved", False))
+                and layer.input_size_per_partition % 256 == 0 and layer.is_k_full)
+
+    def native_eligible(self, layer: torch.nn.Module) -> bool:
+        return (os.environ.get("NMV_W4_NATIVE", "0") == "1" and self._plain_w4(layer)
+                and layer.output_size_per_partition % 64 == 0 and layer.qweight.is_cuda)
+
+    @classmethod
+    def _native(cls, layer, size_m: int) -> bool:
+        return size_m <= cls.NATIVE_MAX_M and getattr(layer, "qweight_native", None) is not None
+
+    # ---- deferred split-K: the GEMM leaves fp32 slabs, the following launch sums them ------------------------------
+    def can_defer_reduce(self, layer: torch.nn.Module) -> bool:
+        return self._plain_w4(layer) and not getattr(layer, "gate_up_interleaved", False)
 
     def apply_partial(self, layer: torch.nn.Module, x: torch.Tensor) -> torch.Tensor:
-        """x @ W as fp32 split-K slabs [splits, T, N]; their sum in split order, rounded to the model
-        dtype, is bit-identical to apply()"""
-        reshaped_x = x.reshape(-1, x.shape[-1])
-        if layer.marlin_state == GPTQMarlinState.REPACK:
-            layer.marlin_state = GPTQMarlinState.READY
-            self._repack(layer)
-        if self._native(layer, reshaped_x.shape[0]):
-            return ops.w4_native_gemm(reshaped_x, layer.qweight_native, layer.scales_native, None, reshaped_x.shape[0],
-                                      layer.output_size_per_partition, layer.input_size_per_partition, mode=2)
-        return ops.gptq_marlin_gemm_partial(reshaped_x, layer.qweight, layer.scales, reshaped_x.shape[0],
-                                            layer.output_size_per_partition, layer.input_size_per_partition)
+        """x @ W as fp32 split-K slabs [splits, T, N]; their sum in split order, rounded to the model dtype, is
+        bit-identical to apply()"""
+        self._ready(layer)
+        rows = x.reshape(-1, x.shape[-1])
+        m, n, k = rows.shape[0], layer.output_size_per_partition, layer.input_size_per_partition
+        if self._native(layer, m):
+            return ops.w4_native_gemm(rows, layer.qweight_native, layer.scales_native, None, m, n, k, mode=2)
+        return ops.gptq_marlin_gemm_partial(rows, layer.qweight, layer.scales, m, n, k)
 
-    # ---- gate_up with silu_and_mul folded into the GEMM epilogue (ops.gptq_marlin_gemm_silu_mul;
-    # not part of the reference's LinearMethod) ----
+    # ---- gate_up with silu_and_mul in the GEMM's epilogue -----------------------------------------------------------
     def can_fuse_silu_mul(self, layer: torch.nn.Module) -> bool:
-        """a merged [gate | up] projection whose columns can be interleaved per 64-column chunk before
-        the (first-touch) Marlin repack, and which is wide enough that running the GEMM without
-        split-K (the epilogue needs the whole K in one workgroup) still beats GEMM + silu_and_mul:
-        measured on MI355X at K = 4096, the fused form wins from 112 chunks (N = 7168, the TP = 4
-        shard of Llama-3-8B) upwards and loses at 56 (TP = 8)"""
-        cfg = self.quant_config
-        n, k = layer.output_size_per_partition, layer.input_size_per_partition
+        """a merged [gate | up] projection whose columns can still be interleaved per 64-column chunk (i.e. before the
+        first-call repack), wide enough that a GEMM without split-K -- the epilogue needs the whole K in one workgroup
+        -- beats GEMM + silu_and_mul: measured on MI355X at K = 4096 the fused form wins from 112 chunks (N = 7168,
+        the TP = 4 shard of Llama-3-8B) and loses at 56 (TP = 8)"""
         if getattr(layer, "gate_up_interleaved", False):
             return True
-        return (layer.marlin_state == GPTQMarlinState.REPACK and cfg.weight_bits == 4 and not cfg.desc_act
-                and cfg.group_size in (-1, 128) and k % 256 == 0 and n % 128 == 0 and n // 64 >= 112
-                and getattr(layer, "bias", None) is None and layer.is_k_full)
+        n = layer.output_size_per_partition
+        return (layer.marlin_state is GPTQMarlinState.REPACK and self._plain_w4(layer) and n % 128 == 0
+                and n // 64 >= 112 and getattr(layer, "bias", None) is None)
 
     @staticmethod
     def _interleave_gate_up(t: torch.Tensor) -> torch.Tensor:
@@ -315,49 +312,13 @@ class GPTQMarlinLinearMethod(LinearMethodBase):
         return t.reshape(*lead, 2, n // 64, 32).transpose(-3, -2).reshape(*lead, n).contiguous()
 
     def apply_silu_mul(self, layer: torch.nn.Module, x: torch.Tensor) -> torch.Tensor:
-        """silu(x @ W_gate) * (x @ W_up) -> [.., N/2], bit-identical to apply() + SiluAndMul"""
-        reshaped_x = x.reshape(-1, x.shape[-1])
-        part_size_n = layer.output_size_per_partition
-        part_size_k = layer.input_size_per_partition
-        if layer.marlin_state == GPTQMarlinState.REPACK:
-            assert self.can_fuse_silu_mul(layer)
-            layer.marlin_state = GPTQMarlinState.READY
-            layer.qweight.data = self._interleave_gate_up(layer.qweight.data)
-            layer.scales.data = self._interleave_gate_up(layer.scales.data)
-            layer.gate_up_interleaved = True
-            self._repack(layer)
+        """silu(x @ W_gate) * (x @ W_up) -> [.., N / 2], bit-identical to apply() + SiluAndMul"""
+        self._ready(layer, interleave_gate_up=True)
         assert getattr(layer, "gate_up_interleaved", False), "layer was repacked without the interleave"
-        if self._native(layer, reshaped_x.shape[0]):
-            out = ops.w4_native_gemm(reshaped_x, layer.qweight_native, layer.scales_native, layer.workspace,
-                                     reshaped_x.shape[0], part_size_n, part_size_k, mode=1)
+        rows = x.reshape(-1, x.shape[-1])
+        m, n, k = rows.shape[0], layer.output_size_per_partition, layer.input_size_per_partition
+        if self._native(layer, m):
+            y = ops.w4_native_gemm(rows, layer.qweight_native, layer.scales_native, layer.workspace, m, n, k, mode=1)
         else:
-            out = ops.gptq_marlin_gemm_silu_mul(reshaped_x, layer.qweight, layer.scales, layer.workspace,
-                                                reshaped_x.shape[0], part_size_n, part_size_k)
-        return out.reshape(x.shape[:-1] + (part_size_n // 2, ))
-
-    def apply(self, layer: torch.nn.Module, x: torch.Tensor,
-              bias: Optional[torch.Tensor] = None) -> torch.Tensor:
-        assert not getattr(layer, "gate_up_interleaved", False), \
-            "this layer's columns are interleaved for apply_silu_mul()"
-        reshaped_x = x.reshape(-1, x.shape[-1])
-        size_m = reshaped_x.shape[0]
-        part_size_n = layer.output_size_per_partition
-        part_size_k = layer.input_size_per_partition
-        out_shape = x.shape[:-1] + (part_size_n, )
-        if layer.marlin_state == GPTQMarlinState.REPACK:
-            layer.marlin_state = GPTQMarlinState.READY
-            self._repack(layer)
-        if self._native(layer, size_m):
-            output = ops.w4_native_gemm(reshaped_x, layer.qweight_native, layer.scales_native, layer.workspace, size_m,
-                                        part_size_n, part_size_k, mode=0)
-        else:
-            output = ops.gptq_marlin_gemm(reshaped_x, layer.qweight, layer.scales, layer.g_idx,
-                                          layer.g_idx_sort_indices, layer.workspace,
-                                          self.quant_config.weight_bits, size_m, part_size_n,
-                                          part_size_k, layer.is_k_full)
-        if bias is not None:
-            output.add_(bias)
-        return output.reshape(out_shape)
-
-    def process_weights_after_loading(self, layer: torch.nn.Module) -> None:
-        return
+            y = ops.gptq_marlin_gemm_silu_mul(rows, layer.qweight, layer.scales, layer.workspace, m, n, k)
+        return y.reshape(x.shape[:-1] + (n // 2, ))

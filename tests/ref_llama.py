@@ -1,5 +1,5 @@
-"""Plain-torch fp32 CPU reference of the Llama decoder used to check end-to-end logits
-(test infrastructure).  Mirrors what the reference's CPU executor computes for
+"""Plain-torch fp32 reference of the Llama decoder used to check end-to-end logits (test infrastructure; runs on
+whatever device its weights are on -- the CPU for the small models, the GPU for the full-size single layer).  Mirrors what the reference's CPU executor computes for
 vllm/model_executor/models/llama.py: RMSNorm -> qkv -> neox rope -> causal attention over the
 whole sequence -> o_proj -> RMSNorm -> silu(gate)*up -> down_proj, with dequantised GPTQ weights."""
 from typing import Dict
@@ -11,7 +11,7 @@ def dequant_gptq(qweight, scales, bits=4):
     pf = 32 // bits
     k = qweight.shape[0] * pf
     q = qweight.to(torch.int64) & 0xFFFFFFFF
-    shifts = (torch.arange(pf, dtype=torch.int64) * bits).view(1, pf, 1)
+    shifts = (torch.arange(pf, dtype=torch.int64, device=qweight.device) * bits).view(1, pf, 1)
     codes = ((q[:, None, :] >> shifts) & (2**bits - 1)).reshape(k, -1).float()
     g = k // scales.shape[0]
     w = (codes - 2**(bits - 1)) * scales.float().repeat_interleave(g, dim=0)
@@ -49,7 +49,7 @@ class RefLlama:
 
     def rope(self, x, pos):
         hd = self.a.head_dim
-        inv = 1.0 / (self.a.rope_theta**(torch.arange(0, hd, 2).float() / hd))
+        inv = 1.0 / (self.a.rope_theta**(torch.arange(0, hd, 2, device=x.device).float() / hd))
         f = pos.float()[:, None] * inv[None]
         cos, sin = f.cos()[:, None, :], f.sin()[:, None, :]
         x1, x2 = x[..., :hd // 2], x[..., hd // 2:]
@@ -59,7 +59,7 @@ class RefLlama:
         """ids [L] -> logits [L, vocab] (causal)"""
         a = self.a
         L = ids.shape[0]
-        pos = torch.arange(L)
+        pos = torch.arange(L, device=ids.device)
         h = self.w["model.embed_tokens.weight"].float()[ids]
         for i in range(a.num_hidden_layers):
             p = f"model.layers.{i}."
@@ -71,7 +71,7 @@ class RefLlama:
             rep = a.num_attention_heads // a.num_key_value_heads
             k, v = k.repeat_interleave(rep, 1), v.repeat_interleave(rep, 1)
             att = torch.einsum("qhd,khd->hqk", q, k) * a.head_dim**-0.5
-            att = att + torch.full((L, L), float("-inf")).triu(1)[None]
+            att = att + torch.full((L, L), float("-inf"), device=ids.device).triu(1)[None]
             o = torch.einsum("hqk,khd->qhd", att.softmax(-1), v).reshape(L, -1)
             h = h + self.linear(p + "self_attn.o_proj", o)
             x = self.rms(h, self.w[p + "post_attention_layernorm.weight"])

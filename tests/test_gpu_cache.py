@@ -179,8 +179,14 @@ def test_reshape_and_cache_and_convert_fp8_float32(gpu_device, head_size, block_
     slots[::7] = -1
     kc, vc = inp["key_cache"].to(gpu_device), inp["value_cache"].to(gpu_device)
     ops.reshape_and_cache(inp["key"].to(gpu_device), inp["value"].to(gpu_device), kc, vc, slots.to(gpu_device), "auto", 1.0)
+    # the layout of cache_kernels.cu:152-204 restated for x = 4 (the C oracle is built for the 16-bit dtypes)
     kr, vr = inp["key_cache"].clone(), inp["value_cache"].clone()
-    oracle.reshape_and_cache(inp["key"], inp["value"], kr, vr, slots)
+    for t, slot in enumerate(slots.tolist()):
+        if slot < 0:
+            continue
+        b, off = divmod(slot, block_size)
+        kr[b, :, :, off, :] = inp["key"][t].reshape(4, head_size // 4, 4)
+        vr[b, :, :, off] = inp["value"][t]
     assert torch.equal(kc.cpu(), kr) and torch.equal(vc.cpu(), vr)
     # float -> fp8 -> float: the round trip is the fp8 rounding of x / scale, times scale
     f8 = torch.empty(kc.shape, dtype=torch.uint8, device=gpu_device)
