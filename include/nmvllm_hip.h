@@ -430,7 +430,7 @@ int64_t nmv_get_max_shared_memory_per_block_device_attribute(int64_t device_id);
  * Same arithmetic as nmv_gptq_marlin_gemm (fp32 group scaling), M tiles <= 64 rows. */
 int nmv_w4_native_repack(const int32_t* qweight, const int32_t* perm, int32_t* out, int size_k, int size_n,
                          void* stream);
-int nmv_w4_native_gemm_splits(int size_m, int size_n, int size_k);
+int nmv_w4_native_gemm_splits(int size_m, int size_n, int size_k, int num_groups);
 int nmv_w4_native_gemm(void* c, const void* a, const int32_t* b_native, const void* b_scales, int32_t* workspace,
                        int64_t workspace_len, void* scratch, int64_t scratch_bytes, int size_m, int size_n,
                        int size_k, int num_groups, nmv_dtype_t dtype, int mode, void* stream);

@@ -389,9 +389,9 @@ def w4_native_repack(qweight: torch.Tensor, perm: Optional[torch.Tensor], size_k
     return tb.w4_native_repack(qweight, perm, size_k, size_n)
 
 
-def w4_native_gemm_splits(size_m: int, size_n: int, size_k: int) -> int:
+def w4_native_gemm_splits(size_m: int, size_n: int, size_k: int, num_groups: Optional[int] = None) -> int:
     from neural_magic_vllm_amd import _torch_bindings as tb
-    return tb.w4_native_gemm_splits(size_m, size_n, size_k)
+    return tb.w4_native_gemm_splits(size_m, size_n, size_k, num_groups)
 
 
 def w4_native_gemm(a: torch.Tensor, b_native: torch.Tensor, scales: torch.Tensor, workspace: Optional[torch.Tensor],

@@ -696,8 +696,11 @@ def w4_native_repack(qweight, perm, size_k, size_n) -> torch.Tensor:
     return out
 
 
-def w4_native_gemm_splits(size_m, size_n, size_k) -> int:
-    return int(_lib.load().nmv_w4_native_gemm_splits(size_m, size_n, size_k))
+def w4_native_gemm_splits(size_m, size_n, size_k, num_groups=None) -> int:
+    """slab count of w4_native_gemm mode 2 (0: unsupported); num_groups = rows of the scale tensor (default: group 128)"""
+    if num_groups is None:
+        num_groups = max(size_k // 128, 1)
+    return int(_lib.load().nmv_w4_native_gemm_splits(size_m, size_n, size_k, num_groups))
 
 
 def w4_native_gemm(a, b_native, scales, workspace, size_m, size_n, size_k, mode=0) -> torch.Tensor:
@@ -710,7 +713,7 @@ def w4_native_gemm(a, b_native, scales, workspace, size_m, size_n, size_k, mode=
     L = _lib.load()
     dev = a.device
     if mode == 2:
-        splits = L.nmv_w4_native_gemm_splits(size_m, size_n, size_k)
+        splits = L.nmv_w4_native_gemm_splits(size_m, size_n, size_k, scales.shape[0])
         _req(splits >= 1, "w4_native_gemm: shape not supported")
         out = torch.empty((splits, size_m, size_n), dtype=torch.float32, device=dev)
         scratch, nbytes, c = out, out.numel() * 4, None

@@ -68,6 +68,19 @@ template <> struct W4<F16> {
 };
 constexpr float W4_ZP = 24.0f;  // (16 + q) - 24 = q - 8
 
+// The MFMA-native tensor (w4a16_gemm.hip "The MFMA-native weight layout"): pair p of a dword = nibbles p and p + 4
+template <typename T> struct W4N;
+template <> struct W4N<BF16> {   // nibble stays in mantissa bits [3:0]: 128 + q
+  static constexpr uint32_t MASK = 0x000F000Fu, MAGIC = 0x43004300u, ONES = 0x3F803F80u;
+  static constexpr int POS = 0;
+  static constexpr float ZPC = 136.0f;
+};
+template <> struct W4N<F16> {    // nibble in mantissa bits [9:6]: 16 + q
+  static constexpr uint32_t MASK = 0x03C003C0u, MAGIC = 0x4C004C00u, ONES = 0x3C003C00u;
+  static constexpr int POS = 6;
+  static constexpr float ZPC = 24.0f;
+};
+
 
 struct GemmParams {
   const uint16_t* a;      // [M, K]

@@ -883,17 +883,7 @@ __global__ __launch_bounds__(GT, 2) void w4a16_gemm_tall_kernel(const GemmParams
 // accumulators exactly as in the tall kernel.  Everything around the operand path -- 4 waves = WN chunks x WK
 // k groups, 4-slot register ring three stages ahead, one barrier per stage, LDS K reduction, slabs / ticket /
 // deferred / silu epilogues -- is the tall kernel's.
-template <typename T> struct W4N;
-template <> struct W4N<BF16> {   // nibble stays in mantissa bits [3:0]: 128 + q
-  static constexpr uint32_t MASK = 0x000F000Fu, MAGIC = 0x43004300u, ONES = 0x3F803F80u;
-  static constexpr int POS = 0;
-  static constexpr float ZPC = 136.0f;
-};
-template <> struct W4N<F16> {    // nibble in mantissa bits [9:6]: 16 + q
-  static constexpr uint32_t MASK = 0x03C003C0u, MAGIC = 0x4C004C00u, ONES = 0x3C003C00u;
-  static constexpr int POS = 6;
-  static constexpr float ZPC = 24.0f;
-};
+// W4N<T> (mask / magic / nibble position / zero-point constant of the native tensor): w4a16_common.h
 
 template <typename T, int MT, int WN, int WK, int GS, bool NT = false>
 __global__ __launch_bounds__(GT, 2) void w4n_gemm_kernel(const GemmParams p) {
@@ -1472,7 +1462,7 @@ static int marlin_gemm_impl(void* c, const void* a, const int32_t* b_q_weight, c
     return NMV_OK;
   }
   // decode batches of the prevalent format (4-bit symmetric, group 128, no act-order): w4a16_stream.hip
-  if (num_bits == 4 && !has_act_order && group_size == 128 && b_zeros == nullptr && !native) {
+  if (num_bits == 4 && !has_act_order && group_size == 128 && b_zeros == nullptr) {
     W4StreamPlan sp;
     if (w4s_make_plan(size_m, size_n, size_k, epi == 2 ? INT64_MAX : (workspace ? workspace_len : 0), epi == 1, epi == 2, &sp) &&
         (epi != 1 || (sp.splits == 1 && size_n % 128 == 0))) {
@@ -1494,7 +1484,7 @@ static int marlin_gemm_impl(void* c, const void* a, const int32_t* b_q_weight, c
       p.group_size = 128;
       p.k_per_wg = sp.k_per_wg;
       p.splits = sp.splits;
-      p.native = 0;
+      p.native = native;
       p.epi = epi;
       p.g_stage = sp.g_stage;
       p.n_stages = sp.n_stages;
@@ -1658,8 +1648,12 @@ extern "C" int nmv_w4_native_repack(const int32_t* qweight, const int32_t* perm,
   return NMV_OK;
 }
 
-extern "C" int nmv_w4_native_gemm_splits(int size_m, int size_n, int size_k) {
+extern "C" int nmv_w4_native_gemm_splits(int size_m, int size_n, int size_k, int num_groups) {
   if (size_m <= 0 || size_n <= 0 || size_k <= 0 || size_n % 64 != 0 || size_k % 256 != 0) return 0;
+  // group 128 takes w4a16_stream.hip (as nmv_gptq_marlin_gemm_partial_splits)
+  W4StreamPlan sp;
+  if (num_groups > 1 && size_k / num_groups == 128 && w4s_make_plan(size_m, size_n, size_k, INT64_MAX, false, true, &sp))
+    return sp.splits;
   const GemmPlan pl = make_plan(size_m, size_n, size_k, INT64_MAX, true, 4, false, false, true);
   return (pl.tall && pl.mt <= 4) ? pl.splits : 0;
 }

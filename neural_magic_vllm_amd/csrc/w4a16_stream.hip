@@ -81,12 +81,25 @@ __device__ __forceinline__ uint4 buf_ld16(__amdgpu_buffer_rsrc_t rs, uint32_t vo
 // Ring: RS = 4 D slots of one k-step (16 bytes per lane) each; a slot is refilled with the k-step RS ahead as soon
 // as its content has been copied out, so 4 D - 1 .. 4 D k-steps are in flight per wave and slot numbers repeat
 // every D groups (the loops below run whole periods so that they are static).
-template <typename T, int MT, int NW, int CPW, int D, int GST /* groups per stage; 0 = resident */>
+// NV: `b` is the MFMA-native tensor of nmv_w4_native_repack (w4a16_gemm.hip: native[kstep][chunk][lane], a lane's 16
+// bytes ARE its four A operands, k in natural order, pair p = nibbles p and p + 4) and `s` the natural [groups, N]
+// scale tensor -- no lane exchange, no byte gather, one pair per dword needs no shift (bf16: 128 + q), and a 16-byte
+// piece of an activation row is the B operand as it stands (no 4 x 4 dword transpose on the way into LDS).
+template <typename T, int MT, int NW, int CPW, int D, int GST /* groups per stage; 0 = resident */, bool NV = false>
 __global__ __launch_bounds__(NW * 64, NW / 4) void w4a16_stream_kernel(const GemmParams p) {
   static_assert(NW % CPW == 0, "waves = chunks x k groups");
   constexpr int P = NW / CPW, MP = 16 * MT, NTHR = NW * 64, RS = 4 * D;
   constexpr bool RES = GST == 0;
   constexpr int NBUF = RES ? 1 : 2;
+#ifdef NMV_W4S_NO_HS
+  constexpr bool HS = false;
+#else
+  // the 64-row streamed stage is issued in a hand-written order (see "hand-scheduled stage" below)
+  constexpr bool HS = MT == 4 && GST == 1 && D == 1;
+#endif
+  // scale image in LDS: [g][j][reg] (one float4 per 16-column tile: native scales arrive in that order, and the
+  // hand-scheduled stage flushes tile by tile) or [g][reg][j] (one permuted 16-byte piece = two float4)
+  constexpr bool SC_JR = NV || HS;
   constexpr int LOG_MP = MT == 1 ? 4 : MT == 2 ? 5 : 6;
   constexpr int LOG_CPW = CPW == 1 ? 0 : CPW == 2 ? 1 : 2;
   static_assert(CPW == 1 || CPW == 2 || CPW == 4, "chunks per workgroup");
@@ -128,10 +141,14 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void w4a16_stream_kernel(const Gem
 
   // ---- weights: lane (blk, n_in, q = g) streams vector n_in*4+q of k-tile 2 ks + blk (w4a16_gemm.hip) ----
   const uint32_t row_bytes = (uint32_t)p.N * 8;               // one k-tile row of the Marlin tensor
-  const uint32_t w_voff = chunk_ok ? ((uint32_t)chunk * 32 + n_in * 4 + g) * 16 + blk * row_bytes : OOB_OFF;
+  // native: a k-step of a chunk is 1 KiB contiguous (lane's vector at 16 lane), a k-step of all chunks N * 16 bytes
+  const uint32_t w_voff = !chunk_ok ? OOB_OFF
+                          : NV      ? ((uint32_t)chunk * 64 + lane) * 16
+                                    : ((uint32_t)chunk * 32 + n_in * 4 + g) * 16 + blk * row_bytes;
   const uint32_t w_s0 = (uint32_t)(k_w0 >> 4) * row_bytes;    // uniform
-  const uint32_t kmask = __builtin_amdgcn_readfirstlane(W4<T>::MASK);
-  uint32_t kmagic = W4<T>::MAGIC;
+  const uint32_t kmask = __builtin_amdgcn_readfirstlane(NV ? W4N<T>::MASK : W4<T>::MASK);
+  uint32_t kmagic = NV ? W4N<T>::MAGIC : W4<T>::MAGIC;
+  constexpr float ZPC = NV ? W4N<T>::ZPC : W4_ZP;   // dequantised code = q + (ZPC - 8)
   asm volatile("" : "+v"(kmagic));
   // v_perm selector ({own, partner} = bytes 7..4, 3..0): block 0 lanes hold the even k-tile and take bytes 0, 2 of
   // both words, block 1 lanes hold the odd k-tile and take bytes 1, 3
@@ -156,10 +173,17 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void w4a16_stream_kernel(const Gem
   // zg: flat index (k group * GW + group of the wave) of the unit's group in ns_s
   auto a_store = [&](int row, int gb, int buf, int zg, const uint4 (&v)[4]) {
     uint4* base = a_s + buf * a_buf_u4 + gb * 16 * MP + (kst_ * 4) * MP + (row ^ ((kst_ << 1) | (gb & 1)));
-    base[0] = make_uint4(v[0].x, v[1].x, v[2].x, v[3].x);
-    base[MP] = make_uint4(v[0].y, v[1].y, v[2].y, v[3].y);
-    base[2 * MP] = make_uint4(v[0].z, v[1].z, v[2].z, v[3].z);
-    base[3 * MP] = make_uint4(v[0].w, v[1].w, v[2].w, v[3].w);
+    if constexpr (NV) {   // piece cc = k 8 cc .. 8 cc + 7 of the k-step = the operand of lane group cc
+      base[0] = v[0];
+      base[MP] = v[1];
+      base[2 * MP] = v[2];
+      base[3 * MP] = v[3];
+    } else {
+      base[0] = make_uint4(v[0].x, v[1].x, v[2].x, v[3].x);
+      base[MP] = make_uint4(v[0].y, v[1].y, v[2].y, v[3].y);
+      base[2 * MP] = make_uint4(v[0].z, v[1].z, v[2].z, v[3].z);
+      base[3 * MP] = make_uint4(v[0].w, v[1].w, v[2].w, v[3].w);
+    }
     float sum = 0.f;
 #pragma unroll
     for (int cc = 0; cc < 4; ++cc) {
@@ -170,17 +194,37 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void w4a16_stream_kernel(const Gem
     }
     sum += dpp_mov_f<0xB1>(sum);   // the four k-steps of the group sit in one quad of lanes
     sum += dpp_mov_f<0x4E>(sum);
-    if (kst_ == 0 && zg >= 0) ns_s[zg * MP + row] = -W4_ZP * sum;
+    if (kst_ == 0 && zg >= 0) ns_s[zg * MP + row] = -ZPC * sum;
   };
   // scale rows: 16-byte piece pc of (group gb, chunk cc) -> two float4 of the fragment image
   auto s_store = [&](int id2, int buf, uint4 v) {
     const int pc = id2 & 7, gbc = id2 >> 3;        // gbc = gb * CPW + cc
     f32x4_t* dst = reinterpret_cast<f32x4_t*>(sc_s + buf * sc_buf + gbc * 64);
-    const f32x4_t h0 = {lo_f<T>(v.x), lo_f<T>(v.y), lo_f<T>(v.z), lo_f<T>(v.w)};
-    const f32x4_t h1 = {hi_f<T>(v.x), hi_f<T>(v.y), hi_f<T>(v.z), hi_f<T>(v.w)};
-    const int g_lo = pc >> 2, reg = pc & 3;
-    dst[g_lo * 4 + reg] = h0;
-    dst[(g_lo + 2) * 4 + reg] = h1;
+    if constexpr (NV) {
+      // natural order: the piece is columns 8 pc .. 8 pc + 7 = tile j = pc / 2, lane groups 2 (pc & 1) and + 1, reg 0..3;
+      // the image is [g][j][reg] (the flush reads one float4 per tile)
+      const f32x4_t h0 = {lo_f<T>(v.x), hi_f<T>(v.x), lo_f<T>(v.y), hi_f<T>(v.y)};
+      const f32x4_t h1 = {lo_f<T>(v.z), hi_f<T>(v.z), lo_f<T>(v.w), hi_f<T>(v.w)};
+      const int j = pc >> 1, g0 = 2 * (pc & 1);
+      dst[g0 * 4 + j] = h0;
+      dst[(g0 + 1) * 4 + j] = h1;
+    } else if constexpr (SC_JR) {
+      // permuted piece (g_lo = pc / 4, reg = pc % 4; dword j = tile j, halves = lane groups g_lo, g_lo + 2) into [g][j][reg]
+      float* d1 = reinterpret_cast<float*>(dst);
+      const int g_lo = pc >> 2, reg = pc & 3;
+      const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        d1[(g_lo * 4 + j) * 4 + reg] = lo_f<T>(w[j]);
+        d1[((g_lo + 2) * 4 + j) * 4 + reg] = hi_f<T>(w[j]);
+      }
+    } else {
+      const f32x4_t h0 = {lo_f<T>(v.x), lo_f<T>(v.y), lo_f<T>(v.z), lo_f<T>(v.w)};
+      const f32x4_t h1 = {hi_f<T>(v.x), hi_f<T>(v.y), hi_f<T>(v.z), hi_f<T>(v.w)};
+      const int g_lo = pc >> 2, reg = pc & 3;
+      dst[g_lo * 4 + reg] = h0;
+      dst[(g_lo + 2) * 4 + reg] = h1;
+    }
   };
   // per-thread part of a scale piece's offset (chunk, piece); OOB for chunks past N
   auto s_voff_thread = [&](int id2) -> uint32_t {
@@ -227,12 +271,22 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void w4a16_stream_kernel(const Gem
         // (nibbles k 2q, 2q+8 | same | k 2q+1, 2q+9 | same): fetch the partner's word with one DPP row rotate and
         // gather MY block's four bytes of both k-tiles with one v_perm -> [E.x, O.x, E.y, O.y] (E / O = even / odd
         // k-tile), so that the four rotate amounts below are the same for every lane
-        const uint32_t pw = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)own[j], 0x128, 0xf, 0xf, true);
-        const uint32_t mw = __builtin_amdgcn_perm(own[j], pw, bsel);
-        const uint4 wv = make_uint4(and_or(__builtin_amdgcn_alignbit(mw, mw, W4<T>::ROT_LO0), kmask, kmagic),
-                                    and_or(__builtin_amdgcn_alignbit(mw, mw, W4<T>::ROT_HI0), kmask, kmagic),
-                                    and_or(__builtin_amdgcn_alignbit(mw, mw, W4<T>::ROT_LO1), kmask, kmagic),
-                                    and_or(__builtin_amdgcn_alignbit(mw, mw, W4<T>::ROT_HI1), kmask, kmagic));
+        uint4 wv;
+        if constexpr (NV) {
+          // pair p = nibbles p and p + 4 of the dword: bring nibble p to bit POS of the low half
+          const uint32_t x = own[j];
+          constexpr int P0 = W4N<T>::POS;
+          wv = make_uint4(and_or(P0 == 0 ? x : x << P0, kmask, kmagic),
+                          and_or(4 >= P0 ? x >> (4 - P0) : x << (P0 - 4), kmask, kmagic),
+                          and_or(x >> (8 - P0), kmask, kmagic), and_or(x >> (12 - P0), kmask, kmagic));
+        } else {
+          const uint32_t pw = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)own[j], 0x128, 0xf, 0xf, true);
+          const uint32_t mw = __builtin_amdgcn_perm(own[j], pw, bsel);
+          wv = make_uint4(and_or(__builtin_amdgcn_alignbit(mw, mw, W4<T>::ROT_LO0), kmask, kmagic),
+                          and_or(__builtin_amdgcn_alignbit(mw, mw, W4<T>::ROT_HI0), kmask, kmagic),
+                          and_or(__builtin_amdgcn_alignbit(mw, mw, W4<T>::ROT_LO1), kmask, kmagic),
+                          and_or(__builtin_amdgcn_alignbit(mw, mw, W4<T>::ROT_HI1), kmask, kmagic));
+        }
 #pragma unroll
         for (int t = 0; t < MT; ++t) accg[j][t] = W4<T>::mfma(wv, af[t], ks == 0 ? zero4 : accg[j][t]);
         if constexpr (MT >= 4) __builtin_amdgcn_sched_barrier(0);
@@ -247,12 +301,14 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void w4a16_stream_kernel(const Gem
     pre_flush();
     const f32x4_t* sc_g = reinterpret_cast<const f32x4_t*>(sc_s + buf * sc_buf + (gb * CPW + c) * 64);
 #pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-      const f32x4_t s4 = sc_g[g * 4 + reg];
+    for (int x = 0; x < 4; ++x) {     // [g][reg][j]: x = reg, the float4 runs over the tiles; [g][j][reg]: x = tile, over reg
+      const f32x4_t s4 = sc_g[g * 4 + x];
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int y = 0; y < 4; ++y) {
+        const int reg = SC_JR ? y : x, j = SC_JR ? x : y;
 #pragma unroll
-        for (int t = 0; t < MT; ++t) accm[j][t][reg] = fmaf(s4[j], accg[j][t][reg], accm[j][t][reg]);
+        for (int t = 0; t < MT; ++t) accm[j][t][reg] = fmaf(s4[y], accg[j][t][reg], accm[j][t][reg]);
+      }
     }
   };
   auto nop = [] {};
@@ -390,107 +446,319 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void w4a16_stream_kernel(const Gem
       s_vo[i] = (id2 < P * GST * CPW * 8 && vt != OOB_OFF) ? vt + (uint32_t)((grp_k0(gb, 0) >> 7) * p.N * 2) : OOB_OFF;
     }
     const uint32_t s_stage_bytes = (uint32_t)(GST * p.N * 2);   // one stage further: GST scale rows
-#ifdef NMV_W4S_STAMPS
-    unsigned long long acc_compute = 0, acc_park = 0, acc_bar = 0;
-#endif
-    for (int st = 0; st < n_stages; ++st) {
-      const int SP = st & 1;
-#ifdef NMV_W4S_STAMPS
-      const unsigned long long t_a = __builtin_amdgcn_s_memrealtime();
-#endif
-      uint4 ar[UPB][4], sr[SPT];
-      const bool more = st + 1 < n_stages;             // uniform; loads past the end are switched off by their offset
-      const uint32_t a_vo_st = more ? a_vo : OOB_OFF;
-      auto fetch = [&](int b) {
+    if constexpr (HS) {
+      // ---- hand-scheduled stage (64 rows, one 128-k group per stage and k group) ----
+      // rocprofv3 counters of the compiler-scheduled stage (profiles/r03_gemm_pmc.txt): MFMA pipe 22 % busy, vector
+      // issue 38 %, a third of the wave-cycles in s_waitcnt -- neither unit is the limit, the order is: every k-step
+      // opened with four LDS reads and waited for them, a word was expanded and THEN its four MFMAs issued, and
+      // parking the next stage (stores, 32 dependent v_dot2) and the flush ran with the MFMA pipe idle, in all eight
+      // waves at once because the barrier aligns them.  Here the source order IS the schedule (a sched_barrier after
+      // every MFMA): each MFMA is followed by the vector work that fits in its shadow --
+      //   * the expansion of the NEXT step's word (a step = one 16-column tile of one k-step: 4 MFMAs),
+      //   * k-step 2: the next stage's activation pieces go to LDS and into the running sums, piece by piece,
+      //   * k-step 3: the flush of the tile whose group chain ended one step earlier, with scales read a step ahead --
+      // and the B operands of k-step ks + 1 are requested during step (ks, 1).  What is left at the end of a stage is
+      // the flush of the last tile, two DPP adds and the barrier.
+      static_assert(UPT == 1 || UPT == 2 || UPT == 4, "activation units per thread and stage");
+      const int gsw = kp & 1;                       // group of the buffer = kp (GST == 1)
+      const uint4* a_rd[4];                         // plane (ks, g) of buffer 0, swizzled row r; + 16 t is an immediate
 #pragma unroll
-        for (int i = 0; i < UPB; ++i) {
-          const uint32_t so = (uint32_t)(grp_k0(gb0 + (b * UPB + i) * GB_STEP, st + 1) * 2);
+      for (int ks = 0; ks < 4; ++ks) a_rd[ks] = a_s + kp * 16 * MP + (ks * 4 + g) * MP + (r ^ ((ks << 1) | gsw));
+      uint4* a_wr[UPT];
+      int z_idx[UPT];
 #pragma unroll
-          for (int cc = 0; cc < 4; ++cc) ar[i][cc] = buf_ld16<0>(rs_a, a_vo_st, so + cc * 16);
+      for (int u = 0; u < UPT; ++u) {
+        const int gb = gb0 + u * GB_STEP;
+        a_wr[u] = a_s + gb * 16 * MP + (kst_ * 4) * MP + (s_row ^ ((kst_ << 1) | (gb & 1)));
+        z_idx[u] = gb * GW * MP + s_row;
+      }
+      auto word = [&](int sl, int jj) -> uint32_t {
+        return jj == 0 ? wq[sl].x : jj == 1 ? wq[sl].y : jj == 2 ? wq[sl].z : wq[sl].w;
+      };
+      // quarter `part` of the expansion of word x into w (tmp: the gathered word of the Marlin form)
+      auto xpart = [&](int part, uint32_t x, uint4& w, uint32_t& tmp) {
+        if constexpr (NV) {
+          constexpr int P0 = W4N<T>::POS;
+          if (part == 0) w.x = and_or(P0 == 0 ? x : x << P0, kmask, kmagic);
+          if (part == 1) w.y = and_or(4 >= P0 ? x >> (4 - P0) : x << (P0 - 4), kmask, kmagic);
+          if (part == 2) w.z = and_or(x >> (8 - P0), kmask, kmagic);
+          if (part == 3) w.w = and_or(x >> (12 - P0), kmask, kmagic);
+        } else {
+          if (part == 0) {
+            const uint32_t pw = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x128, 0xf, 0xf, true);
+            tmp = __builtin_amdgcn_perm(x, pw, bsel);
+            w.x = and_or(__builtin_amdgcn_alignbit(tmp, tmp, W4<T>::ROT_LO0), kmask, kmagic);
+          }
+          if (part == 1) w.y = and_or(__builtin_amdgcn_alignbit(tmp, tmp, W4<T>::ROT_HI0), kmask, kmagic);
+          if (part == 2) w.z = and_or(__builtin_amdgcn_alignbit(tmp, tmp, W4<T>::ROT_LO1), kmask, kmagic);
+          if (part == 3) w.w = and_or(__builtin_amdgcn_alignbit(tmp, tmp, W4<T>::ROT_HI1), kmask, kmagic);
         }
       };
-      auto park = [&](int b) {
+      uint4 wvn;
+      {
+        uint32_t tmp = 0;
 #pragma unroll
-        for (int i = 0; i < UPB; ++i) {
-          const int gb = gb0 + (b * UPB + i) * GB_STEP;
-          a_store(s_row, gb, SP ^ 1, more ? (gb / GST) * GW + (st + 1) * GST + (gb % GST) : -1, ar[i]);   // past the end: zeros, no sum
+        for (int part = 0; part < 4; ++part) xpart(part, word(0, 0), wvn, tmp);
+      }
+      for (int st = 0; st < n_stages; ++st) {
+        const int SP = st & 1;
+        const bool more = st + 1 < n_stages;             // uniform; loads past the end are switched off by their offset
+#ifdef NMV_W4S_ABL_A      // development builds (results garbage, times valid): no activation traffic after stage 0
+        const uint32_t a_vo_st = OOB_OFF;
+#else
+        const uint32_t a_vo_st = more ? a_vo : OOB_OFF;
+#endif
+#ifdef NMV_W4S_ABL_W      // no weight traffic after the first ring fill
+        const uint32_t vo_next = OOB_OFF;
+#else
+        const uint32_t vo_next = more ? w_voff : OOB_OFF;
+#endif
+        uint4 ar[UPT][4], sr[SPT];
+#pragma unroll
+        for (int u = 0; u < UPT; ++u) {
+          const uint32_t so = (uint32_t)(grp_k0(gb0 + u * GB_STEP, st + 1) * 2);
+#pragma unroll
+          for (int cc = 0; cc < 4; ++cc) ar[u][cc] = buf_ld16<0>(rs_a, a_vo_st, so + cc * 16);
         }
-      };
-#ifndef NMV_W4S_ABLATE_A
-      fetch(0);
-#endif
 #pragma unroll
-      for (int i = 0; i < SPT; ++i) sr[i] = buf_ld16<0>(rs_s, more ? s_vo[i] : OOB_OFF, (uint32_t)(st + 1) * s_stage_bytes);
-      auto mid = [&] {
-#ifndef NMV_W4S_ABLATE_A
-        if constexpr (AH == 2) { park(0); fetch(1); }
+        for (int i = 0; i < SPT; ++i) sr[i] = buf_ld16<0>(rs_s, more ? s_vo[i] : OOB_OFF, (uint32_t)(st + 1) * s_stage_bytes);
+        const int rd_off = SP * a_buf_u4, wr_off = (SP ^ 1) * a_buf_u4;
+        const f32x4_t* sc_g = reinterpret_cast<const f32x4_t*>(sc_s + SP * sc_buf + (kp * CPW + c) * 64) + g * 4;
+        uint4 afc[4], afn[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) afc[t] = a_rd[0][rd_off + t * 16];   // (16 t + r) ^ x = 16 t + (r ^ x): x < 8
+        f32x4_t accg[4][4];
+        f32x4_t s4c = zero4, s4n = zero4;
+        float psum[UPT];
+#pragma unroll
+        for (int u = 0; u < UPT; ++u) psum[u] = 0.f;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int sn = (ks * 4 + j + 1) & 15;        // the step whose word is expanded in this one
+            const uint32_t xw = word(sn >> 2, sn & 3);
+            const uint4 wv = wvn;
+            uint32_t tmp = 0;
+            if (j == 1 && ks < 3) {
+#ifndef NMV_W4S_ABL_LDSRD  // no B-operand reads after k-step 0
+#pragma unroll
+              for (int t = 0; t < 4; ++t) afn[t] = a_rd[ks + 1][rd_off + t * 16];
+#else
+#pragma unroll
+              for (int t = 0; t < 4; ++t) afn[t] = afc[t];
 #endif
-      };
-      auto body = [&](auto gi_tag) {
-        constexpr int GI = decltype(gi_tag)::value;
-        if constexpr (GI < GST) {
-          constexpr int U = GI % D;
-          if constexpr (GI == 0) {
-            group_compute(std::integral_constant<int, U>{}, st * GST + GI, kp * GST + GI, SP, mid, nop);
-          } else {
-            group_compute(std::integral_constant<int, U>{}, st * GST + GI, kp * GST + GI, SP, nop, nop);
+            }
+            if (ks == 3) {
+              s4c = s4n;
+              s4n = sc_g[j];
+            }
+#pragma unroll
+            for (int part = 0; part < 4; ++part) {
+#ifndef NMV_W4S_ABL_MFMA   // no MFMA: the operands are kept alive by an empty asm
+              accg[j][part] = W4<T>::mfma(wv, afc[part], ks == 0 ? zero4 : accg[j][part]);
+#else
+              asm volatile("" :: "v"(wv.x), "v"(wv.y), "v"(wv.z), "v"(wv.w), "v"(afc[part].x), "v"(afc[part].w));
+              if (ks == 0) accg[j][part] = zero4;
+#endif
+#ifndef NMV_W4S_ABL_EXP    // no expansion: the raw word is the operand
+              xpart(part, xw, wvn, tmp);
+#else
+              wvn = make_uint4(xw, xw, xw, xw);
+#endif
+#ifndef NMV_W4S_ABL_PARK   // the next stage is fetched but neither stored nor summed
+              if (ks == 2) {
+                // pieces q = j UPT .. + UPT - 1 of this thread's stage: dwords d = part UPT .. of the step's 4 UPT
+#pragma unroll
+                for (int i = 0; i < UPT; ++i) {
+                  const int d = part * UPT + i;                 // dword of the step
+                  const int q = j * UPT + (d >> 2);             // piece of the stage
+                  const int u = q >> 2, cc = q & 3, e = d & 3;  // unit, piece of the unit, dword of the piece
+                  if (e == 0) {
+                    if constexpr (NV) {
+                      a_wr[u][wr_off + cc * MP] = ar[u][cc];
+                    } else {   // plane cc of the k-step takes dword cc of the unit's four pieces
+                      const uint4 tr = cc == 0   ? make_uint4(ar[u][0].x, ar[u][1].x, ar[u][2].x, ar[u][3].x)
+                                       : cc == 1 ? make_uint4(ar[u][0].y, ar[u][1].y, ar[u][2].y, ar[u][3].y)
+                                       : cc == 2 ? make_uint4(ar[u][0].z, ar[u][1].z, ar[u][2].z, ar[u][3].z)
+                                                 : make_uint4(ar[u][0].w, ar[u][1].w, ar[u][2].w, ar[u][3].w);
+                      a_wr[u][wr_off + cc * MP] = tr;
+                    }
+                  }
+                  const uint32_t dv = e == 0 ? ar[u][cc].x : e == 1 ? ar[u][cc].y : e == 2 ? ar[u][cc].z : ar[u][cc].w;
+                  psum[u] = T::dot2(dv, ones2, psum[u]);
+                }
+              }
+#endif
+              if (ks == 3 && j >= 1) {
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg)
+                  accm[j - 1][part][reg] = fmaf(s4c[reg], accg[j - 1][part][reg], accm[j - 1][part][reg]);
+                asm volatile("" : "+v"(accm[j - 1][part]));   // the flush stays in this step (it would sink to the stage's end)
+              }
+            }
+            if (j == 3) {
+              // the k-step's slot was expanded for the last time one step ago: refill it with the next group's k-step
+              if (ks == 0) load_w(std::integral_constant<int, 0>{}, (st + 1) * 4 + 0, vo_next);
+              if (ks == 1) load_w(std::integral_constant<int, 1>{}, (st + 1) * 4 + 1, vo_next);
+              if (ks == 2) load_w(std::integral_constant<int, 2>{}, (st + 1) * 4 + 2, vo_next);
+              if (ks == 3) load_w(std::integral_constant<int, 3>{}, (st + 1) * 4 + 3, vo_next);
+#pragma unroll
+              for (int t = 0; t < 4; ++t) afc[t] = afn[t];
+            }
+            // the order of the step for the machine scheduler: LDS reads first, then four times [one MFMA, its share of
+            // the vector work, at most one LDS store], the ring refill last; nothing crosses into the next step
+            constexpr int VX = NV ? 2 : 3;                                  // expansion: 7 / 10 ops in four shares
+            constexpr int V2 = VX + 2 * UPT + (NV ? 0 : 4), V3 = VX + 4;    // + sums (and transposes) / + flush
+            if ((j == 1 && ks < 3) || ks == 3) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+            for (int part = 0; part < 4; ++part) {
+              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+              if (ks == 2) __builtin_amdgcn_sched_group_barrier(0x002, V2, 0);
+              else if (ks == 3) __builtin_amdgcn_sched_group_barrier(0x002, V3, 0);
+              else __builtin_amdgcn_sched_group_barrier(0x002, VX, 0);
+              if (ks == 2) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+            }
+            if (j == 3) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            __builtin_amdgcn_sched_barrier(0);
           }
         }
-      };
-      body(std::integral_constant<int, 0>{});
-      body(std::integral_constant<int, 1>{});
-#ifdef NMV_W4S_STAMPS
-      const unsigned long long t_b = __builtin_amdgcn_s_memrealtime();
-#endif
-#ifndef NMV_W4S_ABLATE_A
-      park(AH - 1);
-#endif
+        // tail: the last tile's flush, the sums, the scale rows of the next stage
 #pragma unroll
-      for (int i = 0; i < SPT; ++i)
-        if (tid + i * NTHR < P * GST * CPW * 8) s_store(tid + i * NTHR, SP ^ 1, sr[i]);
-#ifdef NMV_W4S_STAMPS
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      const unsigned long long t_c = __builtin_amdgcn_s_memrealtime();
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int reg = 0; reg < 4; ++reg) accm[3][t][reg] = fmaf(s4n[reg], accg[3][t][reg], accm[3][t][reg]);
+#pragma unroll
+        for (int u = 0; u < UPT; ++u) {
+          float sum = psum[u];
+          sum += dpp_mov_f<0xB1>(sum);   // the four k-steps of the group sit in one quad of lanes
+          sum += dpp_mov_f<0x4E>(sum);
+          if (kst_ == 0 && more) ns_s[z_idx[u] + (st + 1) * MP] = -ZPC * sum;
+        }
+#pragma unroll
+        for (int i = 0; i < SPT; ++i)
+          if (tid + i * NTHR < P * GST * CPW * 8) s_store(tid + i * NTHR, SP ^ 1, sr[i]);
+#ifndef NMV_W4S_ABL_BAR    // no barrier between the stages
+        __syncthreads();
+#else
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
-      __syncthreads();
-#ifdef NMV_W4S_STAMPS
-      const unsigned long long t_d = __builtin_amdgcn_s_memrealtime();
-      acc_compute += t_b - t_a; acc_park += t_c - t_b; acc_bar += t_d - t_c;
-#endif
+      }
+    } else {
+  #ifdef NMV_W4S_STAMPS
+      unsigned long long acc_compute = 0, acc_park = 0, acc_bar = 0;
+  #endif
+      for (int st = 0; st < n_stages; ++st) {
+        const int SP = st & 1;
+  #ifdef NMV_W4S_STAMPS
+        const unsigned long long t_a = __builtin_amdgcn_s_memrealtime();
+  #endif
+        uint4 ar[UPB][4], sr[SPT];
+        const bool more = st + 1 < n_stages;             // uniform; loads past the end are switched off by their offset
+        const uint32_t a_vo_st = more ? a_vo : OOB_OFF;
+        auto fetch = [&](int b) {
+  #pragma unroll
+          for (int i = 0; i < UPB; ++i) {
+            const uint32_t so = (uint32_t)(grp_k0(gb0 + (b * UPB + i) * GB_STEP, st + 1) * 2);
+  #pragma unroll
+            for (int cc = 0; cc < 4; ++cc) ar[i][cc] = buf_ld16<0>(rs_a, a_vo_st, so + cc * 16);
+          }
+        };
+        auto park = [&](int b) {
+  #pragma unroll
+          for (int i = 0; i < UPB; ++i) {
+            const int gb = gb0 + (b * UPB + i) * GB_STEP;
+            a_store(s_row, gb, SP ^ 1, more ? (gb / GST) * GW + (st + 1) * GST + (gb % GST) : -1, ar[i]);   // past the end: zeros, no sum
+          }
+        };
+  #ifndef NMV_W4S_ABLATE_A
+        fetch(0);
+  #endif
+  #pragma unroll
+        for (int i = 0; i < SPT; ++i) sr[i] = buf_ld16<0>(rs_s, more ? s_vo[i] : OOB_OFF, (uint32_t)(st + 1) * s_stage_bytes);
+        auto mid = [&] {
+  #ifndef NMV_W4S_ABLATE_A
+          if constexpr (AH == 2) { park(0); fetch(1); }
+  #endif
+        };
+        auto body = [&](auto gi_tag) {
+          constexpr int GI = decltype(gi_tag)::value;
+          if constexpr (GI < GST) {
+            constexpr int U = GI % D;
+            if constexpr (GI == 0) {
+              group_compute(std::integral_constant<int, U>{}, st * GST + GI, kp * GST + GI, SP, mid, nop);
+            } else {
+              group_compute(std::integral_constant<int, U>{}, st * GST + GI, kp * GST + GI, SP, nop, nop);
+            }
+          }
+        };
+        body(std::integral_constant<int, 0>{});
+        body(std::integral_constant<int, 1>{});
+  #ifdef NMV_W4S_STAMPS
+        const unsigned long long t_b = __builtin_amdgcn_s_memrealtime();
+  #endif
+  #ifndef NMV_W4S_ABLATE_A
+        park(AH - 1);
+  #endif
+  #pragma unroll
+        for (int i = 0; i < SPT; ++i)
+          if (tid + i * NTHR < P * GST * CPW * 8) s_store(tid + i * NTHR, SP ^ 1, sr[i]);
+  #ifdef NMV_W4S_STAMPS
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const unsigned long long t_c = __builtin_amdgcn_s_memrealtime();
+  #endif
+        __syncthreads();
+  #ifdef NMV_W4S_STAMPS
+        const unsigned long long t_d = __builtin_amdgcn_s_memrealtime();
+        acc_compute += t_b - t_a; acc_park += t_c - t_b; acc_bar += t_d - t_c;
+  #endif
+      }
+  #ifdef NMV_W4S_STAMPS
+      if (lane == 0) {
+        unsigned long long* q = g_w4s_stamps + (((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * NW + wave) * 8;
+        q[6] = acc_compute | (acc_park << 32);
+        q[7] = acc_bar;
+      }
+  #endif
     }
-#ifdef NMV_W4S_STAMPS
-    if (lane == 0) {
-      unsigned long long* q = g_w4s_stamps + (((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * NW + wave) * 8;
-      q[6] = acc_compute | (acc_park << 32);
-      q[7] = acc_bar;
-    }
-#endif
   }
 
-  // ---- zero point: acc += sum_g s[g, n] * (-24 * S[g, m]) as ONE more MFMA k-step per 16 groups: the k slots are
+  // ---- zero point: acc += sum_g s[g, n] * (-ZPC * S[g, m]) as ONE more MFMA k-step per 16 groups: the k slots are
   //      (group, hi / lo half of the fp32 value split into two bf16), the weight-side operand holds s[g, n] in both
   //      halves.  The split keeps 16 significant bits of a term that is O(24 |sum a| s) -- 2^-17 relative, far below
-  //      the model dtype's rounding -- and a one-hot activation row stays exact (-24 has no low half) ----
+  //      the model dtype's rounding -- and a one-hot activation row stays exact (-24 has no low half).  The native
+  //      bf16 form (128 + q: the term is 2^7 above the signal) splits three ways, the third part in a second MFMA ----
   {
     const float* zs = ns_s + kp * GW * MP;
+    constexpr bool IS_F16 = std::is_same<T, F16>::value;
+    constexpr int NPASS = (NV && !IS_F16) ? 2 : 1;
     for (int gq = 0; gq < GW; gq += 16) {
-      // weight side: lane (r, g) = column 16 j + r, groups gq + 4 g + e; one 16-byte piece of the permuted scale row
-      // holds the column's four tiles j (dword j, half r >> 3)
-      uint4 sp[4];
+      // weight side: lane (r, g) = column 16 j + r, groups gq + 4 g + e.  Marlin: one 16-byte piece of the permuted
+      // scale row holds the column's four tiles j (dword j, half r >> 3); native: the dword of columns (n & ~1, + 1)
+      uint32_t sraw[4][4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int gi = gq + 4 * g + e;
         const bool ok = chunk_ok && gi < GW;
-        sp[e] = buf_ld16<0>(rs_s, ok ? (uint32_t)((chunk * 64 + (r & 7) * 8) * 2 + ((k_w0 >> 7) + gi) * p.N * 2) : OOB_OFF, 0);
+        const uint32_t row_off = (uint32_t)(((k_w0 >> 7) + gi) * p.N * 2);
+        if constexpr (NV) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            sraw[e][j] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(
+                rs_s, ok ? (int)((uint32_t)((chunk * 64 + 16 * j + (r & ~1)) * 2) + row_off) : (int)OOB_OFF, 0, 0);
+        } else {
+          const uint4 sp = buf_ld16<0>(rs_s, ok ? (uint32_t)((chunk * 64 + (r & 7) * 8) * 2) + row_off : OOB_OFF, 0);
+          sraw[e][0] = sp.x; sraw[e][1] = sp.y; sraw[e][2] = sp.z; sraw[e][3] = sp.w;
+        }
       }
-      const uint32_t hsel = (r >> 3) ? 0x03020302u : 0x01000100u;
+      const uint32_t hsel = (NV ? (r & 1) : (r >> 3)) ? 0x03020302u : 0x01000100u;
       // fp16: the sum can leave the type's range (24 * 128 * |a|), so the value travels as z / 16 beside 16 * s
       // (both exact); bf16: high half by truncation
-      constexpr bool IS_F16 = std::is_same<T, F16>::value;
-      uint4 zb[MT];
+      uint4 zb[NPASS][MT];
 #pragma unroll
       for (int t = 0; t < MT; ++t) {
-        uint32_t d[4];
+        uint32_t d[NPASS][4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int gi = gq + 4 * g + e;
@@ -498,24 +766,24 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void w4a16_stream_kernel(const Gem
           if constexpr (IS_F16) {
             z *= 0.0625f;
             const uint16_t zh = T::from_float(z);
-            d[e] = (uint32_t)zh | ((uint32_t)T::from_float(z - T::to_float(zh)) << 16);
+            d[0][e] = (uint32_t)zh | ((uint32_t)T::from_float(z - T::to_float(zh)) << 16);
           } else {
             const uint32_t zh = __float_as_uint(z) & 0xffff0000u;
-            d[e] = (zh >> 16) | ((uint32_t)T::from_float(z - __uint_as_float(zh)) << 16);
+            const float rem = z - __uint_as_float(zh);
+            const uint16_t zm = T::from_float(rem);
+            d[0][e] = (zh >> 16) | ((uint32_t)zm << 16);
+            if constexpr (NPASS == 2) d[1][e] = (uint32_t)T::from_float(rem - T::to_float(zm));
           }
         }
-        zb[t] = make_uint4(d[0], d[1], d[2], d[3]);
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) zb[ps][t] = make_uint4(d[ps][0], d[ps][1], d[ps][2], d[ps][3]);
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const uint32_t w[4] = {j == 0 ? sp[0].x : j == 1 ? sp[0].y : j == 2 ? sp[0].z : sp[0].w,
-                               j == 0 ? sp[1].x : j == 1 ? sp[1].y : j == 2 ? sp[1].z : sp[1].w,
-                               j == 0 ? sp[2].x : j == 1 ? sp[2].y : j == 2 ? sp[2].z : sp[2].w,
-                               j == 0 ? sp[3].x : j == 1 ? sp[3].y : j == 2 ? sp[3].z : sp[3].w};
         uint32_t sd[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          sd[e] = __builtin_amdgcn_perm(w[e], w[e], hsel);   // the column's scale in both halves
+          sd[e] = __builtin_amdgcn_perm(sraw[e][j], sraw[e][j], hsel);   // the column's scale in both halves
           if constexpr (IS_F16) {
             const uint16_t s16 = T::from_float(16.0f * T::to_float((uint16_t)(sd[e] & 0xffffu)));
             sd[e] = (uint32_t)s16 | ((uint32_t)s16 << 16);
@@ -523,7 +791,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void w4a16_stream_kernel(const Gem
         }
         const uint4 sa = make_uint4(sd[0], sd[1], sd[2], sd[3]);
 #pragma unroll
-        for (int t = 0; t < MT; ++t) accm[j][t] = W4<T>::mfma(sa, zb[t], accm[j][t]);
+        for (int ps = 0; ps < NPASS; ++ps)
+#pragma unroll
+          for (int t = 0; t < MT; ++t) accm[j][t] = W4<T>::mfma(sa, zb[ps][t], accm[j][t]);
       }
     }
   }
@@ -721,9 +991,9 @@ bool w4s_make_plan(int M, int N, int K, int64_t tickets_len, bool unsplit, bool 
   return true;
 }
 
-template <typename T, int MT, int NW, int CPW, int D, int GST>
+template <typename T, int MT, int NW, int CPW, int D, int GST, bool NV>
 static int w4s_launch_one(const W4StreamPlan& pl, const GemmParams& p, hipStream_t s) {
-  auto kern = w4a16_stream_kernel<T, MT, NW, CPW, D, GST>;
+  auto kern = w4a16_stream_kernel<T, MT, NW, CPW, D, GST, NV>;
   static int max_lds = 0;   // per instantiation
   if (pl.lds_bytes > max_lds) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -736,24 +1006,30 @@ static int w4s_launch_one(const W4StreamPlan& pl, const GemmParams& p, hipStream
   return 0;
 }
 
-template <typename T>
+template <typename T, bool NV>
 static int w4s_launch_t(const W4StreamPlan& pl, const GemmParams& p, hipStream_t s) {
 #define NMV_W4S_CASE_(mt_, nw_, cpw_, d_, gst_)                                                  \
   if (pl.mt == mt_ && pl.nw == nw_ && pl.cpw == cpw_ && pl.d == d_ && pl.gst == gst_)           \
-    return w4s_launch_one<T, mt_, nw_, cpw_, d_, gst_>(pl, p, s);
+    return w4s_launch_one<T, mt_, nw_, cpw_, d_, gst_, NV>(pl, p, s);
 #define NMV_W4S_CASE(...) NMV_W4S_CASE_(__VA_ARGS__)
 #ifdef NMV_W4S_PROBE_CASE   // development: one instantiation only (tools/kernel_resources.py ... -DNMV_W4S_PROBE_CASE=4,8,2,1,1)
   NMV_W4S_CASE(NMV_W4S_PROBE_CASE)
 #else
-  // resident
-  NMV_W4S_CASE(1, 8, 2, 2, 0) NMV_W4S_CASE(1, 8, 2, 3, 0) NMV_W4S_CASE(1, 8, 1, 2, 0) NMV_W4S_CASE(1, 8, 1, 3, 0)
-  NMV_W4S_CASE(1, 8, 4, 3, 0)
-  NMV_W4S_CASE(1, 4, 1, 3, 0) NMV_W4S_CASE(1, 4, 2, 3, 0) NMV_W4S_CASE(1, 4, 2, 2, 0)
-  NMV_W4S_CASE(1, 16, 2, 2, 0) NMV_W4S_CASE(1, 16, 4, 2, 0)
-  NMV_W4S_CASE(2, 8, 1, 3, 0) NMV_W4S_CASE(2, 8, 2, 3, 0) NMV_W4S_CASE(2, 8, 4, 3, 0) NMV_W4S_CASE(2, 8, 2, 2, 0)
-  // streamed
-  NMV_W4S_CASE(4, 8, 2, 1, 1) NMV_W4S_CASE(4, 8, 4, 1, 1)
-  NMV_W4S_CASE(2, 8, 2, 2, 2) NMV_W4S_CASE(2, 8, 2, 1, 2) NMV_W4S_CASE(2, 8, 2, 1, 1)
+  if constexpr (NV) {   // the native tensor: the plan's defaults and what tools/sweep_stream.py visits around them
+    NMV_W4S_CASE(1, 8, 2, 2, 0) NMV_W4S_CASE(1, 8, 2, 3, 0) NMV_W4S_CASE(1, 4, 2, 3, 0) NMV_W4S_CASE(1, 4, 2, 2, 0)
+    NMV_W4S_CASE(2, 8, 2, 3, 0) NMV_W4S_CASE(2, 8, 4, 3, 0) NMV_W4S_CASE(2, 8, 2, 2, 0)
+    NMV_W4S_CASE(4, 8, 2, 1, 1) NMV_W4S_CASE(4, 8, 4, 1, 1) NMV_W4S_CASE(2, 8, 2, 2, 2) NMV_W4S_CASE(2, 8, 2, 1, 2)
+  } else {
+    // resident
+    NMV_W4S_CASE(1, 8, 2, 2, 0) NMV_W4S_CASE(1, 8, 2, 3, 0) NMV_W4S_CASE(1, 8, 1, 2, 0) NMV_W4S_CASE(1, 8, 1, 3, 0)
+    NMV_W4S_CASE(1, 8, 4, 3, 0)
+    NMV_W4S_CASE(1, 4, 1, 3, 0) NMV_W4S_CASE(1, 4, 2, 3, 0) NMV_W4S_CASE(1, 4, 2, 2, 0)
+    NMV_W4S_CASE(1, 16, 2, 2, 0) NMV_W4S_CASE(1, 16, 4, 2, 0)
+    NMV_W4S_CASE(2, 8, 1, 3, 0) NMV_W4S_CASE(2, 8, 2, 3, 0) NMV_W4S_CASE(2, 8, 4, 3, 0) NMV_W4S_CASE(2, 8, 2, 2, 0)
+    // streamed
+    NMV_W4S_CASE(4, 8, 2, 1, 1) NMV_W4S_CASE(4, 8, 4, 1, 1)
+    NMV_W4S_CASE(2, 8, 2, 2, 2) NMV_W4S_CASE(2, 8, 2, 1, 2) NMV_W4S_CASE(2, 8, 2, 1, 1)
+  }
 #endif
 #undef NMV_W4S_CASE
 #undef NMV_W4S_CASE_
@@ -767,7 +1043,8 @@ extern "C" int nmv_dbg_w4s_stamps(unsigned long long* host, int n) {
 #endif
 
 int w4s_launch(const W4StreamPlan& pl, const GemmParams& p, bool f16, hipStream_t s) {
-  return f16 ? w4s_launch_t<F16>(pl, p, s) : w4s_launch_t<BF16>(pl, p, s);
+  if (p.native) return f16 ? w4s_launch_t<F16, true>(pl, p, s) : w4s_launch_t<BF16, true>(pl, p, s);
+  return f16 ? w4s_launch_t<F16, false>(pl, p, s) : w4s_launch_t<BF16, false>(pl, p, s);
 }
 
 }  // namespace nmv

@@ -106,7 +106,9 @@ def test_native_deferred_slabs_sum_to_the_gemm(gpu_device, m, k, n, dtype):
 def test_native_silu_mul_epilogue_matches_separate_ops(gpu_device, m, dtype):
     from neural_magic_vllm_amd import _custom_ops as ops
     from neural_magic_vllm_amd.model_executor.layers.quantization.gptq_marlin import GPTQMarlinLinearMethod as LM
-    k, inter = 1024, 3584
+    # a projection wide enough that neither form splits K across workgroups (as the Marlin twin of this test,
+    # test_gpu_w4a16.py: the fused form never splits, and a split plain GEMM sums its fp32 slabs in another order)
+    k, inter = 512, 8192
     n = 2 * inter
     a, q_w, s, _ = problem(5, m, k, n, 128, dtype)
     plain = native_gemm(a, q_w, s, k, n, gpu_device, 0)
