@@ -83,9 +83,9 @@ def gemm_roofline(runner, batch, dev, groups=32):
                 continue
             k, n = m.input_size_per_partition, m.output_size_per_partition
             if as_model[0] and getattr(m, "gate_up_interleaved", False):
-                ops.gptq_marlin_gemm_silu_mul(x, m.qweight, m.scales, m.workspace, batch, n, k)
+                m.quant_method.apply_silu_mul(m, x)     # the LinearMethod's own entry points: MFMA-native copy when it keeps one
             elif as_model[0] and j != 2 and ops.gptq_marlin_gemm_partial_splits(batch, n, k) >= 1:
-                ops.gptq_marlin_gemm_partial(x, m.qweight, m.scales, batch, n, k)
+                m.quant_method.apply_partial(m, x)
             else:
                 # gate_up weights may be column-interleaved for the silu epilogue: same bytes, same time
                 ops.gptq_marlin_gemm(x, m.qweight, m.scales, m.g_idx, m.g_idx_sort_indices,
@@ -128,6 +128,8 @@ def gemm_roofline(runner, batch, dev, groups=32):
         as_model[0] = True
         in_model = {"avg_us_per_launch_group": round(timed(None), 2),
                     "per_gemm_us": {nm: round(timed(j), 2) for j, nm in enumerate(names)},
+                    "weights": "MFMA-native copy (nmv_w4_native_gemm)" if getattr(mods[0], "qweight_native", None) is not None
+                               else "Marlin tensor",
                     "note": "the same four launches as the decode step issues them: qkv / o / down leave "
                             "fp32 split-K slabs that the following rope+cache / norm launch sums (deferred "
                             "reduction), gate_up applies silu_and_mul in its epilogue; `achieved` above is "

@@ -12,8 +12,10 @@ Life of a layer
 
 Beyond the reference's LinearMethod (used by the decode harness, each bit-identical to `apply` + the op it absorbs;
 DESIGN.md 3.2): `apply_partial` leaves the split-K reduction to the next launch, `apply_silu_mul` folds silu_and_mul
-into the gate_up GEMM's epilogue on column-interleaved weights, and an optional MFMA-native copy of the codes
-(NMV_W4_NATIVE=1) serves decode-sized calls."""
+into the gate_up GEMM's epilogue on column-interleaved weights, and an MFMA-native copy of the codes (group 128;
+kept beside the Marlin tensor unless NMV_W4_NATIVE=0: + 0.5 byte per weight) serves calls of up to 64 rows through
+csrc/w4a16_stream.hip's native form -- no lane exchange, no activation transpose; the Marlin tensor keeps the
+prompt-sized calls and the reference op `gptq_marlin_gemm`."""
 import enum
 import os
 from typing import Any, Dict, List, Optional
@@ -272,7 +274,7 @@ class GPTQMarlinLinearMethod(LinearMethodBase):
                 and layer.input_size_per_partition % 256 == 0 and layer.is_k_full)
 
     def native_eligible(self, layer: torch.nn.Module) -> bool:
-        return (os.environ.get("NMV_W4_NATIVE", "0") == "1" and self._plain_w4(layer)
+        return (os.environ.get("NMV_W4_NATIVE", "1") != "0" and self._plain_w4(layer) and self.quant_config.group_size == 128
                 and layer.output_size_per_partition % 64 == 0 and layer.qweight.is_cuda)
 
     @classmethod

@@ -27,6 +27,7 @@ if __name__ == "__main__":
     ap.add_argument("--shapes", default="qkv,o,gate_up,down")
     ap.add_argument("--mode", type=int, default=0)
     ap.add_argument("--iters", type=int, default=16)
+    ap.add_argument("--native", action="store_true", help="nmv_w4_native_gemm (the MFMA-native tensor) in the same mode")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     for name in args.shapes.split(","):
@@ -35,10 +36,10 @@ if __name__ == "__main__":
             res = []
             clear()
             os.environ["NMV_W4S"] = "0"
-            us, _ = bench(name, k, n, m, dev, iters=args.iters, mode=args.mode)
+            us, _ = bench(name, k, n, m, dev, iters=args.iters, mode=args.mode, native=args.mode if args.native else None)
             res.append((us, "tall"))
             clear()
-            us, _ = bench(name, k, n, m, dev, iters=args.iters, mode=args.mode)
+            us, _ = bench(name, k, n, m, dev, iters=args.iters, mode=args.mode, native=args.mode if args.native else None)
             res.append((us, "default"))
             mts = [1] if m <= 16 else ([2, 1] if m <= 32 else [4, 2, 1])
             for mt in mts:
@@ -54,7 +55,7 @@ if __name__ == "__main__":
                     os.environ.update({"NMV_W4S_STRICT": "1", "NMV_W4S_MT": str(mt), "NMV_W4S_NW": str(nw), "NMV_W4S_CPW": str(cpw),
                                        "NMV_W4S_D": str(d), "NMV_W4S_SPLITS": str(sp), "NMV_W4S_GST": str(gst)})
                     try:
-                        us, _ = bench(name, k, n, m, dev, iters=args.iters, mode=args.mode)
+                        us, _ = bench(name, k, n, m, dev, iters=args.iters, mode=args.mode, native=args.mode if args.native else None)
                     except Exception as e:  # plan not available / no kernel for it
                         continue
                     res.append((us, f"mt{mt}/gst{gst}/nw{nw}/cpw{cpw}/d{d}/sp{sp}"))
