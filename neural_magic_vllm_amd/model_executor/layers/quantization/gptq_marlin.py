@@ -279,7 +279,12 @@ class GPTQMarlinLinearMethod(LinearMethodBase):
 
     @classmethod
     def _native(cls, layer, size_m: int) -> bool:
-        return size_m <= cls.NATIVE_MAX_M and getattr(layer, "qweight_native", None) is not None
+        """measured on MI355X (tools/bench_gemm.py --native): the native form wins by 3-7 % up to 16 rows and from 33 to 64,
+        and loses 10-15 % on the wide projection at 17..32 rows (the 32-row tile with 256-k activation stages), so
+        those calls keep the Marlin tensor"""
+        if getattr(layer, "qweight_native", None) is None:
+            return False
+        return size_m <= 16 or 32 < size_m <= cls.NATIVE_MAX_M
 
     # ---- deferred split-K: the GEMM leaves fp32 slabs, the following launch sums them ------------------------------
     def can_defer_reduce(self, layer: torch.nn.Module) -> bool:
