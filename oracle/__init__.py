@@ -208,6 +208,21 @@ def scaled_fp8_quant(input, scale=None):
     return out, scale
 
 
+def fp8_marlin_gemm(a, b_q_weight, b_scales, size_m, size_n, size_k):
+    """csrc/quantization/fp8/fp8_marlin.cu:1212-1308 as arithmetic: the 8-bit Marlin tensor holds fp8-e4m3 bytes
+    (pack_fp8_to_int32 + gptq_marlin_repack with num_bits = 8), b_scales is the channelwise scale row in
+    marlin_permute_scales order; the kernel dequantises byte -> half exactly, multiplies by the channel scale in the
+    model dtype and accumulates in fp32.  Composed of pinned pieces: marlin_unpack, fp8_decode."""
+    from . import ref_math
+    w = fp8_decode(marlin_unpack(b_q_weight, size_k, size_n, 8))                   # [K, N] fp32, exact
+    _, single = ref_math.scale_perms()
+    inv = torch.empty(len(single), dtype=torch.long)
+    inv[torch.tensor(single)] = torch.arange(len(single))
+    s = _cpu(b_scales).reshape(-1, len(single))[:, inv].reshape(1, size_n)         # natural column order
+    w = (w.to(a.dtype) * s.to(a.dtype)).float()                                    # scale applied in the model dtype
+    return (_cpu(a).float() @ w).to(a.dtype)
+
+
 def scaled_mm(a, b, scale_a, scale_b, out_dtype, bias=None):
     """a [M,K] int8 / float8_e4m3fn, b [K,N] column-major; returns [M,N] in out_dtype"""
     m, k = a.shape

@@ -108,3 +108,19 @@ def test_paged_attention_v1_v2_truth_table():
             parts = (msl + _PARTITION_SIZE - 1) // _PARTITION_SIZE
             assert parts == row["partitions"] and row["tmp_shape"] == [ns, nh, parts, t["head_size"]]
             assert row["exp_sums_shape"] == [ns, nh, parts] and row["exp_sums_dtype"] == "torch.float32"
+
+
+@pytest.mark.parametrize("case", [0, 1, 2])
+def test_fp8_marlin_gemm_oracle_vs_reference_recipe(case):
+    """tests/golden/fp8_marlin_*.npz = what the reference's test_fp8_marlin_gemm (tests/kernels/test_marlin_gemm.py:238-304)
+    drew and expected when it was run in place (tools/make_golden_fp8_marlin.py); its checker is
+    compute_max_diff = mean|out - ref| / mean|ref| < 0.04 (marlin_utils.py compute_max_diff)"""
+    g = np.load(os.path.join(GOLD, f"fp8_marlin_{case}.npz"))
+    dt = getattr(torch, str(g["dtype"]))
+    m, n, k = int(g["m"]), int(g["n"]), int(g["k"])
+    a = helpers.from_np(g["a"], dt)
+    out = oracle.fp8_marlin_gemm(a, torch.from_numpy(g["marlin_q"].copy()), helpers.from_np(g["marlin_s"], dt), m, n, k)
+    ref = helpers.from_np(g["output_ref"], dt)
+    diff = ((out.float() - ref.float()).abs().mean() / ref.float().abs().mean()).item()
+    assert diff < 0.04
+    assert abs(diff - float(g["reference_max_diff_of_oracle"])) < 1e-3
