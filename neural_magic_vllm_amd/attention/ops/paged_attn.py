@@ -16,6 +16,7 @@ from ... import _custom_ops as ops
 
 PARTITION_TOKENS = 512    # PA_PARTITION of csrc/attention_kernels.hip = the reference's _PARTITION_SIZE
 _PARTITION_SIZE = PARTITION_TOKENS
+_FUSED_V1_MAX_CONTEXT = 896   # use_v1_fused: up to here one launch beats partitions + reduce on MI355X
 _V1_MAX_CONTEXT = 8192    # beyond it the reference always partitions (paged_attn.py:112-121)
 _V1_MIN_PAIRS = 512       # (sequence, head) pairs above which one launch already fills the GPU
 
@@ -92,6 +93,17 @@ class PagedAttention:
         return _partitions(max_seq_len) == 1 or num_seqs * num_heads > _V1_MIN_PAIRS
 
     @staticmethod
+    def use_v1_fused(max_seq_len: int, num_seqs: int, num_heads: int) -> bool:
+        """the choice for this repo's own fused launch (forward_decode_rope_partial: not a reference path, so not bound
+        to the reference's rule).  Measured on MI355X (tools/bench_attn.py --v2 --fused 2, profiles/r03_attn_v1v2.txt):
+        the unpartitioned kernel walks a context with 8 waves per (sequence, kv head) when the grid is small, so up to
+        ~900 tokens it beats two 512-token partitions plus the reduce launch (B=1, 530 tokens: 12.0 vs 15.1 us;
+        break-even near 1000); beyond that, and whenever the reference's rule says v1, the two agree"""
+        if PagedAttention.use_v1(max_seq_len, num_seqs, num_heads):
+            return True
+        return max_seq_len <= _FUSED_V1_MAX_CONTEXT
+
+    @staticmethod
     def forward_decode(query: torch.Tensor, key_cache: torch.Tensor, value_cache: torch.Tensor,
                        block_tables: torch.Tensor, seq_lens: torch.Tensor, max_seq_len: int, kv_cache_dtype: str,
                        num_kv_heads: int, scale: float, alibi_slopes: Optional[torch.Tensor], kv_scale: float,
@@ -123,7 +135,7 @@ class PagedAttention:
         num_seqs = slab.shape[-2]
         out = torch.empty((num_seqs, num_heads, head_size), dtype=dtype, device=slab.device)
         bufs = None
-        if not PagedAttention.use_v1(max_seq_len, num_seqs, num_heads):
+        if not PagedAttention.use_v1_fused(max_seq_len, num_seqs, num_heads):
             bufs = _PartitionBuffers(num_seqs, num_heads, head_size, max_seq_len, dtype, slab.device).as_tuple()
         ops.paged_attention_rope_partial(out, slab, positions, cos_sin_cache, slot_mapping, key_cache, value_cache,
                                          num_heads, num_kv_heads, head_size, scale, block_tables, seq_lens,

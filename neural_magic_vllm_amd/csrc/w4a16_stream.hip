@@ -935,7 +935,10 @@ bool w4s_make_plan(int M, int N, int K, int64_t tickets_len, bool unsplit, bool 
   pl.m_blocks = (M + mp - 1) / mp;
   pl.nw = env_i("NMV_W4S_NW", (!wide && mt == 1 && !solo) ? 4 : 8);
   const int gst = env_i("NMV_W4S_GST", !wide ? 0 : mt == 4 ? 1 : mt == 2 ? 2 : 0);
-  const int cpw = env_i("NMV_W4S_CPW", solo ? 1 : (!wide && mt == 2 && M > 32) ? 4 : 2);
+  // two row blocks of 32 (M = 33..64) on a narrow projection: four chunks per workgroup halve the activation staging, but
+  // need twice the split-K slabs to reach 256 workgroups; o_proj-sized launches (< 96 chunks, K <= 8192) are as fast
+  // with two chunks and half the slabs (profiles/r03_sweep_stream.txt: 9.2 vs 9.3 us), and their consumer reads half
+  const int cpw = env_i("NMV_W4S_CPW", solo ? 1 : (!wide && mt == 2 && M > 32 && (n_chunks >= 96 || K > 8192)) ? 4 : 2);
   if (cpw != 1 && cpw != 2 && cpw != 4) return false;
   if (pl.nw != 4 && pl.nw != 8 && pl.nw != 16) return false;
   if (pl.nw % cpw != 0) return false;

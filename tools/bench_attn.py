@@ -13,7 +13,7 @@ from neural_magic_vllm_amd import _custom_ops as ops  # noqa: E402
 from neural_magic_vllm_amd.attention.ops.paged_attn import PagedAttention  # noqa: E402
 
 
-def bench(b, L, dev, kv, iters=20, nq=32, nkv=8, d=128, bs=16, fused=0, sparse=None):
+def bench(b, L, dev, kv, iters=20, nq=32, nkv=8, d=128, bs=16, fused=0, sparse=None, v2=False):
     """fused = S > 0: the decode step's form -- the kernel starts from S fp32 split-K slabs of the qkv projection
     (slab sums + rotary + cache store of the new token in its prologue; L counts the new token);
     sparse = (local_blocks, vert_stride, block_size, head_sliding_step): block-sparse attention"""
@@ -43,10 +43,18 @@ def bench(b, L, dev, kv, iters=20, nq=32, nkv=8, d=128, bs=16, fused=0, sparse=N
         cos_sin = torch.cat([t.cos(), t.sin()], dim=-1).to(torch.bfloat16).contiguous()
         slots = [(tb[:, (L - 1) // bs].to(torch.int64) * bs + (L - 1) % bs).contiguous() for tb in tables]
 
+    bufs = None
+    if v2:   # the partitioned form (512-token partitions + the reduce launch)
+        from neural_magic_vllm_amd.attention.ops.paged_attn import _PartitionBuffers
+        bufs = _PartitionBuffers(b, nq, d, L, torch.bfloat16, dev).as_tuple()
+
     def run(i):
         if fused:
             ops.paged_attention_rope_partial(out, slab, positions, cos_sin, slots[i], kc, vc, nq, nkv, d, d**-0.5,
-                                             tables[i], seq_lens, bs, L, "fp8" if kv == "fp8" else "auto", 1.0)
+                                             tables[i], seq_lens, bs, L, "fp8" if kv == "fp8" else "auto", 1.0, bufs)
+        elif v2:
+            ops.paged_attention_v2(out, *bufs, q, kc, vc, nkv, d**-0.5, tables[i], seq_lens, bs, L, None,
+                                   "fp8" if kv == "fp8" else "auto", 1.0)
         elif sparse:
             ops.paged_attention_v1(out, q, kc, vc, nkv, d**-0.5, tables[i], seq_lens, bs, L, None,
                                    "fp8" if kv == "fp8" else "auto", 1.0, 0, sparse[0], sparse[1], sparse[2], sparse[3])
@@ -83,6 +91,7 @@ if __name__ == "__main__":
     ap.add_argument("--kv", default="auto")
     ap.add_argument("--fused", type=int, default=0, help="also time the fused rope + cache + attention form from "
                     "this many fp32 qkv slabs")
+    ap.add_argument("--v2", action="store_true", help="also time the partitioned form (v2 + reduce) of every column")
     ap.add_argument("--sparse", default="", help="local_blocks,vert_stride,block_size,head_sliding_step: also time "
                     "block-sparse attention (masked windows are skipped before their K / V are loaded)")
     args = ap.parse_args()
@@ -94,9 +103,15 @@ if __name__ == "__main__":
         if args.sparse:
             su, _ = bench(b, L, dev, args.kv, sparse=tuple(int(v) for v in args.sparse.split(",")))
             extra += f"   block-sparse ({args.sparse}) {su:8.1f} us"
+        if args.v2:
+            vu, _ = bench(b, L, dev, args.kv, v2=True)
+            extra += f"   v2 {vu:8.1f} us"
         if args.fused:
             fu, fg = bench(b, L, dev, args.kv, fused=args.fused)
             extra += f"   fused prologue ({args.fused} slabs) {fu:8.1f} us {fg:7.0f} GB/s"
+            if args.v2:
+                fv, _ = bench(b, L, dev, args.kv, fused=args.fused, v2=True)
+                extra += f"   fused v2 {fv:8.1f} us"
         print(f"attn v1 B={b:3d} L={L:5d} kv={args.kv}  {us:8.1f} us  {gbs:7.0f} GB/s{extra}", flush=True)
 
 
