@@ -106,6 +106,14 @@ __device__ __forceinline__ f32x2_t fp8x2_to_f32(uint32_t w) {
 __device__ __forceinline__ float fp8_to_f32(uint8_t b) {
   return __builtin_amdgcn_cvt_f32_fp8((int)b, 0);
 }
+// fp8 x4 (one dword) -> two packed T pairs: (byte 0, byte 1) and (byte 2, byte 3), exact (3 mantissa bits)
+template <typename T>
+__device__ __forceinline__ void fp8x4_to_pairs_t(uint32_t w, uint32_t& p0, uint32_t& p1) {
+  const f32x2_t a = fp8x2_to_f32<false>(w);
+  const f32x2_t b = fp8x2_to_f32<true>(w);
+  p0 = T::pack2(a.x, a.y);
+  p1 = T::pack2(b.x, b.y);
+}
 // float -> fp8 e4m3fn byte, round-to-nearest-even, saturating to +-448 (NaN stays NaN)
 __device__ __forceinline__ uint8_t f32_to_fp8(float f) {
   float c = __builtin_fminf(__builtin_fmaxf(f, -448.f), 448.f);

@@ -96,6 +96,7 @@ struct GemmParams {
   int group_size;         // 32/64/128, or 0 = channelwise (one scale row)
   int k_per_wg;           // k range of one workgroup (multiple of WK*STAGE_K)
   int splits;
+  int fp8;                // bits == 8: the bytes are fp8-e4m3 numbers (fp8_marlin_gemm), not unsigned codes with zero point 128
   int native;             // b is the MFMA-native tensor of nmv_w4_native_repack, s / zp are natural [groups, N]
   int epi;                // 1: silu(gate) * up epilogue on column-interleaved gate_up weights (tall
                           //    kernel, splits == 1): c is [M, N/2]

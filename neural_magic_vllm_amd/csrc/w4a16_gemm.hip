@@ -557,14 +557,19 @@ __device__ __forceinline__ void w4_tall_epilogue(const GemmParams& p, f32x4_t (&
 // ZP: per-(group, column) zero points (asymmetric AWQ / GPTQ checkpoints repacked to the Marlin
 // layout): p.zp holds z in the model dtype in the layout of the scales; they travel through LDS
 // with the scales (threads 32..63 stage them) and replace the constant 8 in the correction term.
-template <typename T, int MT, int WN, int WK, int GS, bool PS = false, int BITS = 4, bool ZP = false, bool NT = false>
+// F8 (BITS = 8, channelwise scales: fp8_marlin_gemm, fp8_marlin.cu:1212-1308): the bytes of the 8-bit Marlin tensor are
+// fp8-e4m3 numbers; a pair of them becomes a model-dtype pair through the hardware's exact conversion (v_cvt_pk_f32_fp8 +
+// pack: subnormals included, no exponent-bias multiply), there is no zero point and hence no sum-of-activations MFMA.
+template <typename T, int MT, int WN, int WK, int GS, bool PS = false, int BITS = 4, bool ZP = false, bool NT = false,
+          bool F8 = false>
 __global__ __launch_bounds__(GT, 2) void w4a16_gemm_tall_kernel(const GemmParams p) {
+  static_assert(!F8 || (BITS == 8 && GS == 0 && !ZP), "fp8 bytes: 8-bit Marlin tensor, channelwise scales");
   static_assert(!ZP || (BITS == 4 && GS == 128), "zero points: 4-bit, group 128");
   static_assert(WN * WK == 4, "4 waves per workgroup");
   static_assert(BITS == 4 || (BITS == 8 && !PS), "4-bit, or 8-bit without the prescale variant");
   constexpr int WV = BITS / 4;                 // 16-byte loads per lane and k-step
   // what the expanded numbers are offset by: 16 + 8 (4-bit), 128 (8-bit bf16), 1024 + 128 (8-bit fp16)
-  constexpr float ZPC = BITS == 4 ? W4_ZP : (std::is_same<T, F16>::value ? 1152.0f : 128.0f);
+  constexpr float ZPC = F8 ? 0.0f : BITS == 4 ? W4_ZP : (std::is_same<T, F16>::value ? 1152.0f : 128.0f);
   static_assert(MT <= 4 || PS, "128-row tiles only fit without the group accumulators");
   static_assert(GS == 0 || GS == 128, "one scale group per two stages, or channelwise");
   constexpr int MP = 16 * MT;                  // rows per workgroup
@@ -702,7 +707,7 @@ __global__ __launch_bounds__(GT, 2) void w4a16_gemm_tall_kernel(const GemmParams
     if constexpr (PS) return;
     float zs[GT_];
 #pragma unroll
-    for (int t = 0; t < GT_; ++t) zs[t] = -ZPC * accs[t][0];
+    for (int t = 0; t < GT_; ++t) zs[t] = F8 ? 0.0f : -ZPC * accs[t][0];
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
       uint4 d4 = make_uint4(0, 0, 0, 0), z4 = make_uint4(0, 0, 0, 0);
@@ -808,7 +813,13 @@ __global__ __launch_bounds__(GT, 2) void w4a16_gemm_tall_kernel(const GemmParams
           // is my own (block 0 lanes) or the partner's word 2j+1 (block 1 lanes), and vice versa
           const uint32_t e = (uint32_t)__builtin_amdgcn_update_dpp((int)own[2 * j], (int)own[2 * j + 1], 0x128, 0xf, 0xc, false);
           const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp((int)own[2 * j + 1], (int)own[2 * j], 0x128, 0xf, 0x3, false);
-          if constexpr (std::is_same<T, F16>::value) {
+          if constexpr (F8) {
+            // bytes (0, 2) and (1, 3) are the k pairs: bring them together, then two exact fp8 -> f32 -> T conversions
+            uint32_t p0, p1, p2, p3;
+            fp8x4_to_pairs_t<T>(__builtin_amdgcn_perm(e, e, 0x03010200u), p0, p1);
+            fp8x4_to_pairs_t<T>(__builtin_amdgcn_perm(o, o, 0x03010200u), p2, p3);
+            wv = make_uint4(p0, p1, p2, p3);
+          } else if constexpr (std::is_same<T, F16>::value) {
             // bytes {0,2} / {1,3} next to 0x64: fp16 1024 + b, one v_perm_b32 per pair
             wv = make_uint4(__builtin_amdgcn_perm(0x64646464u, e, 0x04020400u), __builtin_amdgcn_perm(0x64646464u, e, 0x04030401u),
                             __builtin_amdgcn_perm(0x64646464u, o, 0x04020400u), __builtin_amdgcn_perm(0x64646464u, o, 0x04030401u));
@@ -839,7 +850,8 @@ __global__ __launch_bounds__(GT, 2) void w4a16_gemm_tall_kernel(const GemmParams
       }
       if constexpr (!PS) {
 #pragma unroll
-        for (int t = 0; t < GT_; ++t) accs[t] = W4<T>::mfma(ones, af[t], first ? zero4 : accs[t]);
+        for (int t = 0; t < GT_; ++t)
+          if constexpr (!F8) accs[t] = W4<T>::mfma(ones, af[t], first ? zero4 : accs[t]);
         if (kstep == 3) flush(gbuf);
       }
     }
@@ -1275,6 +1287,13 @@ static int launch_gemm_gs(const GemmPlan& pl, const GemmParams& p, hipStream_t s
     if (pl.tall && p.bits == 8) {
 #define NMV_W8_TALL_CASE(mt_, wn_, wk_)                                                                  \
   if (pl.mt == mt_ && pl.wn == wn_ && pl.wk == wk_) {                                                    \
+    if constexpr (GS == 0) {                                                                             \
+      if (p.fp8) {                                                                                       \
+        hipLaunchKernelGGL((w4a16_gemm_tall_kernel<T, mt_, wn_, wk_, 0, false, 8, false, false, true>), grid, block, 0, s, p); \
+        return 0;                                                                                        \
+      }                                                                                                  \
+    }                                                                                                    \
+    if (p.fp8) return -1;                                                                                \
     hipLaunchKernelGGL((w4a16_gemm_tall_kernel<T, mt_, wn_, wk_, GS, false, 8>), grid, block, 0, s, p);  \
     return 0;                                                                                            \
   }
@@ -1417,12 +1436,13 @@ extern "C" int64_t nmv_gptq_marlin_gemm_scratch_bytes(int size_m, int size_n, in
   return variant ? std::max(tuned, wq_marlin_fallback_scratch_bytes(size_m, size_n, size_k)) : tuned;
 }
 
+constexpr int NMV_NOT_TALL = -1000;   // marlin_gemm_impl(fp8 = 1): shape outside the tall kernel (no error recorded)
 static int marlin_gemm_impl(void* c, const void* a, const int32_t* b_q_weight, const void* b_scales,
                             const void* b_zeros, const int32_t* g_idx, const int32_t* perm,
                             int32_t* workspace, int64_t workspace_len, void* scratch,
                             int64_t scratch_bytes, int num_bits, int size_m, int size_n, int size_k,
                             int num_groups, int is_k_full, nmv_dtype_t dtype, void* stream,
-                            int epi = 0, int native = 0) {
+                            int epi = 0, int native = 0, int fp8 = 0) {
   // `workspace` (the reference's lock array, zero on entry and exit) holds the split-K tickets
   NMV_CHECK(dtype == NMV_F16 || dtype == NMV_BF16,
             "gpt_marlin_gemm only supports bfloat16 and float16");
@@ -1448,8 +1468,9 @@ static int marlin_gemm_impl(void* c, const void* a, const int32_t* b_q_weight, c
             "Unsupported group_size = %d", group_size);
   // 8-bit codes run the tall kernel when its conditions hold (group 128 / channelwise, no act-order,
   // K in whole rings, at most 128 rows per launch block: M-tiles up to 64 rows exist for 8 bits)
-  const bool tall8 = num_bits == 8 && !has_act_order && (group_size == 0 || group_size == 128) &&
+  const bool tall8 = num_bits == 8 && !has_act_order && (group_size == 0 || (group_size == 128 && !fp8)) &&
                      size_k % 256 == 0 && env_int("NMV_W4_TALL", 1);
+  if (fp8 && !tall8) return NMV_NOT_TALL;   // fp8_marlin_gemm outside the tall kernel's domain: the caller's generic kernel
   if ((num_bits == 8 && !tall8) || (has_act_order && !is_k_full)) {
     // the remaining 8-bit cases, and act-order on a K shard (irregular group runs: one scale row per k
     // through g_idx), take the generic LDS-staged kernel; same math, not HBM-tuned
@@ -1485,6 +1506,7 @@ static int marlin_gemm_impl(void* c, const void* a, const int32_t* b_q_weight, c
       p.k_per_wg = sp.k_per_wg;
       p.splits = sp.splits;
       p.native = native;
+      p.fp8 = 0;
       p.epi = epi;
       p.g_stage = sp.g_stage;
       p.n_stages = sp.n_stages;
@@ -1533,12 +1555,22 @@ static int marlin_gemm_impl(void* c, const void* a, const int32_t* b_q_weight, c
   p.splits = pl.splits;
   p.epi = epi;
   p.native = native;
+  p.fp8 = fp8;
   hipStream_t s = (hipStream_t)stream;
   const int rc = dtype == NMV_F16 ? launch_gemm<F16>(pl, p, s) : launch_gemm<BF16>(pl, p, s);
   NMV_CHECK(rc == 0, "gptq_marlin_gemm: no kernel for plan mt=%d wn=%d wm=%d wk=%d", pl.mt, pl.wn,
             pl.wm, pl.wk);
   NMV_LAUNCH_CHECK();
   return NMV_OK;
+}
+
+// fp8_marlin_gemm on the tall 8-bit kernel (channelwise scales, K % 256 == 0); NMV_NOT_TALL (-1000) when the shape is
+// outside its domain -- wq_generic.hip then takes the generic kernel
+int marlin_tall_fp8(void* c, const void* a, const int32_t* b_q_weight, const void* b_scales, int32_t* workspace,
+                    int64_t workspace_len, void* scratch, int64_t scratch_bytes, int size_m, int size_n, int size_k,
+                    int num_groups, nmv_dtype_t dtype, void* stream) {
+  return marlin_gemm_impl(c, a, b_q_weight, b_scales, nullptr, nullptr, nullptr, workspace, workspace_len, scratch,
+                          scratch_bytes, 8, size_m, size_n, size_k, num_groups, 1, dtype, stream, 0, 0, 1);
 }
 
 /* gate_up projection with silu_and_mul folded into the epilogue (not an op of nm-vllm 0.5.1).

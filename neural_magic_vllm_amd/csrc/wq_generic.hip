@@ -859,20 +859,31 @@ extern "C" int nmv_awq_dequantize(void* out, const int32_t* qweight, const void*
   return NMV_OK;
 }
 
+int marlin_tall_fp8(void* c, const void* a, const int32_t* b_q_weight, const void* b_scales, int32_t* workspace,
+                    int64_t workspace_len, void* scratch, int64_t scratch_bytes, int size_m, int size_n, int size_k,
+                    int num_groups, nmv_dtype_t dtype, void* stream);   // w4a16_gemm.hip
+
 extern "C" int64_t nmv_fp8_marlin_gemm_scratch_bytes(int size_m, int size_n, int size_k) {
   if (size_m <= 0 || size_n <= 0 || size_k <= 0) return 0;
-  return wq_generic_scratch_bytes(size_m, size_n, size_k);
+  // the generic kernel's gathered activations + slabs, or the tall 8-bit kernel's split-K slabs
+  return std::max(wq_generic_scratch_bytes(size_m, size_n, size_k), nmv_gptq_marlin_gemm_scratch_bytes(size_m, size_n, size_k, 0));
 }
 
 extern "C" int nmv_fp8_marlin_gemm(void* c, const void* a, const int32_t* b_q_weight,
                                    const void* b_scales, int32_t* workspace, int64_t workspace_len,
                                    void* scratch, int64_t scratch_bytes, int num_bits, int size_m, int size_n,
                                    int size_k, int num_groups, nmv_dtype_t dtype, void* stream) {
-  (void)workspace; (void)workspace_len;
   NMV_CHECK(dtype == NMV_F16 || dtype == NMV_BF16, "fp8_marlin_gemm only supports bfloat16 and float16");
   NMV_CHECK(num_bits == 8, "num_bits must be 8 for fp8. Got = %d", num_bits);
   NMV_CHECK(size_n % 64 == 0 && size_k % 32 == 0, "fp8_marlin_gemm: N %% 64 and K %% 32 required");
   if (size_m == 0) return NMV_OK;
+  // channelwise scales and K in whole 256-k rings: the tall 8-bit Marlin kernel with the fp8 byte conversion
+  // (4-5 x the generic kernel); `workspace` is the reference's zeroed lock array = its split-K tickets
+  if (num_groups == 1 && workspace != nullptr) {
+    const int rc = marlin_tall_fp8(c, a, b_q_weight, b_scales, workspace, workspace_len, scratch, scratch_bytes, size_m,
+                                   size_n, size_k, num_groups, dtype, stream);
+    if (rc != -1000) return rc;
+  }
   const int rc = wq_marlin_fallback(c, a, b_q_weight, b_scales, nullptr, nullptr, 8, size_m, size_n,
                                     size_k, num_groups, 1, dtype, scratch, scratch_bytes, (hipStream_t)stream);
   NMV_CHECK(rc == 0, "fp8_marlin_gemm: launch failed");
