@@ -398,8 +398,6 @@ class DecodeRunner:
             torch.cuda.synchronize(self.device)
             get_tp_group().barrier()
         try:
-            if os.environ.get("NMV_TEST_FAIL_CAPTURE_RANK") == str(self.tp_rank):   # tests: inject a capture failure
-                raise RuntimeError("injected capture failure (NMV_TEST_FAIL_CAPTURE_RANK)")
             s = torch.cuda.Stream(device=self.device)
             s.wait_stream(prev_stream)
             with torch.cuda.stream(s):
@@ -407,6 +405,10 @@ class DecodeRunner:
                     self._step_body()
             prev_stream.wait_stream(s)
             torch.cuda.synchronize(self.device)
+            # tests: inject a capture failure on one rank -- after the eager warm-up, which every rank has to take part
+            # in (a rank missing from it would leave its peers in the P2P collectives' bounded waits, 2 s each)
+            if os.environ.get("NMV_TEST_FAIL_CAPTURE_RANK") == str(self.tp_rank):
+                raise RuntimeError("injected capture failure (NMV_TEST_FAIL_CAPTURE_RANK)")
             graph = torch.cuda.CUDAGraph()
             # thread_local: helper threads of the process group (watchdog, event polling) may call
             # into the runtime while this thread captures

@@ -297,8 +297,19 @@ def test_paged_attention_rope_partial_matches_separate_launches(gpu_device, head
     qkv = ops.rotary_embedding_and_cache_partial(pos_d, slab, heads, kv_heads, head_size, cos_sin, ref_kc, ref_vc,
                                                  slots_d, kv_cache_dtype, kv_scale, dtype)
     q = qkv[:, :heads * head_size].reshape(num_seqs, heads, head_size)
-    ref = PagedAttention.forward_decode(q, ref_kc, ref_vc, bt_d, sl_d, max_ctx, kv_cache_dtype, kv_heads, scale,
-                                        None, kv_scale)
+    def decode(qq, kcc, vcc):
+        # the separate-launch form of what the fused launch takes: it keeps the unpartitioned kernel up to ~900 tokens
+        # (PagedAttention.use_v1_fused, measured on MI355X) where forward_decode follows the reference's rule and
+        # partitions; v1 and v2 differ in the last bits, so the comparison is form against form
+        if PagedAttention.use_v1_fused(max_ctx, num_seqs, heads) and not PagedAttention.use_v1(max_ctx, num_seqs, heads):
+            out = torch.empty_like(qq)
+            ops.paged_attention_v1(out, qq, kcc, vcc, kv_heads, scale, bt_d, sl_d, block_size, max_ctx, None,
+                                   kv_cache_dtype, kv_scale)
+            return out
+        return PagedAttention.forward_decode(qq, kcc, vcc, bt_d, sl_d, max_ctx, kv_cache_dtype, kv_heads, scale, None,
+                                             kv_scale)
+
+    ref = decode(q, ref_kc, ref_vc)
     kc, vc = caches()
     got = PagedAttention.forward_decode_rope_partial(slab, pos_d, cos_sin, slots_d, kc, vc, bt_d, sl_d, max_ctx,
                                                      kv_cache_dtype, heads, kv_heads, head_size, scale, kv_scale, dtype)
@@ -312,8 +323,7 @@ def test_paged_attention_rope_partial_matches_separate_launches(gpu_device, head
     q2, k2, v2 = rot.split([heads * head_size, kv_heads * head_size, kv_heads * head_size], dim=-1)
     ops.rotary_embedding_and_cache(pos_d, q2, k2, v2, head_size, cos_sin, True, ref_kc2, ref_vc2, slots_d,
                                    kv_cache_dtype, kv_scale)
-    ref2 = PagedAttention.forward_decode(q2.reshape(num_seqs, heads, head_size), ref_kc2, ref_vc2, bt_d, sl_d,
-                                         max_ctx, kv_cache_dtype, kv_heads, scale, None, kv_scale)
+    ref2 = decode(q2.reshape(num_seqs, heads, head_size).contiguous(), ref_kc2, ref_vc2)
     kc2, vc2 = caches()
     got2 = PagedAttention.forward_decode_rope_partial(row, pos_d, cos_sin, slots_d, kc2, vc2, bt_d, sl_d, max_ctx,
                                                       kv_cache_dtype, heads, kv_heads, head_size, scale, kv_scale,

@@ -1,20 +1,10 @@
 #!/bin/bash
 # scratch driver of one gpurun call (edited per call; see tools/gpu_ci.sh for the standing steps)
 mkdir -p gpurun_out
-cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
-prof() {  # name, rocprof args..., -- command
-  name=$1; shift
-  timeout -k 10 300 rocprofv3 "$@" > gpurun_out/$name.log 2>&1
-  echo "== $name rc=$?"
-}
-prof gprof --kernel-trace --output-format csv -d gpurun_out/gprof -- python tools/bench_gemm.py --ms 1,16,64
-find gpurun_out/gprof -name "*kernel_trace.csv" | head -1 | xargs -I{} cp {} gpurun_out/gemm_trace.csv; rm -rf gpurun_out/gprof
-prof gprofn --kernel-trace --output-format csv -d gpurun_out/gprofn -- python tools/bench_gemm.py --native --ms 1,16,64
-find gpurun_out/gprofn -name "*kernel_trace.csv" | head -1 | xargs -I{} cp {} gpurun_out/gemm_trace_native.csv; rm -rf gpurun_out/gprofn
-prof gpmc --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU --kernel-trace --output-format csv -d gpurun_out/gpmc -- python tools/bench_gemm.py --native --ms 1,64 --shapes gate_up
-find gpurun_out/gpmc -name "*counter_collection.csv" | head -1 | xargs -I{} cp {} gpurun_out/gemm_pmc.csv; rm -rf gpurun_out/gpmc
-for c in FETCH_SIZE WRITE_SIZE; do
-  prof traffic_$c --pmc $c --kernel-trace --output-format csv -d gpurun_out/tr_$c -- python tools/bench_gemm.py --ms 1,16,32,64
-  find gpurun_out/tr_$c -name "*counter_collection.csv" | head -1 | xargs -I{} cp {} gpurun_out/traffic_$c.csv; rm -rf gpurun_out/tr_$c
-done
-ls -la gpurun_out/*.csv
+timeout -k 10 400 python -m pytest tests/test_gpu_attention.py -q -m gpu -k "rope_partial" --timeout 200 > gpurun_out/t_attn_rp.log 2>&1; echo "attn rc=$?"; tail -3 gpurun_out/t_attn_rp.log
+timeout -k 10 400 python -m pytest tests/test_gpu_wq_formats.py -q -m gpu --timeout 200 > gpurun_out/t_wq.log 2>&1; echo "wq rc=$?"; tail -3 gpurun_out/t_wq.log
+timeout -k 10 200 python tools/bench_wq.py --generic --ms 1,64 2>&1 | grep -v amdgpu.ids > gpurun_out/r3_wq.log; cat gpurun_out/r3_wq.log
+echo "== failed-capture rehearsal"
+NMV_BENCH_DIST_BACKEND=gloo NMV_BENCH_SINGLE_DEVICE=1 NMV_CUSTOM_ALLREDUCE=force NMV_CUSTOM_AR_TIMEOUT_MS=30000 NMV_TEST_FAIL_CAPTURE_RANK=1 \
+  timeout -k 10 240 python bench.py --gpus 2 --steps 4 --warmup 2 --model tiny --batch 4 --context 40 --no-sweep > gpurun_out/fc.out 2> gpurun_out/fc.err
+echo "rc=$?"; tail -c 600 gpurun_out/fc.out; tail -25 gpurun_out/fc.err
