@@ -460,6 +460,10 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void w4a16_stream_kernel(const Gem
       // and the B operands of k-step ks + 1 are requested during step (ks, 1).  What is left at the end of a stage is
       // the flush of the last tile, two DPP adds and the barrier.
       static_assert(UPT == 1 || UPT == 2 || UPT == 4, "activation units per thread and stage");
+#ifndef NMV_W4S_PARK_KS
+#define NMV_W4S_PARK_KS 2
+#endif
+      constexpr int PARK_KS = NMV_W4S_PARK_KS;   // the k-step in whose MFMA shadow the next stage is parked (probe: 1 / 2 / 3)
       const int gsw = kp & 1;                       // group of the buffer = kp (GST == 1)
       const uint4* a_rd[4];                         // plane (ks, g) of buffer 0, swizzled row r; + 16 t is an immediate
 #pragma unroll
@@ -568,7 +572,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void w4a16_stream_kernel(const Gem
               wvn = make_uint4(xw, xw, xw, xw);
 #endif
 #ifndef NMV_W4S_ABL_PARK   // the next stage is fetched but neither stored nor summed
-              if (ks == 2) {
+              if (ks == PARK_KS) {
                 // pieces q = j UPT .. + UPT - 1 of this thread's stage: dwords d = part UPT .. of the step's 4 UPT
 #pragma unroll
                 for (int i = 0; i < UPT; ++i) {
@@ -610,15 +614,16 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void w4a16_stream_kernel(const Gem
             // the order of the step for the machine scheduler: LDS reads first, then four times [one MFMA, its share of
             // the vector work, at most one LDS store], the ring refill last; nothing crosses into the next step
             constexpr int VX = NV ? 2 : 3;                                  // expansion: 7 / 10 ops in four shares
-            constexpr int V2 = VX + 2 * UPT + (NV ? 0 : 4), V3 = VX + 4;    // + sums (and transposes) / + flush
+            constexpr int VP = 2 * UPT + (NV ? 0 : 4);                      // sums (and transposes) of the park slices
+            constexpr int V2 = VX + VP, V3 = VX + 4 + (PARK_KS == 3 ? VP : 0);   // park step / flush step
             if ((j == 1 && ks < 3) || ks == 3) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
 #pragma unroll
             for (int part = 0; part < 4; ++part) {
               __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-              if (ks == 2) __builtin_amdgcn_sched_group_barrier(0x002, V2, 0);
-              else if (ks == 3) __builtin_amdgcn_sched_group_barrier(0x002, V3, 0);
+              if (ks == 3) __builtin_amdgcn_sched_group_barrier(0x002, V3, 0);
+              else if (ks == PARK_KS) __builtin_amdgcn_sched_group_barrier(0x002, V2, 0);
               else __builtin_amdgcn_sched_group_barrier(0x002, VX, 0);
-              if (ks == 2) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+              if (ks == PARK_KS) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
             }
             if (j == 3) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
             __builtin_amdgcn_sched_barrier(0);
