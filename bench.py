@@ -335,7 +335,10 @@ def weights_fit(arch, quant: str, world: int, batch: int, max_context: int, kv_d
     kvh = max(arch.num_key_value_heads // world, 1)
     qkv = h * (arch.num_attention_heads // world + 2 * kvh) * arch.head_dim
     per_layer = qkv + (arch.num_attention_heads // world) * arch.head_dim * h + 3 * h * inter // world
-    bytes_per_w = {"w4a16": 0.5 + 2 / 128, "w8a8": 1.0, "bf16": 2.0}[quant]
+    # w4a16: the Marlin tensor + group-128 scales, and (unless NMV_W4_NATIVE=0) the MFMA-native copy of the codes that
+    # serves the decode-sized calls (GPTQMarlinLinearMethod, + 0.5 byte per weight + a second scale tensor)
+    native = os.environ.get("NMV_W4_NATIVE", "1") != "0"
+    bytes_per_w = {"w4a16": (0.5 + 2 / 128) * (2 if native else 1), "w8a8": 1.0, "bf16": 2.0}[quant]
     weights = layers * per_layer * bytes_per_w + 2 * (arch.vocab_size // world) * h * 2 + (2 * layers + 1) * h * 2
     kv = 2 * layers * batch * max_context * kvh * arch.head_dim * (1 if kv_dtype.startswith("fp8") else 2)
     total = weights + kv
