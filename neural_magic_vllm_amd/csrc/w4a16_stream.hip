@@ -19,10 +19,15 @@
 //   * Weights go straight from a bounds-checked buffer load to registers in a ring PER = D + 1 scale groups
 //     deep (D = 3: 12 KiB in flight per wave); a load past the wave's range is turned off by an out-of-range
 //     offset (no memory request, no branch in the loop).
-//   * Zero point without a second MFMA chain and without an add in the flush:  sum (16 + q) a - 24 sum a  is
-//     obtained by STARTING each group's accumulator chain from -24 * S[m, group], where S (the group's sum of
-//     activations per row) is computed with v_dot2 by the threads that stage the activations.  The flush is one
-//     fma per accumulator element and group:  acc += s[group, n] * acc_group.
+//   * Zero point without a second MFMA chain and without an add in the flush:  sum (16 + q) a - 24 sum a :  S (the
+//     group's sum of activations per row) is computed with v_dot2 by the threads that stage the activations and kept in
+//     LDS; after the main loop ONE more MFMA k-step per 16 groups adds sum_g s[g, n] * (-24 S[g, m]).  The flush is
+//     one fma per accumulator element and group:  acc += s[group, n] * acc_group.
+//   * Two forms of the same kernel (template flag NV): on the Marlin interchange tensor (the reference op), and on the
+//     MFMA-native tensor of nmv_w4_native_repack with natural scales (what the decode step uses: no lane exchange, no
+//     byte gather, no activation transpose).  The 64-row streamed stage is written out step by step (HS), see there.
+//   * What the stage is bound by, and the probes that did not move it: DESIGN.md 3.2, profiles/r03_gemm_ablation.txt
+//     (development switches NMV_W4S_ABL_*, NMV_W4S_PARK_KS below; tools/debug/abl_w4s.sh).
 // The epilogue forms (model-dtype store, silu(gate) * up, fp32 slabs + ticket + last-arriver sum, deferred slabs)
 // are those of the tall kernel, bit-compatible with its consumers (slabs are summed in split order from +0).
 #include <climits>
