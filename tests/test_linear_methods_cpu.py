@@ -116,6 +116,23 @@ def test_paged_attention_v1_v2_heuristic():
     assert PagedAttention.get_kv_cache_shape(10, 16, 8, 128) == (2, 10, 16 * 8 * 128)
 
 
+def test_fused_attention_launch_form_and_native_copy_ranges():
+    """this repo's own choices beside the reference's rules: the fused rope + cache + attention launch stays
+    unpartitioned up to 896 tokens (measured on MI355X) and follows the reference's rule beyond; the
+    MFMA-native copy of the 4-bit weights serves calls of <= 16 and of 33 .. 64 rows"""
+    from types import SimpleNamespace
+
+    from neural_magic_vllm_amd.attention.ops.paged_attn import PagedAttention
+    from neural_magic_vllm_amd.model_executor.layers.quantization.gptq_marlin import GPTQMarlinLinearMethod as LM
+    for (msl, ns, nh), exp in {(512, 1, 32): True, (530, 1, 32): True, (896, 16, 32): True, (897, 16, 32): False,
+                               (897, 17, 32): True, (4096, 1, 32): False, (8193, 64, 32): False}.items():
+        assert PagedAttention.use_v1_fused(msl, ns, nh) == exp, (msl, ns, nh)
+        assert PagedAttention.use_v1_fused(msl, ns, nh) or not PagedAttention.use_v1(msl, ns, nh)   # never stricter
+    with_copy, without = SimpleNamespace(qweight_native=object()), SimpleNamespace()
+    assert [m for m in (1, 16, 17, 32, 33, 64, 65, 512) if LM._native(with_copy, m)] == [1, 16, 33, 64]
+    assert not any(LM._native(without, m) for m in (1, 16, 64))
+
+
 def test_checkpoint_iterator_and_quant_config(tmp_path):
     """model_loader: every tensor of every safetensors shard comes back under its name; the quantisation
     config is config.json's `quantization_config` when present, else quantize_config.json
