@@ -1,8 +1,7 @@
 #!/bin/bash
 # scratch driver of one gpurun call (edited per call; see tools/gpu_ci.sh for the standing steps)
 mkdir -p gpurun_out
-NMV_HIP_LIB=build/abl/lib_PR1.so timeout -k 10 90 python tools/bench_gemm.py --native --ms 48,64 --shapes gate_up 2>&1 | grep -v amdgpu > gpurun_out/r3_pair1.log; rc=$?; echo "PAIR rc=$rc"; cat gpurun_out/r3_pair1.log
-if [ $rc -ne 0 ]; then echo "STOP"; exit 1; fi
-NMV_HIP_LIB=build/abl/lib_PR0.so timeout -k 10 90 python tools/bench_gemm.py --native --ms 48,64 --shapes gate_up 2>&1 | grep -v amdgpu; echo "(refactored default above)"
-NMV_HIP_LIB=build/abl/lib_PR1.so timeout -k 10 90 python tools/bench_gemm.py --native --ms 64 --shapes gate_up 2>&1 | grep -v amdgpu; echo "(pair again)"
-NMV_HIP_LIB=build/abl/lib_PR1.so timeout -k 10 500 python -m pytest tests/test_gpu_w4_native.py tests/test_gpu_w4a16.py -x -q --timeout 120 > gpurun_out/t_pair.log 2>&1; echo "tests rc=$?"; tail -4 gpurun_out/t_pair.log
+timeout -k 10 500 python tools/sweep_stream.py --native --mode 2 --ms 1,16,64 --shapes qkv,o,down 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r3_sweep_native_m2.log
+timeout -k 10 300 python tools/sweep_stream.py --native --mode 1 --ms 1,16,64 --shapes gate_up 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r3_sweep_native_m1.log
+timeout -k 10 200 python bench.py --quant w8a8 --kv-cache-dtype fp8 --no-cpu-baseline > gpurun_out/bench_w8a8.log 2>&1; tail -c 400 gpurun_out/bench_w8a8.log
+timeout -k 10 200 python bench.py --quant bf16 --no-cpu-baseline > gpurun_out/bench_bf16.log 2>&1; tail -c 400 gpurun_out/bench_bf16.log
