@@ -117,3 +117,33 @@ def test_native_silu_mul_epilogue_matches_separate_ops(gpu_device, m, dtype):
     qi, si = LM._interleave_gate_up(q_w), LM._interleave_gate_up(s)
     got = native_gemm(a, qi, si, k, n, gpu_device, 1)
     assert torch.equal(got.view(torch.int16), want.view(torch.int16))
+
+
+@pytest.mark.parametrize("m", [1, 16, 48, 64])
+def test_native_gemm_full_gate_up(gpu_device, m):
+    """the whole Llama-3-8B gate_up projection (K = 4096, N = 28672: 448 chunks) on the native tensor -- the widest
+    launch of the decode step in the form it actually takes (resident at M <= 16, the hand-scheduled 64-row stage at
+    M = 33 .. 64) -- every column against the dequantise-then-matmul definition, chunk by chunk (the Marlin twin:
+    test_gpu_w4a16.py::test_marlin_gemm_full_gate_up), and twice for the fixed-order reductions"""
+    from neural_magic_vllm_amd import _custom_ops as ops
+    k, n = 4096, 28672
+    g = torch.Generator().manual_seed(60 + m)
+    q_w = torch.randint(0, 16, (k, n), generator=g, dtype=torch.int32)
+    s = (torch.rand((k // 128, n), generator=g) * 0.01 + 0.001).to(torch.bfloat16)
+    a = torch.randn((m, k), generator=g).to(torch.bfloat16)
+    d = gpu_device
+    b = ops.w4_native_repack(ref_math.gptq_pack(q_w, 4, k, n).to(d), None, k, n)
+    ws = torch.zeros(n // 64 * 16, dtype=torch.int32, device=d)
+    c1 = ops.w4_native_gemm(a.to(d), b, s.to(d), ws, m, n, k, 0)
+    c2 = ops.w4_native_gemm(a.to(d), b, s.to(d), ws, m, n, k, 0)
+    assert torch.equal(c1, c2)
+    c = c1.float().cpu()
+    ref = torch.empty((m, n))
+    for c0 in range(0, n, 4096):   # column slabs keep the dense fp32 weight at 64 MB
+        sl = slice(c0, c0 + 4096)
+        w = ((q_w[:, sl] - 8).float() * s.float().repeat_interleave(128, dim=0)[:, sl]).to(torch.bfloat16).float()
+        ref[:, sl] = a.float() @ w
+    assert rel_err(c, ref) < 6e-3
+    per_chunk = ((c - ref).abs().view(m, n // 64, 64).mean(dim=(0, 2)) /
+                 ref.abs().view(m, n // 64, 64).mean(dim=(0, 2)).clamp_min(1e-6))
+    assert per_chunk.max().item() < 3e-2, per_chunk.argmax().item()
