@@ -309,7 +309,10 @@ int nmv_marlin_gemm(void* c, const void* a, const int32_t* b_q_weight, const voi
 
 /* fp8_marlin_gemm  (csrc/quantization/fp8/fp8_marlin.cu:1212-1308): fp8-e4m3 weights packed by
  * pack_fp8_to_int32 + gptq_marlin_repack(bits=8), channelwise (or grouped) scales in
- * marlin_permute_scales order.  scratch: >= nmv_fp8_marlin_gemm_scratch_bytes() (split-K slabs). */
+ * marlin_permute_scales order.  scratch: >= nmv_fp8_marlin_gemm_scratch_bytes() (split-K slabs).
+ * workspace: the reference's zeroed lock array (size_n / 64 * 16 ints; zero again on return) -- with channelwise
+ * scales and size_k % 256 == 0 the call runs the tall 8-bit Marlin kernel and takes its split-K tickets from
+ * there (a null workspace, grouped scales or another size_k take the generic kernel). */
 int64_t nmv_fp8_marlin_gemm_scratch_bytes(int size_m, int size_n, int size_k);
 int nmv_fp8_marlin_gemm(void* c, const void* a, const int32_t* b_q_weight, const void* b_scales,
                         int32_t* workspace, int64_t workspace_len, void* scratch, int64_t scratch_bytes,
