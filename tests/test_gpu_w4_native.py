@@ -147,3 +147,24 @@ def test_native_gemm_full_gate_up(gpu_device, m):
     per_chunk = ((c - ref).abs().view(m, n // 64, 64).mean(dim=(0, 2)) /
                  ref.abs().view(m, n // 64, 64).mean(dim=(0, 2)).clamp_min(1e-6))
     assert per_chunk.max().item() < 3e-2, per_chunk.argmax().item()
+
+
+@pytest.mark.parametrize("m", [5, 40, 64])
+@pytest.mark.parametrize("dtype", [torch.half, torch.bfloat16])
+def test_wide_launch_with_an_odd_chunk_count(gpu_device, m, dtype):
+    """a wide projection (>= 224 chunks: one k range per workgroup, the streamed 64-row stage from M = 33) whose chunk
+    count is odd -- the last workgroup owns one real chunk and one past N -- on both tensors, against a @ w_ref"""
+    from neural_magic_vllm_amd import _custom_ops as ops
+    k, n = 512, 225 * 64
+    a, q_w, s, w_ref = problem(7, m, k, n, 128, dtype)
+    ref = (a.double() @ w_ref.double()).float()
+    out = native_gemm(a, q_w, s, k, n, gpu_device).cpu()
+    assert rel_err(out, ref) < 6e-3
+    d = gpu_device
+    e = torch.empty(0, dtype=torch.int32, device=d)
+    mq = ops.gptq_marlin_repack(ref_math.gptq_pack(q_w, 4, k, n).to(d), e, k, n, 4)
+    ms = ref_math.marlin_permute_scales(s, k, n, 128).to(d)
+    ws = torch.zeros(n // 64 * 16, dtype=torch.int32, device=d)
+    out2 = ops.gptq_marlin_gemm(a.to(d), mq, ms, e, e, ws, 4, m, n, k, True).cpu()
+    assert rel_err(out2, ref) < 6e-3
+    assert int(ws.abs().sum()) == 0
