@@ -168,3 +168,20 @@ def test_wide_launch_with_an_odd_chunk_count(gpu_device, m, dtype):
     out2 = ops.gptq_marlin_gemm(a.to(d), mq, ms, e, e, ws, 4, m, n, k, True).cpu()
     assert rel_err(out2, ref) < 6e-3
     assert int(ws.abs().sum()) == 0
+
+
+@pytest.mark.parametrize("k,n", [(8192, 1280), (1024, 8192), (8192, 7168), (3584, 8192),      # Llama-3-70B at TP = 8, per rank
+                                 (4096, 3072), (2048, 4096), (4096, 14336), (7168, 4096)])    # Llama-3-8B at TP = 2
+@pytest.mark.parametrize("m", [1, 64])
+def test_native_gemm_tensor_parallel_shard_shapes(gpu_device, k, n, m):
+    """the per-rank projections of BASELINE.json configs[4] (Llama-3-70B w4a16, TP = 8) and of Llama-3-8B at TP = 2 on
+    the native tensor -- what every rank of a tensor-parallel decode step launches since the native copy is the default:
+    the plain form against a @ w_ref, and the deferred slabs summing to it bit for bit"""
+    a, q_w, s, w_ref = problem(9, m, k, n, 128, torch.bfloat16)
+    out = native_gemm(a, q_w, s, k, n, gpu_device)
+    assert rel_err(out.cpu(), (a.double() @ w_ref.double()).float()) < 6e-3
+    slabs = native_gemm(a, q_w, s, k, n, gpu_device, 2)
+    acc = torch.zeros_like(slabs[0])
+    for i in range(slabs.shape[0]):
+        acc = acc + slabs[i]
+    assert torch.equal(acc.to(torch.bfloat16).view(torch.int16), out.view(torch.int16))
