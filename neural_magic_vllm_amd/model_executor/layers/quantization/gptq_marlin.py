@@ -304,13 +304,19 @@ class GPTQMarlinLinearMethod(LinearMethodBase):
     def can_fuse_silu_mul(self, layer: torch.nn.Module) -> bool:
         """a merged [gate | up] projection whose columns can still be interleaved per 64-column chunk (i.e. before the
         first-call repack), wide enough that a GEMM without split-K -- the epilogue needs the whole K in one workgroup
-        -- beats GEMM + silu_and_mul: measured on MI355X at K = 4096 the fused form wins from 112 chunks (N = 7168,
-        the TP = 4 shard of Llama-3-8B) and loses at 56 (TP = 8)"""
+        -- beats GEMM + silu_and_mul: from 224 chunks (N = 14336: Llama-3-8B at TP <= 2)"""
         if getattr(layer, "gate_up_interleaved", False):
             return True
         n = layer.output_size_per_partition
+        # round 3, re-measured on the stream kernel (tools/bench_gemm.py --native --shapes gate_up_tp2,gate_up_tp4,gate_up_tp8,
+        # gate_up70): the fused form never splits K, so below 224 chunks it fills a fraction of the CUs (112 chunks = 56
+        # workgroups) while the plain GEMM splits K to 256 -- at N = 7168 (Llama-3-8B at TP = 4) fused 15.5 / 16.2 / 19.0 us
+        # at M = 1 / 16 / 64 against 9.2 / 10.0 / 16.7 + a 4.5 us silu_and_mul launch, and at K = 8192 (Llama-3-70B at
+        # TP = 8) it leaves the stream kernel altogether (28.2 us against 12.7).  From 224 chunks on (activations
+        # streamed, one k range per workgroup) it costs 0.3-1.2 us over the plain GEMM and saves the launch.
+        wide_enough = n // 64 >= 224
         return (layer.marlin_state is GPTQMarlinState.REPACK and self._plain_w4(layer) and n % 128 == 0
-                and n // 64 >= 112 and getattr(layer, "bias", None) is None)
+                and wide_enough and getattr(layer, "bias", None) is None)
 
     @staticmethod
     def _interleave_gate_up(t: torch.Tensor) -> torch.Tensor:

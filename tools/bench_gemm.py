@@ -13,7 +13,9 @@ from neural_magic_vllm_amd import _custom_ops as ops  # noqa: E402
 
 SHAPES = {"qkv": (4096, 6144), "o": (4096, 4096), "gate_up": (4096, 28672), "down": (14336, 4096),
           # Llama-3-70B, TP=8, per rank (BASELINE.json configs[4])
-          "qkv70": (8192, 1280), "o70": (1024, 8192), "gate_up70": (8192, 7168), "down70": (3584, 8192)}
+          "qkv70": (8192, 1280), "o70": (1024, 8192), "gate_up70": (8192, 7168), "down70": (3584, 8192),
+          # Llama-3-8B gate_up under TP = 2 / 4 / 8 (224 / 112 / 56 chunks: where the fused silu form starts to pay)
+          "gate_up_tp2": (4096, 14336), "gate_up_tp4": (4096, 7168), "gate_up_tp8": (4096, 3584)}
 DEFAULT_SHAPES = "qkv,o,gate_up,down"
 
 
