@@ -304,7 +304,8 @@ class GPTQMarlinLinearMethod(LinearMethodBase):
     def can_fuse_silu_mul(self, layer: torch.nn.Module) -> bool:
         """a merged [gate | up] projection whose columns can still be interleaved per 64-column chunk (i.e. before the
         first-call repack), wide enough that a GEMM without split-K -- the epilogue needs the whole K in one workgroup
-        -- beats GEMM + silu_and_mul: from 224 chunks (N = 14336: Llama-3-8B at TP <= 2)"""
+        -- beats GEMM + silu_and_mul: from 224 chunks (N = 14336: Llama-3-8B at TP <= 2) always, from 112 while the
+        whole K fits a workgroup's LDS"""
         if getattr(layer, "gate_up_interleaved", False):
             return True
         n = layer.output_size_per_partition
@@ -314,7 +315,11 @@ class GPTQMarlinLinearMethod(LinearMethodBase):
         # at M = 1 / 16 / 64 against 9.2 / 10.0 / 16.7 + a 4.5 us silu_and_mul launch, and at K = 8192 (Llama-3-70B at
         # TP = 8) it leaves the stream kernel altogether (28.2 us against 12.7).  From 224 chunks on (activations
         # streamed, one k range per workgroup) it costs 0.3-1.2 us over the plain GEMM and saves the launch.
-        wide_enough = n // 64 >= 224
+        # Between 112 and 223 chunks it stays on where the whole K fits a workgroup's LDS (K <= 4096), because at the
+        # headline batch it still wins (M = 64: 16.5 us on the Marlin tensor against 21.2) -- apply_silu_mul picks the
+        # tensor per call there.
+        k = layer.input_size_per_partition
+        wide_enough = n // 64 >= 224 or (n // 64 >= 112 and k <= 4096)
         return (layer.marlin_state is GPTQMarlinState.REPACK and self._plain_w4(layer) and n % 128 == 0
                 and wide_enough and getattr(layer, "bias", None) is None)
 
@@ -330,7 +335,9 @@ class GPTQMarlinLinearMethod(LinearMethodBase):
         assert getattr(layer, "gate_up_interleaved", False), "layer was repacked without the interleave"
         rows = x.reshape(-1, x.shape[-1])
         m, n, k = rows.shape[0], layer.output_size_per_partition, layer.input_size_per_partition
-        if self._native(layer, m):
+        # narrow fused launches (112 .. 223 chunks, resident form without split-K): the native tensor only wins up to a
+        # few rows (M = 1: 15.5 vs 16.8 us; M = 16: 16.2 vs 12.2; M = 64: 19.0 vs 16.5)
+        if self._native(layer, m) and (n // 64 >= 224 or m <= 8):
             y = ops.w4_native_gemm(rows, layer.qweight_native, layer.scales_native, layer.workspace, m, n, k, mode=1)
         else:
             y = ops.gptq_marlin_gemm_silu_mul(rows, layer.qweight, layer.scales, layer.workspace, m, n, k)
