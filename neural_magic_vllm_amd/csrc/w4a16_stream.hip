@@ -938,7 +938,11 @@ bool w4s_make_plan(int M, int N, int K, int64_t tickets_len, bool unsplit, bool 
   // (measured -- profiles/r03_sweep_stream.txt -- but OFF by default, NMV_W4S_SOLO=1: a plan that depends on the
   // mode would break the bit-identity of gemm_partial + consumer with the self-contained op)
   const bool solo = !wide && !deferred && K <= 8192 && env_i("NMV_W4S_SOLO", 0);
-  const int mt = env_i("NMV_W4S_MT", (M <= 16 || solo) ? 1 : (M <= 32 || !wide) ? 2 : 4);
+  // small shards (the qkv / o projections of Llama-3-8B at TP = 4 / 8: <= 2.5 MB of codes) keep the 16-row tile at every
+  // M -- row blocks instead of taller tiles: more workgroups, the later blocks read the weights from L2 (tools/sweep_stream.py
+  // --native --shapes qkv_tp8,o_tp8,o_tp4 at M = 64: 5.4 / 4.7 / 5.5 us against 6.9 / 6.7 / 7.0 with the 32-row tile)
+  const bool small = !wide && (int64_t)K * N / 2 <= (5 << 19);
+  const int mt = env_i("NMV_W4S_MT", (M <= 16 || solo || small) ? 1 : (M <= 32 || !wide) ? 2 : 4);
   if (mt != 1 && mt != 2 && mt != 4) return false;
   pl.mt = mt;
   const int mp = 16 * mt;
@@ -948,7 +952,10 @@ bool w4s_make_plan(int M, int N, int K, int64_t tickets_len, bool unsplit, bool 
   // two row blocks of 32 (M = 33..64) on a narrow projection: four chunks per workgroup halve the activation staging, but
   // need twice the split-K slabs to reach 256 workgroups; o_proj-sized launches (< 96 chunks, K <= 8192) are as fast
   // with two chunks and half the slabs (profiles/r03_sweep_stream.txt: 9.2 vs 9.3 us), and their consumer reads half
-  const int cpw = env_i("NMV_W4S_CPW", solo ? 1 : (!wide && mt == 2 && M > 32 && (n_chunks >= 96 || K > 8192)) ? 4 : 2);
+  // (two chunks only where K then splits evenly into 4 slices of whole k-group sets: K % 2048 == 0 -- at K = 3584, the
+  // TP = 4 shard of down_proj, the only other split is 7 and the launch goes from 8.8 to 12.3 us)
+  const bool two_chunks_ok = n_chunks < 96 && K <= 8192 && groups % 16 == 0;
+  const int cpw = env_i("NMV_W4S_CPW", solo ? 1 : (!wide && mt == 2 && M > 32 && !two_chunks_ok) ? 4 : 2);
   if (cpw != 1 && cpw != 2 && cpw != 4) return false;
   if (pl.nw != 4 && pl.nw != 8 && pl.nw != 16) return false;
   if (pl.nw % cpw != 0) return false;
