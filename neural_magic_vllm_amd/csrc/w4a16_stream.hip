@@ -987,10 +987,15 @@ bool w4s_make_plan(int M, int N, int K, int64_t tickets_len, bool unsplit, bool 
       if (splits == forced) { best_splits = splits; break; }
       continue;
     }
+    // past 16 rows the slabs weigh in (splits * M * N * 4 bytes each way): no more than 8 of them
+    if (M > 16 && splits > 8 && best_splits != 0) break;
     const int dist = std::abs(base_wgs * splits - target);
     if (dist < best_dist) { best_dist = dist; best_splits = splits; }
   }
   if (best_splits == 0) return false;
+  // two 32-row blocks whose k slices cannot fill the chip (Llama-3-70B at TP = 8: qkv 8192 x 1280, down 3584 x 8192 --
+  // 160 / 128 workgroups): the tall kernel's 64-column workgroups do better there (7.6 vs 8.4 us, 11.4 vs 14.3 us at M = 64)
+  if (!forced && !wide && mt == 2 && M > 32 && base_wgs * best_splits < 192 && !env_i("NMV_W4S_STRICT", 0)) return false;
   pl.splits = best_splits;
   const int g_wg = groups / best_splits;
   pl.k_per_wg = g_wg * 128;

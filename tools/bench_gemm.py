@@ -18,7 +18,8 @@ SHAPES = {"qkv": (4096, 6144), "o": (4096, 4096), "gate_up": (4096, 28672), "dow
           "gate_up_tp2": (4096, 14336), "gate_up_tp4": (4096, 7168), "gate_up_tp8": (4096, 3584),
           # the other Llama-3-8B projections under TP = 4 / 8
           "qkv_tp4": (4096, 1536), "qkv_tp8": (4096, 768), "o_tp4": (1024, 4096), "o_tp8": (512, 4096),
-          "down_tp4": (3584, 4096), "down_tp8": (1792, 4096)}
+          "down_tp4": (3584, 4096), "down_tp8": (1792, 4096),
+          "qkv_tp2": (4096, 3072), "o_tp2": (2048, 4096), "down_tp2": (7168, 4096)}
 DEFAULT_SHAPES = "qkv,o,gate_up,down"
 
 
