@@ -437,6 +437,10 @@ int nmv_w4_native_gemm_splits(int size_m, int size_n, int size_k, int num_groups
 int nmv_w4_native_gemm(void* c, const void* a, const int32_t* b_native, const void* b_scales, int32_t* workspace,
                        int64_t workspace_len, void* scratch, int64_t scratch_bytes, int size_m, int size_n,
                        int size_k, int num_groups, nmv_dtype_t dtype, int mode, void* stream);
+/* Calls of 33..64 rows (group 128) run csrc/w4a16_ring.hip: loader waves fill an LDS ring by LDS-DMA, consumer waves
+ * wait on per-slot words in LDS with bounded spins.  nmv_w4_ring_timeouts: workgroups that gave up on a slot since the
+ * library was loaded (0 in a healthy process; their tiles are garbage); synchronises the device; -1 on a HIP error. */
+int nmv_w4_ring_timeouts(void);
 
 /* ------------------------------------------------------------------------------------------
  * One-shot / two-shot P2P all-reduce over HIP IPC (the analogue of csrc/custom_all_reduce.cuh:130-250

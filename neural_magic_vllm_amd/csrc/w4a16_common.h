@@ -204,4 +204,17 @@ struct W4StreamPlan {
 bool w4s_make_plan(int M, int N, int K, int64_t tickets_len, bool unsplit, bool deferred, W4StreamPlan* out);
 int w4s_launch(const W4StreamPlan& pl, const GemmParams& p, bool f16, hipStream_t s);
 
+// ---- w4a16_ring.hip: loader / consumer waves over an LDS-DMA ring (native tensor, 17..64 rows) ----
+struct W4RingPlan {
+  int mt;                       // 16 mt rows per workgroup (2, 3, 4)
+  int splits, k_per_wg, n_blocks, m_blocks;
+  int lds_bytes;
+};
+// false: outside the kernel's domain (the caller takes the stream kernel)
+bool w4r_make_plan(int M, int N, int K, int64_t tickets_len, bool unsplit, W4RingPlan* out);
+int w4r_launch(const W4RingPlan& pl, const GemmParams& p, bool f16, hipStream_t s);
+// the > 64 KiB dynamic-LDS opt-in (hipFuncSetAttribute) holds for the device that is current when it is made: one bit
+// per device ordinal in *mask; true = this device has not opted in yet (ordinals past 63: always true)
+bool lds_optin_needed(unsigned long long* mask, int device);
+
 }  // namespace nmv

@@ -1019,12 +1019,16 @@ bool w4s_make_plan(int M, int N, int K, int64_t tickets_len, bool unsplit, bool 
 template <typename T, int MT, int NW, int CPW, int D, int GST, bool NV>
 static int w4s_launch_one(const W4StreamPlan& pl, const GemmParams& p, hipStream_t s) {
   auto kern = w4a16_stream_kernel<T, MT, NW, CPW, D, GST, NV>;
-  static int max_lds = 0;   // per instantiation
-  if (pl.lds_bytes > max_lds) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+  // > 64 KiB of dynamic LDS needs an opt-in that holds for the device current at the call: tracked per device ordinal
+  // (w4a16_ring.hip: lds_optin_needed), so the first launch on a second GPU of the process opts in too
+  static unsigned long long optin = 0;   // per instantiation
+  if (pl.lds_bytes > 64 * 1024) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return -2;
+    if (lds_optin_needed(&optin, dev) &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                             160 * 1024) != hipSuccess)
       return -2;
-    max_lds = 160 * 1024;
   }
   dim3 grid(pl.n_blocks, pl.splits, pl.m_blocks), block(NW * 64);
   hipLaunchKernelGGL(kern, grid, block, pl.lds_bytes, s, p);
