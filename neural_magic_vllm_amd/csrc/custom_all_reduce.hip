@@ -85,8 +85,12 @@ __device__ __forceinline__ bool ar_rendezvous(const ArPeers& peers, ArComm* mine
   if (threadIdx.x < world) {
     const int q = threadIdx.x;
     __hip_atomic_store(&peers.comm[q]->flags[phase][b][rank], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    // fail fast: once a wait of this communicator has run out, no later rendezvous waits again -- a step holds ~65
+    // collectives, and a lost peer must cost one bound, not 65 (the error word is never cleared: the communicator is rebuilt)
+    if (__hip_atomic_load(&mine->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) *dead = 1;
     const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
-    while ((int32_t)(__hip_atomic_load(&mine->flags[phase][b][q], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - seq) < 0) {
+    while (*dead == 0 &&
+           (int32_t)(__hip_atomic_load(&mine->flags[phase][b][q], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - seq) < 0) {
       if (__builtin_amdgcn_s_memrealtime() - t0 > spin_ticks) {
         __hip_atomic_store(&mine->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         *dead = 1;

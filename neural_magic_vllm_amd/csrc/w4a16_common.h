@@ -206,7 +206,7 @@ int w4s_launch(const W4StreamPlan& pl, const GemmParams& p, bool f16, hipStream_
 
 // ---- w4a16_ring.hip: loader / consumer waves over an LDS-DMA ring (native tensor, 17..64 rows) ----
 struct W4RingPlan {
-  int mt;                       // 16 mt rows per workgroup (2, 3, 4)
+  int mt;                       // 16 mt rows per workgroup (2, 4)
   int splits, k_per_wg, n_blocks, m_blocks;
   int lds_bytes;
 };

@@ -11,22 +11,23 @@
 //   * 4 LOADER waves (one per SIMD) move everything by LDS-DMA (`buffer_load_dwordx4 ... lds`, no registers, no
 //     LDS stores): per 128-k scale group one ring SLOT = activations [16 MT rows][128 k] (from L2, rows XOR-swizzled
 //     through the per-lane source address so that the operand reads are conflict-free), the group's 4-bit codes
-//     of the workgroup's 128 columns (8 KiB, non-temporal) and its scale row.  A loader keeps D = R - 2 groups in
-//     flight behind a counted `s_waitcnt vmcnt`, sums the rows it has landed (the zero-point term, below) and
-//     publishes the slot by adding to its FULL word in LDS.
-//   * 8 CONSUMER waves (two per SIMD) = 2 column chunks x 2 tile pairs x 2 k-lanes: a wave owns 32 columns
-//     (16-column tiles h and h + 2 of its chunk: a gate tile and its up tile under the silu epilogue) x 16 MT rows
-//     and, of every group, the two 32-k steps of its k-lane: 2 MT x 2 MFMA 16x16x32 per step on operands read
-//     from the slot (activations = A operand: `ds_read_b128`; codes: the lane's 16-byte native vector, expanded in
-//     registers exactly once chip-wide).  It waits for a slot by polling the FULL word, and releases it with one
-//     LDS add to the slot's FREE word as soon as its last operand read has been issued (LDS serves a wave's
-//     operations in order).  No workgroup barrier inside the K loop.
-//   * Accumulators: columns on the lanes (D[m][n]: n = lane & 15), so a group's scale is ONE register per tile:
-//     acc += s[g, n] * acc_group is a v_fmac per element with no LDS traffic; 32 + 32 accumulator registers.
-//   * Zero point as in the stream kernel: sum (128 + q) a - 136 sum a, the second term as one more MFMA k-step
-//     per 16 groups at the end (k slots = (group, hi / mid [/ lo] part of -136 * S[g][m])), S summed by the loaders.
-//   * The two k-lanes meet in LDS after the loop, transposed on the way: every store of the epilogue (model dtype,
+//     of the workgroup's 128 columns (8 KiB, non-temporal) and its scale row.  A loader keeps D groups in flight
+//     behind a counted `s_waitcnt vmcnt`, publishes a landed group with one LDS add to its FULL word and then sums
+//     the rows it moved (the zero-point term, below).
+//   * 12 CONSUMER waves (three per SIMD) = 4 column blocks of 32 x 3 k-lanes: a wave owns 32 columns x 16 MT rows
+//     and every third scale group, whole: 8 k-steps of MT / 2 `v_mfma_f32_32x32x16` each, on operands read from the
+//     slot (activations = A operand: `ds_read_b128`; codes: 8 dwords of the native image, expanded in registers
+//     exactly once chip-wide).  It waits for a slot by polling the FULL word, and releases it with one LDS add to
+//     the slot's FREE word as soon as its last operand read has been issued (LDS serves a wave's operations in
+//     order).  No workgroup barrier inside the K loop.
+//   * Accumulators: columns on the lanes (D[m][n]: n = lane & 31), so a group's scale is ONE register:
+//     acc += s[g, n] * acc_group, a v_pk_fma per two elements, no LDS traffic; 16 MT / 2 + 16 MT / 2 registers.
+//   * Zero point as in the stream kernel: sum (128 + q) a - 136 sum a, the second term as MFMA k-steps over the
+//     groups at the end (k slots = (group, hi / mid [/ lo] part of -136 * S[g][m])), S summed by the loaders.
+//   * The k-lanes meet in LDS after the loop, transposed on the way: every store of the epilogue (model dtype,
 //     silu(gate) * up, fp32 slabs) is a whole 16-byte piece of a row.
+// What bounds it (measured, tools/debug/ring_timeline.py): instruction issue.  A SIMD retires about one wave
+// instruction per 2.5-3 cycles whatever the mix, so the kernel is written to the instruction count per 128-k group.
 // Every spin is bounded: a wave that gives up opens every gate (all counters are set far past any target), so the
 // workgroup drains with garbage in its tile and `nmv_w4_ring_timeouts()` reports it.
 #include <climits>
@@ -39,27 +40,62 @@
 namespace nmv {
 
 __device__ unsigned int g_w4r_timeouts;
+#if defined(NMV_W4R_STAMPS)
+// development: with NMV_W4R_DBG bit 32 every wave of the first 256 workgroups records the 100 MHz clock at 8 points
+__device__ unsigned long long g_w4r_stamps[256 * 16 * 16];   // 0..7 clock stamps, 8..15 summed phase times (shader clocks)
+#define W4R_STAMP(i)                                                                                      \
+  do {                                                                                                    \
+    if ((dbg & 32) && lane == 0 && blockIdx.y == 0 && blockIdx.z == 0 && blockIdx.x < 256)               \
+      g_w4r_stamps[(blockIdx.x * 16 + wave) * 16 + (i)] = __builtin_amdgcn_s_memrealtime();                \
+  } while (0)
+// phase timers: W4R_T0(); ...; W4R_ACC(k) adds the shader clocks since the last W4R_T0 / W4R_ACC to sum k (0..7)
+#define W4R_T0() unsigned long long w4r_t = __builtin_amdgcn_s_memtime(); unsigned long long w4r_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define W4R_ACC(k)                                                 \
+  do {                                                             \
+    const unsigned long long n_ = __builtin_amdgcn_s_memtime();    \
+    w4r_sum[k] += n_ - w4r_t;                                      \
+    w4r_t = n_;                                                    \
+  } while (0)
+#define W4R_FLUSH()                                                                                       \
+  do {                                                                                                    \
+    if ((dbg & 32) && lane == 0 && blockIdx.y == 0 && blockIdx.z == 0 && blockIdx.x < 256)               \
+      for (int k_ = 0; k_ < 8; ++k_) g_w4r_stamps[(blockIdx.x * 16 + wave) * 16 + 8 + k_] = w4r_sum[k_]; \
+  } while (0)
+#else
+#define W4R_STAMP(i)
+#define W4R_T0()
+#define W4R_ACC(k)
+#define W4R_FLUSH()
+#endif
 
 namespace {
 
-constexpr int RW_CONS = 8, RW_LOAD = 4, RW_NTHR = (RW_CONS + RW_LOAD) * 64;
+constexpr int RW_KL = 3, RW_CB = 4;         // k-lanes x 32-column blocks
+constexpr int RW_CONS = RW_KL * RW_CB, RW_LOAD = 4, RW_NTHR = (RW_CONS + RW_LOAD) * 64;
 constexpr int RW_GMAX = 32;                 // scale groups per workgroup (S image: RW_GMAX x rows floats)
 constexpr int RW_WB = 8192, RW_SB = 256;    // codes / scale row of one group and 128 columns
 constexpr int RW_OUT_LD = 132;              // floats per row of the epilogue image (128 + 4: 16-byte aligned, bank-shifted)
 constexpr uint32_t RW_OOB = 0x7ffffff0u;    // a voffset no buffer of ours reaches: zeros, no request
 constexpr uint32_t RW_SPIN_LIMIT = 1u << 18;
 constexpr uint32_t RW_POISON = 0x40000000u;
-constexpr int RW_NFLAGS = 64;               // full[32], free[8], ticket, pad
+constexpr int RW_NFLAGS = 64;               // full[32], free_a[8], free_w[8], sdone, ticket, pad
 
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+
+// Two rings: activation slots (16 MT rows x 256 bytes, from L2: short latency) and code slots (8 KiB of 4-bit codes + the
+// scale row, from HBM: long latency, so the ring is deep).  A k-lane holds one slot of each while it works on a group.
 template <int MT> struct RingGeom {
   static constexpr int MP = 16 * MT;
-  static constexpr int ACT = MP * 256;
-  static constexpr int SLOT = ACT + RW_WB + RW_SB;
-  static constexpr int R = MT >= 4 ? 6 : MT == 3 ? 7 : 8;
-  static constexpr int D = R - 2;
-  static constexpr int S_OFF = R * SLOT;
+  static constexpr int ACT = MP * 256;          // activation slot
+  static constexpr int WSL = RW_WB + RW_SB;     // code slot: codes, then the scale row
+  static constexpr int RA = 5, RW = 8;          // slots: RW_KL being read + 2 / 5 in flight
+  static constexpr int DA = RA - RW_KL, DW = RW - RW_KL;   // groups a loader keeps in flight
+  static constexpr int W_OFF = RA * ACT;
+  static constexpr int S_OFF = W_OFF + RW * WSL;
   static constexpr int F_OFF = S_OFF + RW_GMAX * MP * 4;
   static constexpr int LDS = F_OFF + RW_NFLAGS * 4;
+  static_assert(RW_KL * MP * RW_OUT_LD * 4 <= S_OFF, "the epilogue image fits the rings");
+  static_assert(LDS <= 160 * 1024, "LDS");
 };
 
 template <int N>
@@ -69,23 +105,24 @@ __device__ __forceinline__ void wait_vm() {
 
 // One LDS-DMA piece: 64 lanes x 16 bytes from buffer `rs` (per-lane byte offset `voff`, bounds-checked; uniform `soff`)
 // to LDS bytes [lds_addr, lds_addr + 1024) in lane order.  hipcc neither counts this load nor orders LDS reads behind it:
-// the caller waits with wait_vm<>.  M0 is saved and restored inside the statement.
+// the caller waits with wait_vm<>.  M0 is written in the statement that uses it (nothing else in this kernel reads M0).
 template <bool NT>
 __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rs, uint32_t voff, uint32_t soff, uint32_t lds_addr) {
-  uint32_t keep;
   if constexpr (NT)
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen nt lds\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "s"(lds_addr), "v"(voff), "s"(rs), "s"(soff) : "memory");
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen nt lds"
+                 :: "s"(lds_addr), "v"(voff), "s"(rs), "s"(soff) : "memory");
   else
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "s"(lds_addr), "v"(voff), "s"(rs), "s"(soff) : "memory");
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                 :: "s"(lds_addr), "v"(voff), "s"(rs), "s"(soff) : "memory");
 }
 
 // LDS add without a wait in front of it: LDS serves the operations of a wave in issue order, so the reads issued before it
 // have been performed when the add is; the "memory" clobber keeps the compiler from moving them across.
+// Issued by lane 0 alone through EXEC inside the statement -- the callers run with all 64 lanes active (uniform control
+// flow in whole waves) -- because an `if (lane == 0)` around it is a branch, and a branch ends the scheduling region.
 __device__ __forceinline__ void lds_signal(uint32_t lds_addr) {
   const uint32_t one = 1;
-  asm volatile("ds_add_u32 %0, %1" ::"v"(lds_addr), "v"(one) : "memory");
+  asm volatile("s_mov_b64 exec, 1\n\tds_add_u32 %0, %1\n\ts_mov_b64 exec, -1" ::"v"(lds_addr), "v"(one) : "memory");
 }
 
 // wait until *word >= need (one relaxed LDS poll per trip, the whole wave reads the same word)
@@ -94,7 +131,7 @@ __device__ __forceinline__ void spin_ge(uint32_t* word, uint32_t need, uint32_t*
     const uint32_t v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
     if (v >= need) break;
     if (it > RW_SPIN_LIMIT) {   // give up: open every gate, the workgroup drains
-      if (lane < RW_GMAX + 8) __hip_atomic_store(flags + lane, RW_POISON, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (lane < RW_GMAX + 17) __hip_atomic_store(flags + lane, RW_POISON, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       if (lane == 0) atomicAdd(&g_w4r_timeouts, 1u);
       break;
     }
@@ -116,225 +153,375 @@ __device__ __forceinline__ float row16_sum_f(float v) {   // sum over the 16 lan
 }
 
 template <typename T>
-__device__ __forceinline__ f32x4_t mfma16(uint4 a, uint4 b, f32x4_t c) {
+__device__ __forceinline__ f32x16_t mfma32(uint4 a, uint4 b, f32x16_t c) {
   if constexpr (std::is_same<T, F16>::value)
-    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
   else
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
 }
 
 }  // namespace
 
-// grid (ceil(N / 128), splits, ceil(M / (16 MT))), 768 threads: waves 0..7 consume, waves 8..11 load.
+// grid (ceil(N / 128), splits, ceil(M / (16 MT))), 1024 threads: waves 0..11 consume, waves 12..15 load.
 // p.b: native[kstep][chunk][lane] (uint4), p.s: natural [groups, N]; p.k_per_wg = 128 * (groups per workgroup) <= 4096.
+// MT = 2 or 4 (32 or 64 rows: whole 32-row MFMA tiles).
 template <typename T, int MT>
-__global__ __launch_bounds__(RW_NTHR, 3) void w4a16_ring_kernel(const GemmParams p) {
+__global__ __launch_bounds__(RW_NTHR, 4) void w4a16_ring_kernel(const GemmParams p) {
   using GEO = RingGeom<MT>;
-  constexpr int MP = GEO::MP, ACT = GEO::ACT, SLOT = GEO::SLOT, R = GEO::R, D = GEO::D;
-  constexpr int PPG = MT + 2;   // DMA pieces per loader wave and group (+ the scale piece, for one of the four)
+  constexpr int MP = GEO::MP, ACT = GEO::ACT, WSL = GEO::WSL, RA = GEO::RA, RW = GEO::RW, DA = GEO::DA, DW = GEO::DW;
+  constexpr int MT2 = MT / 2;   // 32-row MFMA tiles
   constexpr bool IS_F16 = std::is_same<T, F16>::value;
   constexpr float ZPC = W4N<T>::ZPC;
+  static_assert(MT == 2 || MT == 4, "whole 32-row tiles");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int r = lane & 15, g = lane >> 4;
   const int n_chunks = p.N >> 6;
   const int chunk0 = blockIdx.x * 2;
   const int split = blockIdx.y;
   const int m0 = blockIdx.z * MP;
   const int k_wg0 = split * p.k_per_wg;
   const int G = min(p.k_per_wg, p.K - k_wg0) >> 7;     // scale groups of this workgroup (uniform, 1..RW_GMAX)
+  // development switches (compile time, -DNMV_W4R_ABL=bits: results garbage, times valid): 1 no row sums, 2 no MFMA, 4 no
+  // operand reads, 8 no expansion / MFMA, 16 no DMA; -DNMV_W4R_STAMPS: with NMV_W4R_DBG=32 every wave stamps the clock
+#ifndef NMV_W4R_ABL
+#define NMV_W4R_ABL 0
+#endif
+#if defined(NMV_W4R_STAMPS)
+  const int dbg = NMV_W4R_ABL | (p.g_stage & 32);
+#else
+  constexpr int dbg = NMV_W4R_ABL;
+#endif
 
   float* s_all = reinterpret_cast<float*>(smem + GEO::S_OFF);          // [G][MP]: -ZPC * sum of the group's activations
   uint32_t* flags = reinterpret_cast<uint32_t*>(smem + GEO::F_OFF);
   uint32_t* full = flags;                                               // [RW_GMAX]: loader arrivals per group (4 = landed)
-  uint32_t* freec = flags + RW_GMAX;                                    // [R]: consumer releases per slot, cumulative
+  uint32_t* free_a = flags + RW_GMAX;                                   // [RA]: consumer releases per activation slot, cumulative
+  uint32_t* free_w = flags + RW_GMAX + 8;                               // [RW]: ... per code slot
+  uint32_t* sdone = flags + RW_GMAX + 16;                                // consumers that have written their last row sum
   const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
 
+  W4R_STAMP(0);
   if (tid < RW_NFLAGS) flags[tid] = 0;
   __syncthreads();
+  W4R_STAMP(1);
 
   const __amdgpu_buffer_rsrc_t rs_s = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<uint16_t*>(p.s), 0, (int)((int64_t)(p.K >> 7) * p.N * 2), 0x00020000);
 
-  // consumer identity (also used by the epilogue)
-  const int kl = wave >> 2, ch = (wave >> 1) & 1, h = wave & 1;
-  f32x4_t acc[2][MT];
-  const f32x4_t zero4 = {0.f, 0.f, 0.f, 0.f};
+  // consumer identity (also used by the epilogue): k-lane, 32-column block; lane = (column n5, k half kh)
+  const int kl = wave >> 2, cb = wave & 3;
+  const int n5 = lane & 31, kh = lane >> 5;
+  f32x16_t acc[MT2];
 #pragma unroll
-  for (int jj = 0; jj < 2; ++jj)
+  for (int t = 0; t < MT2; ++t)
 #pragma unroll
-    for (int t = 0; t < MT; ++t) acc[jj][t] = zero4;
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
 
   if (wave >= RW_CONS) {
     // ------------------------------------------------ loader ------------------------------------------------
+    // `s_waitcnt vmcnt` counts a wave's loads in issue order, so a wave moves ONE of the two streams: waves 0, 1 the
+    // activations (half of the rows each), waves 2, 3 the codes (two k-steps each; wave 2 the scale row as well).
     const int lw = wave - RW_CONS;
-    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<uint16_t*>(p.a), 0, (int)((int64_t)p.M * p.K * 2), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<uint4*>(p.b), 0, (int)(((int64_t)p.K * p.N) >> 1), 0x00020000);
-    // activation piece u of this wave = rows 4 lw + 16 u + (lane >> 4) of the tile (4 rows x 256 bytes); the LDS image is
-    // lane-linear, so lane (row, slot) fetches chunk slot ^ (row & 15) of its row: the reader XORs the same way
-    const int rl = 4 * lw + (lane >> 4);                                  // row & 15
-    uint32_t va[MT];
+    W4R_T0();
+    if (lw < 2) {
+      const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<uint16_t*>(p.a), 0, (int)((int64_t)p.M * p.K * 2), 0x00020000);
+      // piece u of this wave = rows 4 (lw + 2 u) + (lane >> 4) of the tile (4 rows x 256 bytes); the LDS image is
+      // lane-linear, so lane (row, slot) fetches chunk slot ^ (row & 15) of its row: the reader XORs the same way
+      constexpr int NP = MT * 2;                 // pieces per wave and group
+      uint32_t va[NP];
 #pragma unroll
-    for (int u = 0; u < MT; ++u) {
-      const int row = m0 + rl + 16 * u;
-      va[u] = row < p.M ? (uint32_t)(row * p.K * 2) + (uint32_t)(((lane & 15) ^ rl) << 4) : RW_OOB;
-    }
-    // code pieces q = lw (k-step lw >> 1, chunk lw & 1) and q + 4 (k-step + 2): 1 KiB contiguous each
-    const int chq = lw & 1;
-    const uint32_t vw = (chunk0 + chq < n_chunks) ? (uint32_t)((chunk0 + chq) * 1024 + lane * 16) : RW_OOB;
-    const uint32_t w_row = (uint32_t)n_chunks * 1024u;                    // one k-step of all chunks
-    // scale row of the group: 128 columns = 16 lanes x 16 bytes
-    const uint32_t vs = (lane < 16 && chunk0 * 64 + lane * 8 < p.N) ? (uint32_t)(chunk0 * 128 + lane * 16) : RW_OOB;
-    const uint32_t ones2 = W4N<T>::ONES;
-
-    auto issue = [&](int i) {
-      const uint32_t sb = lds0 + (uint32_t)((i % R) * SLOT);
-      const uint32_t so_a = (uint32_t)((k_wg0 + i * 128) * 2);
+      for (int u = 0; u < NP; ++u) {
+        const int row = 4 * (lw + 2 * u) + (lane >> 4);
+        va[u] = m0 + row < p.M ? (uint32_t)((m0 + row) * p.K * 2) + (uint32_t)(((lane & 15) ^ (row & 15)) << 4) : RW_OOB;
+      }
+      uint32_t so_a = (uint32_t)(k_wg0 * 2);
+      uint32_t sb_i = lds0;
+      int slot_i = 0;
+      for (int i = 0; i < G; ++i) {
+        if (i >= RA) spin_ge(free_a + slot_i, (uint32_t)(RW_CB * (i / RA)), flags, lane);
+        W4R_ACC(0);
+        if (!(dbg & 16)) {
 #pragma unroll
-      for (int u = 0; u < MT; ++u) dma16<false>(rs_a, va[u], so_a, sb + (uint32_t)((lw + 4 * u) * 1024));
-      const uint32_t so_w = (uint32_t)((k_wg0 >> 5) + i * 4 + (lw >> 1)) * w_row;
-      dma16<true>(rs_w, vw, so_w, sb + (uint32_t)(ACT + lw * 1024));
-      dma16<true>(rs_w, vw, so_w + 2u * w_row, sb + (uint32_t)(ACT + (lw + 4) * 1024));
-      if ((i & 3) == lw) {
-        if (lane < 16) dma16<false>(rs_s, vs, (uint32_t)(((k_wg0 >> 7) + i) * p.N * 2), sb + (uint32_t)(ACT + RW_WB));
+          for (int u = 0; u < NP; ++u) dma16<false>(rs_a, va[u], so_a, sb_i + (uint32_t)((lw + 2 * u) * 1024));
+        }
+        so_a += 256;
+        sb_i += ACT;
+        if (++slot_i == RA) { slot_i = 0; sb_i = lds0; }
+        W4R_ACC(1);
+        const int j = i - (DA - 1);
+        if (j >= 0) {
+          wait_vm<NP*(DA - 1)>();   // NP (DA - 1) pieces were issued after group j's
+          W4R_ACC(2);
+          if (j == 0) W4R_STAMP(2);
+          lds_signal(lds0 + (uint32_t)(GEO::F_OFF + j * 4));
+          W4R_ACC(3);
+        }
+        if (i == (G >> 1)) W4R_STAMP(3);
       }
-    };
-    // group j has landed (the caller waited): sum my rows, publish
-    auto publish = [&](int j) {
-      const unsigned char* sl = smem + (j % R) * SLOT;
+      static_assert(DA == 2, "one drain step");
+      wait_vm<0>();
+      if (G >= 1) lds_signal(lds0 + (uint32_t)(GEO::F_OFF + (G - 1) * 4));
+    } else {
+      const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<uint4*>(p.b), 0, (int)(((int64_t)p.K * p.N) >> 1), 0x00020000);
+      // code pieces: k-steps 2 (lw - 2) and + 1 of the group, both chunks: 1 KiB contiguous each; slot image [k-step][chunk]
+      const int ks0 = 2 * (lw - 2);
+      uint32_t vw[2];
 #pragma unroll
-      for (int u = 0; u < MT; ++u) {
-        const uint4 v = *reinterpret_cast<const uint4*>(sl + (lw + 4 * u) * 1024 + lane * 16);
-        float s = T::dot2(v.x, ones2, 0.f);
-        s = T::dot2(v.y, ones2, s);
-        s = T::dot2(v.z, ones2, s);
-        s = T::dot2(v.w, ones2, s);
-        s = row16_sum_f(s);
-        if ((lane & 15) == 0) s_all[j * MP + rl + 16 * u] = -ZPC * s;
+      for (int c = 0; c < 2; ++c)
+        vw[c] = (chunk0 + c < n_chunks) ? (uint32_t)((chunk0 + c) * 1024 + lane * 16) : RW_OOB;
+      const uint32_t w_row = (uint32_t)n_chunks * 1024u;                    // one k-step of all chunks
+      // scale row of the group: 128 columns = 16 lanes x 16 bytes (wave 2)
+      const uint32_t vs = (lane < 16 && chunk0 * 64 + lane * 8 < p.N) ? (uint32_t)(chunk0 * 128 + lane * 16) : RW_OOB;
+      const bool with_s = lw == 2;
+      uint32_t so_w = (uint32_t)((k_wg0 >> 5) + ks0) * w_row;
+      uint32_t so_s = (uint32_t)((k_wg0 >> 7) * p.N * 2);
+      uint32_t sb_i = lds0 + GEO::W_OFF;
+      int slot_i = 0;
+      auto landed = [&](int j) {
+        if (j == 0) W4R_STAMP(2);
+        lds_signal(lds0 + (uint32_t)(GEO::F_OFF + j * 4));
+      };
+      for (int i = 0; i < G; ++i) {
+        if (i >= RW) spin_ge(free_w + slot_i, (uint32_t)(RW_CB * (i / RW)), flags, lane);
+        W4R_ACC(0);
+        if (!(dbg & 16)) {
+#pragma unroll
+          for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+              dma16<true>(rs_w, vw[c], so_w + (uint32_t)q * w_row, sb_i + (uint32_t)(((ks0 + q) * 2 + c) * 1024));
+          if (with_s) {   // under EXEC = lanes 0..15 (a uniform branch around a divergent one)
+            if (lane < 16) dma16<false>(rs_s, vs, so_s, sb_i + (uint32_t)RW_WB);
+          }
+        }
+        so_w += 4u * w_row;
+        so_s += (uint32_t)(p.N * 2);
+        sb_i += WSL;
+        if (++slot_i == RW) { slot_i = 0; sb_i = lds0 + GEO::W_OFF; }
+        W4R_ACC(1);
+        const int j = i - (DW - 1);
+        if (j >= 0) {
+          if (with_s) wait_vm<5 * (DW - 1)>();   // 5 (4) pieces per group were issued after group j's
+          else wait_vm<4 * (DW - 1)>();
+          W4R_ACC(2);
+          landed(j);
+          W4R_ACC(3);
+        }
+        if (i == (G >> 1)) W4R_STAMP(3);
       }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      if (lane == 0) __hip_atomic_fetch_add(full + j, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    };
-    for (int i = 0; i < G; ++i) {
-      if (i >= R) spin_ge(freec + (i % R), (uint32_t)(RW_CONS * (i / R)), flags, lane);
-      issue(i);
-      const int j = i - (D - 1);
-      if (j >= 0) {
-        wait_vm<PPG*(D - 1)>();   // at least PPG (D - 1) pieces were issued after group j's
-        publish(j);
+      static_assert(DW == 5, "four drain steps");
+      for (int j = max(0, G - (DW - 1)); j < G; ++j) {
+        const int rem = G - 1 - j;  // groups issued after j
+        if (rem == 0) wait_vm<0>();
+        else if (with_s) {
+          if (rem >= 3) wait_vm<15>();
+          else if (rem == 2) wait_vm<10>();
+          else wait_vm<5>();
+        } else {
+          if (rem >= 3) wait_vm<12>();
+          else if (rem == 2) wait_vm<8>();
+          else wait_vm<4>();
+        }
+        landed(j);
       }
     }
-    for (int j = max(0, G - (D - 1)); j < G; ++j) {
-      const int rem = G - 1 - j;  // groups issued after j
-      if (rem >= 5) wait_vm<PPG * 5>();
-      else if (rem == 4) wait_vm<PPG * 4>();
-      else if (rem == 3) wait_vm<PPG * 3>();
-      else if (rem == 2) wait_vm<PPG * 2>();
-      else if (rem == 1) wait_vm<PPG>();
-      else wait_vm<0>();
-      publish(j);
-    }
+    W4R_STAMP(4);
+    W4R_FLUSH();
+    W4R_STAMP(5);
   } else {
     // ----------------------------------------------- consumer -----------------------------------------------
     const uint32_t kmask = __builtin_amdgcn_readfirstlane(W4N<T>::MASK);
     uint32_t kmagic = W4N<T>::MAGIC;
     asm volatile("" : "+v"(kmagic));
-    // operand addresses inside a slot, step s = k-step 2 kl + s of the group
-    int a_off[2], w_off[2];
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const int ks = 2 * kl + s;
-      a_off[s] = r * 256 + (((4 * ks + g) ^ r) << 4);
-      w_off[s] = ACT + (ks * 2 + ch) * 1024 + lane * 16;
-    }
-    const int s_off = ACT + RW_WB + (ch * 64 + 16 * h + r) * 2;   // tile h; tile h + 2 is 64 bytes further
+    // operand addresses inside a slot.  A operand of k-step t (16 k), row tile mt: row 32 mt + n5, 16-byte chunk 2 t + kh,
+    // XORed with row & 15.  B operand: column 32 cb + n5 = tile j = 2 (cb & 1) + (n5 >> 4) of chunk cb >> 1, k octet
+    // 2 t + kh = native lane 16 (2 (t & 1) + kh) + (n5 & 15) of k-step t >> 1: dword j of that lane's vector
+    // (2 t + kh) ^ rx = (2 t) ^ (kh ^ rx): with slots a multiple of 256 bytes the chunk of k-step t is ONE xor of the
+    // lane's offset with 32 t (no table of eight offsets in registers)
+    const int rx = n5 & 15;
+    const int a_base = n5 * 256 + ((rx ^ kh) << 4);
+    static_assert(ACT % 256 == 0, "the k-step xor stays inside a row");
+    const int w_base = GEO::W_OFF + (((cb >> 1) * 64 + 16 * kh + rx) << 4) + 4 * (2 * (cb & 1) + (n5 >> 4));
+    const int s_base = GEO::W_OFF + RW_WB + (32 * cb + n5) * 2;
+    const uint32_t ones2 = W4N<T>::ONES;
 
-    auto rd_step = [&](const unsigned char* sl, int s, uint4 (&af)[MT], uint4& wv) {
-      wv = *reinterpret_cast<const uint4*>(sl + w_off[s]);
+    f32x16_t accg[MT2];
+    uint32_t wq[8];
+    // the scales of the zero-point pass after the loop (this k-lane's rounds of 8 groups, below) are fetched after the loop,
+    // under the wait for the other consumers' row sums (requesting them before the loop costs four registers the loop
+    // does not have: the 64-row tile sits at the 128-register limit of four waves per SIMD)
+    constexpr int ZR = (RW_GMAX / 8 + RW_KL - 1) / RW_KL;
+    const int zcol = chunk0 * 64 + 32 * cb + n5;
+    auto ld_zs = [&](int rr, uint32_t (&z)[4]) {
 #pragma unroll
-      for (int t = 0; t < MT; ++t) af[t] = *reinterpret_cast<const uint4*>(sl + a_off[s] + t * 4096);
-    };
-    auto expand = [&](uint32_t x) -> uint4 {
-      constexpr int P0 = W4N<T>::POS;
-      return make_uint4(and_or(P0 == 0 ? x : x << P0, kmask, kmagic),
-                        and_or(4 >= P0 ? x >> (4 - P0) : x << (P0 - 4), kmask, kmagic),
-                        and_or(x >> (8 - P0), kmask, kmagic), and_or(x >> (12 - P0), kmask, kmagic));
-    };
-    f32x4_t accg[2][MT];
-    auto compute = [&](const uint4 (&af)[MT], const uint4& wv, bool first) {
-      const uint32_t x0 = h ? wv.y : wv.x, x1 = h ? wv.w : wv.z;
-#pragma unroll
-      for (int jj = 0; jj < 2; ++jj) {
-        const uint4 w4 = expand(jj ? x1 : x0);
-#pragma unroll
-        for (int t = 0; t < MT; ++t) accg[jj][t] = mfma16<T>(af[t], w4, first ? zero4 : accg[jj][t]);
+      for (int e = 0; e < 4; ++e) {
+        const int gz = 8 * (kl + RW_KL * rr) + 4 * kh + e;
+        const bool ok = gz < G && zcol < p.N;
+        z[e] = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(
+            rs_s, ok ? (int)((((k_wg0 >> 7) + gz) * p.N + zcol) * 2) : (int)RW_OOB, 0, 0);
       }
     };
-
-    uint4 afA[MT], afB[MT], wvA, wvB;
-    uint32_t sc0, sc1;
-    spin_ge(full + 0, RW_LOAD, flags, lane);
-    {
-      const unsigned char* sl = smem;
-      sc0 = *reinterpret_cast<const uint16_t*>(sl + s_off);
-      sc1 = *reinterpret_cast<const uint16_t*>(sl + s_off + 64);
-      rd_step(sl, 0, afA, wvA);
-    }
-    for (int gi = 0; gi < G; ++gi) {
-      const int slot = gi % R;
-      const unsigned char* sl = smem + slot * SLOT;
-      rd_step(sl, 1, afB, wvB);
-      // every operand read of this group has been issued: hand the slot back
-      if (lane == 0) lds_signal(lds0 + (uint32_t)(GEO::F_OFF + (RW_GMAX + slot) * 4));
-      compute(afA, wvA, true);
-      const float sf0 = T::to_float((uint16_t)sc0), sf1 = T::to_float((uint16_t)sc1);
-      if (gi + 1 < G) {
-        spin_ge(full + gi + 1, RW_LOAD, flags, lane);
-        const unsigned char* sn = smem + ((gi + 1) % R) * SLOT;
-        sc0 = *reinterpret_cast<const uint16_t*>(sn + s_off);
-        sc1 = *reinterpret_cast<const uint16_t*>(sn + s_off + 64);
-        rd_step(sn, 0, afA, wvA);
-      }
-      compute(afB, wvB, false);
-#pragma unroll
-      for (int t = 0; t < MT; ++t)
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-          acc[0][t][reg] = fmaf(sf0, accg[0][t][reg], acc[0][t][reg]);
-          acc[1][t][reg] = fmaf(sf1, accg[1][t][reg], acc[1][t][reg]);
+    int slot_a = kl, slot_w = kl;   // slots of group gi = gi % RA, gi % RW; the lane's groups are RW_KL apart
+    W4R_T0();
+    for (int gi = kl; gi < G; gi += RW_KL) {
+      const unsigned char* sl = smem + slot_w * WSL;   // the code slot (w_base, s_base carry the ring's offset)
+      if (gi == (G >> 1) + kl) W4R_STAMP(3);
+      W4R_ACC(0);
+      spin_ge(full + gi, RW_LOAD, flags, lane);
+      W4R_ACC(1);
+      if (gi == kl) W4R_STAMP(2);
+      const uint32_t sc = *reinterpret_cast<const uint16_t*>(sl + s_base);
+      // codes of k-steps 2 t2 (offset 0) and 2 t2 + 1 (+ 512 bytes) of 32-k step t2 (2 KiB apart); the second half of the
+      // group is requested at k-step 2 (four registers less across the first half)
+      auto rd_w = [&](int t2) {
+        if (dbg & 4) {
+          wq[2 * t2] = lane + t2;
+          wq[2 * t2 + 1] = lane - t2;
+          return;
         }
-    }
-
-    // ---- zero point (k-lane 0 only: S is the sum over the whole group): acc += sum_g (-ZPC S[g, m]) * s[g, n] as MFMA
-    //      k-steps of 16 groups: slot 2 e + part of lane group g4 = group gq + 4 g4 + e, part = hi / mid half of the
-    //      fp32 value (bf16: a third part in a second MFMA; fp16: the value travels as z / 16 beside 16 s) ----
-    if (kl == 0) {
-      constexpr int NPASS = IS_F16 ? 1 : 2;
-      for (int gq = 0; gq < G; gq += 16) {
-        uint32_t sraw[2][4];
+        wq[2 * t2] = *reinterpret_cast<const uint32_t*>(sl + w_base + t2 * 2048);
+        wq[2 * t2 + 1] = *reinterpret_cast<const uint32_t*>(sl + w_base + t2 * 2048 + 512);
+      };
+      rd_w(0);
+      rd_w(1);
+      // row sums of the group (zero-point term): taken by ONE of the four column-block waves that read the group, in turn
+      const bool summer = !(dbg & 1) && (((gi - kl) / RW_KL) & 3) == cb;   // uniform
+      float rs[MT2];
 #pragma unroll
-        for (int jj = 0; jj < 2; ++jj) {
-          const int col = (chunk0 + ch) * 64 + 16 * (h + 2 * jj) + r;
+      for (int mt = 0; mt < MT2; ++mt) rs[mt] = 0.f;
+      uint4 af[2][MT2];
+      const int a_slot = slot_a * ACT + a_base;
+      auto rd_a = [&](int t, uint4 (&a)[MT2]) {
+        if (dbg & 4) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int gi = gq + 4 * g + e;
-            const bool ok = gi < G && col < p.N;
-            sraw[jj][e] = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(
-                rs_s, ok ? (int)((((k_wg0 >> 7) + gi) * p.N + col) * 2) : (int)RW_OOB, 0, 0);
+          for (int mt = 0; mt < MT2; ++mt) a[mt] = make_uint4(lane, t, mt, lane);
+          return;
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT2; ++mt)
+          a[mt] = *reinterpret_cast<const uint4*>(smem + ((a_slot ^ (t << 5)) + mt * 8192));
+      };
+      rd_a(0, af[0]);
+      // the eight k-steps, with or without the row sums: two straight-line bodies (a branch per step would end the
+      // scheduling region there: measured, the loop took twice as long)
+      auto ksteps = [&](auto sum_tag) {
+      constexpr bool SUM = decltype(sum_tag)::value;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        if (t + 1 < 8) rd_a(t + 1, af[(t + 1) & 1]);
+        if (t == 2) {   // the group's last code read: hand the code slot back
+          rd_w(2);
+          rd_w(3);
+          lds_signal(lds0 + (uint32_t)(GEO::F_OFF + (RW_GMAX + 8 + slot_w) * 4));
+        }
+        if (t == 6) {   // its last activation read has been issued: hand the activation slot back
+          lds_signal(lds0 + (uint32_t)(GEO::F_OFF + (RW_GMAX + slot_a) * 4));
+        }
+        if (dbg & 8) {
+          if (t == 0) {
+#pragma unroll
+            for (int mt = 0; mt < MT2; ++mt)
+#pragma unroll
+              for (int i = 0; i < 16; ++i) accg[mt][i] = 0.f;
+          }
+          asm volatile("" ::"v"(af[t & 1][0].x), "v"(wq[t]));
+          continue;
+        }
+        if constexpr (SUM) {
+#pragma unroll
+          for (int mt = 0; mt < MT2; ++mt) {
+            rs[mt] = T::dot2(af[t & 1][mt].x, ones2, rs[mt]);
+            rs[mt] = T::dot2(af[t & 1][mt].y, ones2, rs[mt]);
+            rs[mt] = T::dot2(af[t & 1][mt].z, ones2, rs[mt]);
+            rs[mt] = T::dot2(af[t & 1][mt].w, ones2, rs[mt]);
           }
         }
-        uint4 zb[NPASS][MT];
+        const uint32_t x = wq[t];
+        constexpr int P0 = W4N<T>::POS;
+        const uint4 w4 = make_uint4(and_or(P0 == 0 ? x : x << P0, kmask, kmagic),
+                                    and_or(4 >= P0 ? x >> (4 - P0) : x << (P0 - 4), kmask, kmagic),
+                                    and_or(x >> (8 - P0), kmask, kmagic), and_or(x >> (12 - P0), kmask, kmagic));
 #pragma unroll
-        for (int t = 0; t < MT; ++t) {
+        for (int mt = 0; mt < MT2; ++mt) {
+          if (dbg & 2) {
+            asm volatile("" ::"v"(af[t & 1][mt].x), "v"(af[t & 1][mt].w), "v"(w4.x), "v"(w4.y), "v"(w4.z), "v"(w4.w));
+            if (t == 0) {
+#pragma unroll
+              for (int i = 0; i < 16; ++i) accg[mt][i] = 0.f;
+            }
+          } else if (t == 0) {
+            f32x16_t z;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) z[i] = 0.f;
+            accg[mt] = mfma32<T>(af[0][mt], w4, z);
+          } else {
+            accg[mt] = mfma32<T>(af[t & 1][mt], w4, accg[mt]);
+          }
+        }
+        // a k-step is a scheduling region: without the fence hipcc hoists the later steps' operand reads to the top and
+        // spills (the tile sits at the 128-register limit of four waves per SIMD)
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      };
+      if (summer) ksteps(std::true_type{});
+      else ksteps(std::false_type{});
+      const float sf = T::to_float((uint16_t)sc);
+#pragma unroll
+      for (int mt = 0; mt < MT2; ++mt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[mt][i] = fmaf(sf, accg[mt][i], acc[mt][i]);
+      if (summer) {   // lane (row, k half) + its other half; the kh = 0 lanes store
+#pragma unroll
+        for (int mt = 0; mt < MT2; ++mt) {
+          const float other = __builtin_bit_cast(
+              float, __builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, __builtin_bit_cast(int, rs[mt])));
+          if (kh == 0) s_all[gi * MP + 32 * mt + n5] = -ZPC * (rs[mt] + other);
+        }
+      }
+      slot_a += RW_KL;
+      if (slot_a >= RA) slot_a -= RA;
+      slot_w += RW_KL;
+      if (slot_w >= RW) slot_w -= RW;
+    }
+    W4R_ACC(0);
+    W4R_STAMP(4);
+    W4R_FLUSH();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // my row sums are in LDS
+    if (lane == 0) __hip_atomic_fetch_add(sdone, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+
+    // ---- zero point: acc += sum_g (-ZPC S[g, m]) * s[g, n] as MFMA k-steps of 8 groups, dealt over the k-lanes (their
+    //      tiles are summed below): slot 2 e + part of lane half kh = group gq + 4 kh + e, part = hi / mid half of the
+    //      fp32 value (bf16: a third part in a second MFMA; fp16: the value travels as z / 16 beside 16 s) ----
+    {
+      constexpr int NPASS = IS_F16 ? 1 : 2;
+      uint32_t zs0[4], zs1[4] = {0u, 0u, 0u, 0u};
+      ld_zs(0, zs0);
+      if (ZR > 1 && 8 * (kl + RW_KL) < G) ld_zs(1, zs1);
+      static_assert(ZR <= 2, "two rounds of zero-point scales per k-lane");
+      spin_ge(sdone, RW_CONS, flags, lane);   // every consumer has written its last row sum
+#pragma unroll
+      for (int rr = 0; rr < ZR; ++rr) {
+        const int gq = 8 * (kl + RW_KL * rr);
+        if (gq >= G) break;
+        uint32_t sd[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          uint32_t s16 = rr == 0 ? zs0[e] : zs1[e];
+          if constexpr (IS_F16) s16 = T::from_float(16.0f * T::to_float((uint16_t)s16));
+          sd[e] = s16 | (s16 << 16);
+        }
+        const uint4 sa = make_uint4(sd[0], sd[1], sd[2], sd[3]);
+#pragma unroll
+        for (int mt = 0; mt < MT2; ++mt) {
           uint32_t d[NPASS][4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const int gi = gq + 4 * g + e;
-            float z = gi < G ? s_all[gi * MP + t * 16 + r] : 0.f;
+            const int gi = gq + 4 * kh + e;
+            float z = gi < G ? s_all[gi * MP + 32 * mt + n5] : 0.f;
             if constexpr (IS_F16) {
               z *= 0.0625f;
               const uint16_t zh = T::from_float(z);
@@ -348,46 +535,35 @@ __global__ __launch_bounds__(RW_NTHR, 3) void w4a16_ring_kernel(const GemmParams
             }
           }
 #pragma unroll
-          for (int ps = 0; ps < NPASS; ++ps) zb[ps][t] = make_uint4(d[ps][0], d[ps][1], d[ps][2], d[ps][3]);
-        }
-#pragma unroll
-        for (int jj = 0; jj < 2; ++jj) {
-          uint32_t sd[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            uint32_t s16 = sraw[jj][e];
-            if constexpr (IS_F16) s16 = T::from_float(16.0f * T::to_float((uint16_t)s16));
-            sd[e] = s16 | (s16 << 16);
-          }
-          const uint4 sa = make_uint4(sd[0], sd[1], sd[2], sd[3]);
-#pragma unroll
           for (int ps = 0; ps < NPASS; ++ps)
-#pragma unroll
-            for (int t = 0; t < MT; ++t) acc[jj][t] = mfma16<T>(zb[ps][t], sa, acc[jj][t]);
+            acc[mt] = mfma32<T>(make_uint4(d[ps][0], d[ps][1], d[ps][2], d[ps][3]), sa, acc[mt]);
         }
       }
     }
   }
 
   // ---- the k-lanes meet in LDS, transposed: out[kl][m][n] (row stride RW_OUT_LD floats) ----
+  if (wave < RW_CONS) W4R_STAMP(5);
   __syncthreads();   // the ring is dead: loaders have drained, consumers have read their last slot
+  W4R_STAMP(6);
   float* out = reinterpret_cast<float*>(smem);
   if (wave < RW_CONS) {
-    float* o = out + kl * (MP * RW_OUT_LD) + (4 * g) * RW_OUT_LD + ch * 64 + 16 * h + r;
+    // D[m][n] of a 32x32 tile: column = lane & 31, row = (i & 3) + 8 (i >> 2) + 4 (lane >> 5)
+    float* o = out + kl * (MP * RW_OUT_LD) + (4 * kh) * RW_OUT_LD + 32 * cb + n5;
 #pragma unroll
-    for (int jj = 0; jj < 2; ++jj)
+    for (int mt = 0; mt < MT2; ++mt)
 #pragma unroll
-      for (int t = 0; t < MT; ++t)
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) o[(16 * t + reg) * RW_OUT_LD + 32 * jj] = acc[jj][t][reg];
+      for (int i = 0; i < 16; ++i) o[(32 * mt + (i & 3) + 8 * (i >> 2)) * RW_OUT_LD] = acc[mt][i];
   }
   __syncthreads();
+  W4R_STAMP(7);
 
   const int n0 = chunk0 * 64;
   auto tile_sum = [&](int m, int n) -> f32x4_t {
-    const f32x4_t a = *reinterpret_cast<const f32x4_t*>(out + m * RW_OUT_LD + n);
-    const f32x4_t b = *reinterpret_cast<const f32x4_t*>(out + MP * RW_OUT_LD + m * RW_OUT_LD + n);
-    return a + b;   // k-lane 0 + k-lane 1
+    f32x4_t v = *reinterpret_cast<const f32x4_t*>(out + m * RW_OUT_LD + n);
+#pragma unroll
+    for (int q = 1; q < RW_KL; ++q) v += *reinterpret_cast<const f32x4_t*>(out + (q * MP + m) * RW_OUT_LD + n);   // k-lane order
+    return v;
   };
   if (p.splits == 1 && p.epi != 2) {
     if (p.epi) {
@@ -435,7 +611,7 @@ __global__ __launch_bounds__(RW_NTHR, 3) void w4a16_ring_kernel(const GemmParams
   }
   if (p.epi == 2) return;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  int* ticket_s = reinterpret_cast<int*>(flags + RW_GMAX + 16);
+  int* ticket_s = reinterpret_cast<int*>(flags + RW_GMAX + 24);
   __syncthreads();
   const int tile = blockIdx.z * gridDim.x + blockIdx.x;
   if (tid == 0)
@@ -460,8 +636,8 @@ bool w4r_make_plan(int M, int N, int K, int64_t tickets_len, bool unsplit, W4Rin
   if (!env_r("NMV_W4R", 1)) return false;
   if (M < env_r("NMV_W4R_MIN_M", 33) || M > env_r("NMV_W4R_MAX_M", 64) || N % 64 != 0 || K % 128 != 0) return false;
   W4RingPlan pl;
-  pl.mt = env_r("NMV_W4R_MT", M <= 32 ? 2 : M <= 48 ? 3 : 4);
-  if (pl.mt < 2 || pl.mt > 4) return false;
+  pl.mt = env_r("NMV_W4R_MT", M <= 32 ? 2 : 4);
+  if (pl.mt != 2 && pl.mt != 4) return false;
   const int mp = 16 * pl.mt;
   pl.m_blocks = (M + mp - 1) / mp;
   pl.n_blocks = (N / 64 + 1) / 2;
@@ -484,7 +660,7 @@ bool w4r_make_plan(int M, int N, int K, int64_t tickets_len, bool unsplit, W4Rin
   if (best == 0) return false;
   pl.splits = best;
   pl.k_per_wg = (groups / best) * 128;
-  pl.lds_bytes = pl.mt == 4 ? RingGeom<4>::LDS : pl.mt == 3 ? RingGeom<3>::LDS : RingGeom<2>::LDS;
+  pl.lds_bytes = pl.mt == 4 ? RingGeom<4>::LDS : RingGeom<2>::LDS;
   *out = pl;
   return true;
 }
@@ -514,17 +690,24 @@ static int w4r_launch_one(const W4RingPlan& pl, const GemmParams& p, hipStream_t
   return 0;
 }
 
-int w4r_launch(const W4RingPlan& pl, const GemmParams& p, bool f16, hipStream_t s) {
-  if (!p.native) return -1;
+int w4r_launch(const W4RingPlan& pl, const GemmParams& p0, bool f16, hipStream_t s) {
+  if (!p0.native) return -1;
+  GemmParams p = p0;
+  p.g_stage = env_r("NMV_W4R_DBG", 0);
   switch (pl.mt) {
     case 2: return f16 ? w4r_launch_one<F16, 2>(pl, p, s) : w4r_launch_one<BF16, 2>(pl, p, s);
-    case 3: return f16 ? w4r_launch_one<F16, 3>(pl, p, s) : w4r_launch_one<BF16, 3>(pl, p, s);
     case 4: return f16 ? w4r_launch_one<F16, 4>(pl, p, s) : w4r_launch_one<BF16, 4>(pl, p, s);
     default: return -1;
   }
 }
 
 }  // namespace nmv
+
+#if defined(NMV_W4R_STAMPS)
+extern "C" int w4r_dbg_stamps(unsigned long long* host, int n) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(nmv::g_w4r_stamps), (size_t)n * 8);
+}
+#endif
 
 // workgroups that gave up on a ring slot since the library was loaded (0 in a healthy process); synchronises the device
 extern "C" int nmv_w4_ring_timeouts(void) {

@@ -61,10 +61,22 @@ def _worker(rank, world, port, q, run_model, algo=0):
             tp.check_custom_ar_error()          # nothing yet
             dist.barrier()
             if rank == 0:
+                import time
+                t0 = time.perf_counter()
                 y = car.all_reduce(x)
                 torch.cuda.synchronize()
+                first = time.perf_counter() - t0
                 assert bool(torch.isnan(y.float()).all()), "a timed-out all-reduce must poison its output"
                 assert car.local_error()
+                # fail fast: a decode step holds ~65 collectives, a lost peer must cost ONE bound, not one per call --
+                # after the first timeout every later rendezvous of the communicator returns at once, poisoned
+                t0 = time.perf_counter()
+                for _ in range(65):
+                    y = car.all_reduce(x)
+                torch.cuda.synchronize()
+                rest = time.perf_counter() - t0
+                assert bool(torch.isnan(y.float()).all())
+                assert first >= 0.25 and rest < 0.3, (first, rest)
             else:
                 assert not car.local_error()
             dist.barrier()
