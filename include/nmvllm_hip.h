@@ -164,7 +164,9 @@ int nmv_activation(void* out, const void* input, int num_tokens, int d, int act,
  * tensors (gptq_marlin_repack / marlin_permute_scales) of a 4-bit symmetric weight, group 128 or
  * channelwise, no act-order, whose OUTPUT COLUMNS were interleaved before the repack so that
  * 64-column chunk c = [gate 32c..32c+31 | up 32c..32c+31]; c: [size_m, size_n / 2].  K % 256 == 0,
- * N % 128 == 0.  Bit-identical to gptq_marlin_gemm on the original weight + silu_and_mul. */
+ * N % 128 == 0.  The roundings of gptq_marlin_gemm on the original weight + silu_and_mul; bit-identical to them when
+ * that GEMM does not split K across workgroups, otherwise equal up to the order of the fp32 partial sums (the fused
+ * launch never splits K): at most an ulp of the model dtype on a few elements. */
 int nmv_gptq_marlin_gemm_silu_mul(void* c, const void* a, const int32_t* b_q_weight,
                                   const void* b_scales, int32_t* workspace, int64_t workspace_len,
                                   int size_m, int size_n, int size_k, int num_groups,
@@ -437,7 +439,7 @@ int nmv_w4_native_gemm_splits(int size_m, int size_n, int size_k, int num_groups
 int nmv_w4_native_gemm(void* c, const void* a, const int32_t* b_native, const void* b_scales, int32_t* workspace,
                        int64_t workspace_len, void* scratch, int64_t scratch_bytes, int size_m, int size_n,
                        int size_k, int num_groups, nmv_dtype_t dtype, int mode, void* stream);
-/* Calls of 33..64 rows (group 128) run csrc/w4a16_ring.hip: loader waves fill an LDS ring by LDS-DMA, consumer waves
+/* Calls of 17..64 rows (group 128) may run csrc/w4a16_ring.hip: loader waves fill an LDS ring by LDS-DMA, consumer waves
  * wait on per-slot words in LDS with bounded spins.  nmv_w4_ring_timeouts: workgroups that gave up on a slot since the
  * library was loaded (0 in a healthy process; their tiles are garbage); synchronises the device; -1 on a HIP error. */
 int nmv_w4_ring_timeouts(void);

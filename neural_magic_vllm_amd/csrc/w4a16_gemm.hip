@@ -1612,7 +1612,8 @@ int marlin_tall_fp8(void* c, const void* a, const int32_t* b_q_weight, const voi
 /* gate_up projection with silu_and_mul folded into the epilogue (not an op of nm-vllm 0.5.1).
  * b_q_weight / b_scales: the Marlin tensors of a weight whose OUTPUT COLUMNS were interleaved before
  * the repack -- 64-column chunk c = [gate 32c..32c+31 | up 32c..32c+31] -- c: [size_m, size_n / 2].
- * Bit-identical to gptq_marlin_gemm on the original weight followed by silu_and_mul. */
+ * The roundings of gptq_marlin_gemm on the original weight followed by silu_and_mul: bit-identical when that GEMM does
+ * not split K across workgroups, otherwise equal up to the order of the fp32 partial sums. */
 extern "C" int nmv_gptq_marlin_gemm_silu_mul(void* c, const void* a, const int32_t* b_q_weight,
                                              const void* b_scales, int32_t* workspace,
                                              int64_t workspace_len, int size_m, int size_n,

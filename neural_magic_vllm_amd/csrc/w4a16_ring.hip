@@ -70,7 +70,7 @@ __device__ unsigned long long g_w4r_stamps[256 * 16 * 16];   // 0..7 clock stamp
 
 namespace {
 
-constexpr int RW_KL = 3, RW_CB = 4;         // k-lanes x 32-column blocks
+constexpr int RW_KL = 2, RW_CB = 4;         // k-lanes x 32-column blocks
 constexpr int RW_CONS = RW_KL * RW_CB, RW_LOAD = 4, RW_NTHR = (RW_CONS + RW_LOAD) * 64;
 constexpr int RW_GMAX = 32;                 // scale groups per workgroup (S image: RW_GMAX x rows floats)
 constexpr int RW_WB = 8192, RW_SB = 256;    // codes / scale row of one group and 128 columns
@@ -88,8 +88,9 @@ template <int MT> struct RingGeom {
   static constexpr int MP = 16 * MT;
   static constexpr int ACT = MP * 256;          // activation slot
   static constexpr int WSL = RW_WB + RW_SB;     // code slot: codes, then the scale row
-  static constexpr int RA = 5, RW = 8;          // slots: RW_KL being read + 2 / 5 in flight
+  static constexpr int RA = 5, RW = 8;          // slots: RW_KL being read + the rest in flight
   static constexpr int DA = RA - RW_KL, DW = RW - RW_KL;   // groups a loader keeps in flight
+  static_assert(DA - 1 <= 5 && DW - 1 <= 5 && 5 * (DW - 1) < 64 && 2 * MT * (DA - 1) < 64, "counted waits");
   static constexpr int W_OFF = RA * ACT;
   static constexpr int S_OFF = W_OFF + RW * WSL;
   static constexpr int F_OFF = S_OFF + RW_GMAX * MP * 4;
@@ -100,7 +101,18 @@ template <int MT> struct RingGeom {
 
 template <int N>
 __device__ __forceinline__ void wait_vm() {
+  static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+// all but the pieces of the `rem` (uniform, <= 5) most recent groups have landed, PPG pieces per group
+template <int PPG>
+__device__ __forceinline__ void wait_vm_groups(int rem) {
+  if (rem <= 0) wait_vm<0>();
+  else if (rem == 1) wait_vm<PPG>();
+  else if (rem == 2) wait_vm<2 * PPG>();
+  else if (rem == 3) wait_vm<3 * PPG>();
+  else if (rem == 4) wait_vm<4 * PPG>();
+  else wait_vm<5 * PPG>();
 }
 
 // One LDS-DMA piece: 64 lanes x 16 bytes from buffer `rs` (per-lane byte offset `voff`, bounds-checked; uniform `soff`)
@@ -153,6 +165,14 @@ __device__ __forceinline__ float row16_sum_f(float v) {   // sum over the 16 lan
 }
 
 template <typename T>
+__device__ __forceinline__ f32x16_t mfma32(u32x4_t a, uint4 b4, f32x16_t c) {
+  const u32x4_t b = {b4.x, b4.y, b4.z, b4.w};
+  if constexpr (std::is_same<T, F16>::value)
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+template <typename T>
 __device__ __forceinline__ f32x16_t mfma32(uint4 a, uint4 b, f32x16_t c) {
   if constexpr (std::is_same<T, F16>::value)
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
@@ -166,7 +186,7 @@ __device__ __forceinline__ f32x16_t mfma32(uint4 a, uint4 b, f32x16_t c) {
 // p.b: native[kstep][chunk][lane] (uint4), p.s: natural [groups, N]; p.k_per_wg = 128 * (groups per workgroup) <= 4096.
 // MT = 2 or 4 (32 or 64 rows: whole 32-row MFMA tiles).
 template <typename T, int MT>
-__global__ __launch_bounds__(RW_NTHR, 4) void w4a16_ring_kernel(const GemmParams p) {
+__global__ __launch_bounds__(RW_NTHR, 3) void w4a16_ring_kernel(const GemmParams p) {
   using GEO = RingGeom<MT>;
   constexpr int MP = GEO::MP, ACT = GEO::ACT, WSL = GEO::WSL, RA = GEO::RA, RW = GEO::RW, DA = GEO::DA, DW = GEO::DW;
   constexpr int MT2 = MT / 2;   // 32-row MFMA tiles
@@ -261,9 +281,10 @@ __global__ __launch_bounds__(RW_NTHR, 4) void w4a16_ring_kernel(const GemmParams
         }
         if (i == (G >> 1)) W4R_STAMP(3);
       }
-      static_assert(DA == 2, "one drain step");
-      wait_vm<0>();
-      if (G >= 1) lds_signal(lds0 + (uint32_t)(GEO::F_OFF + (G - 1) * 4));
+      for (int j = max(0, G - (DA - 1)); j < G; ++j) {
+        wait_vm_groups<NP>(G - 1 - j);   // groups issued after j
+        lds_signal(lds0 + (uint32_t)(GEO::F_OFF + j * 4));
+      }
     } else {
       const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
           const_cast<uint4*>(p.b), 0, (int)(((int64_t)p.K * p.N) >> 1), 0x00020000);
@@ -313,19 +334,9 @@ __global__ __launch_bounds__(RW_NTHR, 4) void w4a16_ring_kernel(const GemmParams
         }
         if (i == (G >> 1)) W4R_STAMP(3);
       }
-      static_assert(DW == 5, "four drain steps");
       for (int j = max(0, G - (DW - 1)); j < G; ++j) {
-        const int rem = G - 1 - j;  // groups issued after j
-        if (rem == 0) wait_vm<0>();
-        else if (with_s) {
-          if (rem >= 3) wait_vm<15>();
-          else if (rem == 2) wait_vm<10>();
-          else wait_vm<5>();
-        } else {
-          if (rem >= 3) wait_vm<12>();
-          else if (rem == 2) wait_vm<8>();
-          else wait_vm<4>();
-        }
+        if (with_s) wait_vm_groups<5>(G - 1 - j);   // groups issued after j
+        else wait_vm_groups<4>(G - 1 - j);
         landed(j);
       }
     }
@@ -375,52 +386,40 @@ __global__ __launch_bounds__(RW_NTHR, 4) void w4a16_ring_kernel(const GemmParams
       W4R_ACC(1);
       if (gi == kl) W4R_STAMP(2);
       const uint32_t sc = *reinterpret_cast<const uint16_t*>(sl + s_base);
-      // codes of k-steps 2 t2 (offset 0) and 2 t2 + 1 (+ 512 bytes) of 32-k step t2 (2 KiB apart); the second half of the
-      // group is requested at k-step 2 (four registers less across the first half)
-      auto rd_w = [&](int t2) {
-        if (dbg & 4) {
-          wq[2 * t2] = lane + t2;
-          wq[2 * t2 + 1] = lane - t2;
-          return;
+      // every operand of the group is requested at once -- 8 code dwords, 8 MT2 activation fragments (64 registers at 64
+      // rows: the kernel runs three waves per SIMD, 168 registers) -- and both slots are handed back before the first MFMA:
+      // the LDS latency is paid once per group, not once per k-step, and a slot is held for the length of the issue only
+      if (!(dbg & 4)) {
+#pragma unroll
+        for (int t2 = 0; t2 < 4; ++t2) {   // k-steps 2 t2 (offset 0) and 2 t2 + 1 (+ 512 bytes) of 32-k step t2 (2 KiB apart)
+          wq[2 * t2] = *reinterpret_cast<const uint32_t*>(sl + w_base + t2 * 2048);
+          wq[2 * t2 + 1] = *reinterpret_cast<const uint32_t*>(sl + w_base + t2 * 2048 + 512);
         }
-        wq[2 * t2] = *reinterpret_cast<const uint32_t*>(sl + w_base + t2 * 2048);
-        wq[2 * t2 + 1] = *reinterpret_cast<const uint32_t*>(sl + w_base + t2 * 2048 + 512);
-      };
-      rd_w(0);
-      rd_w(1);
+      } else {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) wq[t] = 0x88888888u;
+      }
+      lds_signal(lds0 + (uint32_t)(GEO::F_OFF + (RW_GMAX + 8 + slot_w) * 4));
       // row sums of the group (zero-point term): taken by ONE of the four column-block waves that read the group, in turn
       const bool summer = !(dbg & 1) && (((gi - kl) / RW_KL) & 3) == cb;   // uniform
       float rs[MT2];
 #pragma unroll
       for (int mt = 0; mt < MT2; ++mt) rs[mt] = 0.f;
-      uint4 af[2][MT2];
+      u32x4_t af[8][MT2];   // vector loads: as a struct of four dwords hipcc splits a fragment into b96 + b32 reads
       const int a_slot = slot_a * ACT + a_base;
-      auto rd_a = [&](int t, uint4 (&a)[MT2]) {
-        if (dbg & 4) {
 #pragma unroll
-          for (int mt = 0; mt < MT2; ++mt) a[mt] = make_uint4(lane, t, mt, lane);
-          return;
+      for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int mt = 0; mt < MT2; ++mt) {
+          if (dbg & 4) af[t][mt] = u32x4_t{0x3C003C00u, 0x3C003C00u, 0x3C003C00u, 0x3C003C00u};
+          else af[t][mt] = *reinterpret_cast<const u32x4_t*>(smem + ((a_slot ^ (t << 5)) + mt * 8192));
         }
-#pragma unroll
-        for (int mt = 0; mt < MT2; ++mt)
-          a[mt] = *reinterpret_cast<const uint4*>(smem + ((a_slot ^ (t << 5)) + mt * 8192));
-      };
-      rd_a(0, af[0]);
-      // the eight k-steps, with or without the row sums: two straight-line bodies (a branch per step would end the
-      // scheduling region there: measured, the loop took twice as long)
-      auto ksteps = [&](auto sum_tag) {
-      constexpr bool SUM = decltype(sum_tag)::value;
+      lds_signal(lds0 + (uint32_t)(GEO::F_OFF + (RW_GMAX + slot_a) * 4));
+      // the eight k-steps: one straight-line body (a branch per step would end the scheduling region there: measured, the
+      // loop took twice as long); each step is fenced so that hipcc expands a code dword next to its MFMAs instead of
+      // expanding all eight ahead (32 more live registers)
 #pragma unroll
       for (int t = 0; t < 8; ++t) {
-        if (t + 1 < 8) rd_a(t + 1, af[(t + 1) & 1]);
-        if (t == 2) {   // the group's last code read: hand the code slot back
-          rd_w(2);
-          rd_w(3);
-          lds_signal(lds0 + (uint32_t)(GEO::F_OFF + (RW_GMAX + 8 + slot_w) * 4));
-        }
-        if (t == 6) {   // its last activation read has been issued: hand the activation slot back
-          lds_signal(lds0 + (uint32_t)(GEO::F_OFF + (RW_GMAX + slot_a) * 4));
-        }
         if (dbg & 8) {
           if (t == 0) {
 #pragma unroll
@@ -428,17 +427,8 @@ __global__ __launch_bounds__(RW_NTHR, 4) void w4a16_ring_kernel(const GemmParams
 #pragma unroll
               for (int i = 0; i < 16; ++i) accg[mt][i] = 0.f;
           }
-          asm volatile("" ::"v"(af[t & 1][0].x), "v"(wq[t]));
+          asm volatile("" ::"v"(af[t][0][0]), "v"(wq[t]));
           continue;
-        }
-        if constexpr (SUM) {
-#pragma unroll
-          for (int mt = 0; mt < MT2; ++mt) {
-            rs[mt] = T::dot2(af[t & 1][mt].x, ones2, rs[mt]);
-            rs[mt] = T::dot2(af[t & 1][mt].y, ones2, rs[mt]);
-            rs[mt] = T::dot2(af[t & 1][mt].z, ones2, rs[mt]);
-            rs[mt] = T::dot2(af[t & 1][mt].w, ones2, rs[mt]);
-          }
         }
         const uint32_t x = wq[t];
         constexpr int P0 = W4N<T>::POS;
@@ -448,7 +438,7 @@ __global__ __launch_bounds__(RW_NTHR, 4) void w4a16_ring_kernel(const GemmParams
 #pragma unroll
         for (int mt = 0; mt < MT2; ++mt) {
           if (dbg & 2) {
-            asm volatile("" ::"v"(af[t & 1][mt].x), "v"(af[t & 1][mt].w), "v"(w4.x), "v"(w4.y), "v"(w4.z), "v"(w4.w));
+            asm volatile("" ::"v"(af[t][mt][0]), "v"(af[t][mt][3]), "v"(w4.x), "v"(w4.y), "v"(w4.z), "v"(w4.w));
             if (t == 0) {
 #pragma unroll
               for (int i = 0; i < 16; ++i) accg[mt][i] = 0.f;
@@ -459,16 +449,22 @@ __global__ __launch_bounds__(RW_NTHR, 4) void w4a16_ring_kernel(const GemmParams
             for (int i = 0; i < 16; ++i) z[i] = 0.f;
             accg[mt] = mfma32<T>(af[0][mt], w4, z);
           } else {
-            accg[mt] = mfma32<T>(af[t & 1][mt], w4, accg[mt]);
+            accg[mt] = mfma32<T>(af[t][mt], w4, accg[mt]);
           }
         }
-        // a k-step is a scheduling region: without the fence hipcc hoists the later steps' operand reads to the top and
-        // spills (the tile sits at the 128-register limit of four waves per SIMD)
         __builtin_amdgcn_sched_barrier(0);
       }
-      };
-      if (summer) ksteps(std::true_type{});
-      else ksteps(std::false_type{});
+      if (summer) {   // the fragments are still in registers: one branch per group
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+#pragma unroll
+          for (int mt = 0; mt < MT2; ++mt) {
+            rs[mt] = T::dot2(af[t][mt][0], ones2, rs[mt]);
+            rs[mt] = T::dot2(af[t][mt][1], ones2, rs[mt]);
+            rs[mt] = T::dot2(af[t][mt][2], ones2, rs[mt]);
+            rs[mt] = T::dot2(af[t][mt][3], ones2, rs[mt]);
+          }
+      }
       const float sf = T::to_float((uint16_t)sc);
 #pragma unroll
       for (int mt = 0; mt < MT2; ++mt)
@@ -634,7 +630,7 @@ static int env_r(const char* name, int dflt) {
 // per CU; no more than NMV_W4R_MAX_SPLITS slices (each costs M * N * 8 bytes of slab traffic).
 bool w4r_make_plan(int M, int N, int K, int64_t tickets_len, bool unsplit, W4RingPlan* out) {
   if (!env_r("NMV_W4R", 1)) return false;
-  if (M < env_r("NMV_W4R_MIN_M", 33) || M > env_r("NMV_W4R_MAX_M", 64) || N % 64 != 0 || K % 128 != 0) return false;
+  if (M < env_r("NMV_W4R_MIN_M", 17) || M > env_r("NMV_W4R_MAX_M", 64) || N % 64 != 0 || K % 128 != 0) return false;
   W4RingPlan pl;
   pl.mt = env_r("NMV_W4R_MT", M <= 32 ? 2 : 4);
   if (pl.mt != 2 && pl.mt != 4) return false;
@@ -643,6 +639,11 @@ bool w4r_make_plan(int M, int N, int K, int64_t tickets_len, bool unsplit, W4Rin
   pl.n_blocks = (N / 64 + 1) / 2;
   const int groups = K / 128;
   const int base = pl.n_blocks * pl.m_blocks;
+  // measured (tools/sweep_ring.py, profiles/r04_ring_sweep.txt).  17..32 rows (one 32-row MFMA tile): the ring wins on
+  // every Llama-3-8B projection (gate_up 18.5 us against 25.8 at M = 32, o_proj 6.6 against 7.6 as the step issues it).
+  // 33..64 rows: it wins where one k range per workgroup fills the chip (gate_up: 224 strips, 28.8 us against 32.1 at
+  // M = 64) and ties on the narrow projections, whose launches are prologue and epilogue: those keep the stream kernel.
+  if (M > 32 && base < env_r("NMV_W4R_MIN_WGS", 160)) return false;
   const int target = env_r("NMV_W4R_WGS", 256);
   const int max_splits = unsplit ? 1 : env_r("NMV_W4R_MAX_SPLITS", 8);
   const int forced = unsplit ? 0 : env_r("NMV_W4R_SPLITS", 0);
@@ -708,6 +709,9 @@ extern "C" int w4r_dbg_stamps(unsigned long long* host, int n) {
   return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(nmv::g_w4r_stamps), (size_t)n * 8);
 }
 #endif
+
+// the opt-in bookkeeping above, for tests/test_capi_symbols.py (host only: no HIP call)
+extern "C" int w4r_dbg_lds_optin(unsigned long long* mask, int device) { return nmv::lds_optin_needed(mask, device) ? 1 : 0; }
 
 // workgroups that gave up on a ring slot since the library was loaded (0 in a healthy process); synchronises the device
 extern "C" int nmv_w4_ring_timeouts(void) {

@@ -37,6 +37,18 @@ def divide(numerator: int, denominator: int) -> int:
 # pack_factor (several logical columns per stored element), marlin_tile_size (a Marlin tensor stores tile_size
 # logical columns per unit of its packed dimension the other way round), needs_scalar_to_array (one scalar per
 # logical shard of a fused module).
+
+def _method_can_defer(qm, layer, rows: int, n: int, k: int) -> bool:
+    """one plan query for the admission check and the launch: the method's own can_defer(layer, rows) (it knows the tensor
+    and the group count apply_partial will use); methods without the hook are asked through the generic splits query with
+    the layer's real group count"""
+    hook = getattr(qm, "can_defer", None)
+    if hook is not None:
+        return bool(hook(layer, rows))
+    scales = getattr(layer, "scales", None)
+    groups = int(scales.shape[0]) if scales is not None and scales.dim() == 2 else None
+    return ops.gptq_marlin_gemm_partial_splits(rows, n, k, groups) >= 1
+
 class _Shard:
     """one logical sub-matrix of a fused output dimension: where it sits in this rank's parameter (`local`), in
     the un-sharded checkpoint tensor (`whole`), and which slice of a per-matrix checkpoint tensor this rank takes
@@ -193,7 +205,7 @@ class ColumnParallelLinear(LinearBase):
                 or not isinstance(input_, torch.Tensor) or not input_.is_cuda or not qm.can_defer_reduce(self):
             return None
         rows = input_.numel() // input_.shape[-1]
-        if ops.gptq_marlin_gemm_partial_splits(rows, self.output_size_per_partition, self.input_size) < 1:
+        if not _method_can_defer(qm, self, rows, self.output_size_per_partition, self.input_size):
             return None
         return qm.apply_partial(self, input_)
 
@@ -324,7 +336,7 @@ class RowParallelLinear(LinearBase):
                 or self.output_size % 8 != 0 or self.output_size > 8192:
             return False
         rows = input_.numel() // input_.shape[-1]
-        return ops.gptq_marlin_gemm_partial_splits(rows, self.output_size, self.input_size_per_partition) >= 1
+        return _method_can_defer(qm, self, rows, self.output_size, self.input_size_per_partition)
 
     def forward(self, input_):
         if self.input_is_parallel:

@@ -229,8 +229,16 @@ class GPTQMarlinLinearMethod(LinearMethodBase):
         else:
             layer.g_idx, layer.g_idx_sort_indices = _empty_index(dev), _empty_index(dev)
         if self.native_eligible(layer):   # built from the same GPTQ words, beside the Marlin tensor
-            layer.qweight_native = ops.w4_native_repack(layer.qweight.data, None, k, n)
-            layer.scales_native = layer.scales.data.clone()      # natural [groups, N]
+            # buffers, not plain attributes: module.to() / memory accounting see them; persistent=False keeps them out of
+            # the state dict (they are derived data).  + 0.5 byte per weight and a second scale tensor, resident for good
+            for name, t in (("qweight_native", ops.w4_native_repack(layer.qweight.data, None, k, n)),
+                            ("scales_native", layer.scales.data.clone())):     # natural [groups, N]
+                if name in layer._buffers:
+                    layer._buffers[name] = t
+                else:
+                    layer.register_buffer(name, t, persistent=False)
+            extra = layer.qweight_native.numel() * 4 + layer.scales_native.numel() * layer.scales_native.element_size()
+            type(self).native_extra_bytes = getattr(type(self), "native_extra_bytes", 0) + extra
         _overwrite(layer.qweight, ops.gptq_marlin_repack(layer.qweight, layer.g_idx_sort_indices, k, n, cfg.weight_bits))
         scales_k = layer.input_size if cfg.desc_act else k
         _overwrite(layer.scales, marlin_permute_scales(layer.scales, scales_k, n, cfg.group_size, cfg.weight_bits))
@@ -279,16 +287,31 @@ class GPTQMarlinLinearMethod(LinearMethodBase):
 
     @classmethod
     def _native(cls, layer, size_m: int) -> bool:
-        """measured on MI355X (tools/bench_gemm.py --native): the native form wins by 3-7 % up to 16 rows and from 33 to 64,
-        and loses 10-15 % on the wide projection at 17..32 rows (the 32-row tile with 256-k activation stages), so
-        those calls keep the Marlin tensor"""
+        """measured on MI355X (tools/bench_gemm.py --native, tools/sweep_ring.py): every decode-sized call takes the native
+        tensor -- up to 16 rows csrc/w4a16_stream.hip's resident form (3-7 % over the Marlin form), 17..32 rows the ring
+        kernel (csrc/w4a16_ring.hip: gate_up 18.5 us against 25.8 on the Marlin tensor at M = 32), 33..64 rows the ring on the
+        wide projection and the stream kernel's native form elsewhere.  The Marlin tensor serves prompt-sized calls and
+        the reference op."""
         if getattr(layer, "qweight_native", None) is None:
             return False
-        return size_m <= 16 or 32 < size_m <= cls.NATIVE_MAX_M
+        return size_m <= cls.NATIVE_MAX_M
 
     # ---- deferred split-K: the GEMM leaves fp32 slabs, the following launch sums them ------------------------------
     def can_defer_reduce(self, layer: torch.nn.Module) -> bool:
         return self._plain_w4(layer) and not getattr(layer, "gate_up_interleaved", False)
+
+    def can_defer(self, layer: torch.nn.Module, rows: int) -> bool:
+        """can_defer_reduce() and the kernel has a deferred plan for `rows` rows of THIS layer: asked of the planner that
+        apply_partial will run (native or Marlin tensor) with the layer's own group count (channelwise layers have one)"""
+        if not self.can_defer_reduce(layer):
+            return False
+        if layer.qweight.is_cuda:
+            self._ready(layer)   # the first-call repack decides which tensor apply_partial will use
+        n, k = layer.output_size_per_partition, layer.input_size_per_partition
+        groups = int(layer.scales.shape[0]) if layer.scales.dim() == 2 else max(k // 128, 1)
+        if self._native(layer, rows):
+            return ops.w4_native_gemm_splits(rows, n, k, groups) >= 1
+        return ops.gptq_marlin_gemm_partial_splits(rows, n, k, groups) >= 1
 
     def apply_partial(self, layer: torch.nn.Module, x: torch.Tensor) -> torch.Tensor:
         """x @ W as fp32 split-K slabs [splits, T, N]; their sum in split order, rounded to the model dtype, is
@@ -330,7 +353,11 @@ class GPTQMarlinLinearMethod(LinearMethodBase):
         return t.reshape(*lead, 2, n // 64, 32).transpose(-3, -2).reshape(*lead, n).contiguous()
 
     def apply_silu_mul(self, layer: torch.nn.Module, x: torch.Tensor) -> torch.Tensor:
-        """silu(x @ W_gate) * (x @ W_up) -> [.., N / 2], bit-identical to apply() + SiluAndMul"""
+        """silu(x @ W_gate) * (x @ W_up) -> [.., N / 2]: the roundings of apply() + SiluAndMul (gate and up rounded to the
+        model dtype, silu rounded, product rounded).  Bit-identical to that sequence when the plain GEMM does not split K
+        across workgroups; where it does (112 .. 223 chunks) the two differ in the order of the fp32 sums only -- the fused
+        launch never splits -- i.e. by at most an ulp of the model dtype on a few elements (tests/test_gpu_w4_native.py:
+        test_native_silu_mul_on_a_split_shape)"""
         self._ready(layer, interleave_gate_up=True)
         assert getattr(layer, "gate_up_interleaved", False), "layer was repacked without the interleave"
         rows = x.reshape(-1, x.shape[-1])

@@ -77,3 +77,19 @@ def test_no_cpu_fallback():
     x = torch.zeros(2, 8, dtype=torch.bfloat16)
     with pytest.raises((NotImplementedError, RuntimeError)):
         ops.rms_norm(torch.empty_like(x), x, torch.ones(8, dtype=torch.bfloat16), 1e-5)
+
+
+def test_lds_optin_is_tracked_per_device():
+    """the > 64 KiB dynamic-LDS opt-in (hipFuncSetAttribute) holds for the device current at the call: the launchers ask
+    lds_optin_needed(mask, device) -- true exactly once per device ordinal, independently per device (round-3 ADVICE: a
+    process-wide flag skipped the opt-in on the second GPU of a process)"""
+    from neural_magic_vllm_amd import _lib
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    lib.w4r_dbg_lds_optin.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
+    mask = ctypes.c_ulonglong(0)
+    assert lib.w4r_dbg_lds_optin(ctypes.byref(mask), 0) == 1
+    assert lib.w4r_dbg_lds_optin(ctypes.byref(mask), 0) == 0
+    assert lib.w4r_dbg_lds_optin(ctypes.byref(mask), 1) == 1      # a second device opts in on its own first launch
+    assert lib.w4r_dbg_lds_optin(ctypes.byref(mask), 1) == 0
+    assert lib.w4r_dbg_lds_optin(ctypes.byref(mask), 7) == 1 and mask.value == 0b10000011
+    assert lib.w4r_dbg_lds_optin(ctypes.byref(mask), 64) == 1 and lib.w4r_dbg_lds_optin(ctypes.byref(mask), 64) == 1   # untracked: always

@@ -119,6 +119,26 @@ def test_native_silu_mul_epilogue_matches_separate_ops(gpu_device, m, dtype):
     assert torch.equal(got.view(torch.int16), want.view(torch.int16))
 
 
+@pytest.mark.parametrize("m", [1, 16, 64])
+def test_native_silu_mul_on_a_split_shape(gpu_device, m):
+    """K = 4096, N = 7168 (112 chunks: Llama-3-8B gate_up at TP = 4): the plain GEMM splits K across workgroups and sums
+    its fp32 slabs, the fused launch never splits, so the two agree up to fp32 summation order -- stated tolerance: the
+    reference's (test_marlin_gemm.py:172-179, < 0.04 relative) and at most one ulp of the model dtype per element"""
+    from neural_magic_vllm_amd import _custom_ops as ops
+    from neural_magic_vllm_amd.model_executor.layers.quantization.gptq_marlin import GPTQMarlinLinearMethod as LM
+    dtype = torch.bfloat16
+    k, n = 4096, 7168
+    a, q_w, s, _ = problem(9, m, k, n, 128, dtype)
+    plain = native_gemm(a, q_w, s, k, n, gpu_device, 0)
+    want = torch.empty((m, n // 2), dtype=dtype, device=gpu_device)
+    ops.silu_and_mul(want, plain)
+    got = native_gemm(a, LM._interleave_gate_up(q_w), LM._interleave_gate_up(s), k, n, gpu_device, 1)
+    assert rel_err(got, want) < 1e-3
+    ulps = (got.view(torch.int16).int() - want.view(torch.int16).int()).abs()
+    # gate and up are each rounded before silu * up: one ulp in either moves the product by at most a few
+    assert int(ulps.max()) <= 4 and float((ulps > 0).float().mean()) < 0.05
+
+
 @pytest.mark.parametrize("m", [1, 16, 48, 64])
 def test_native_gemm_full_gate_up(gpu_device, m):
     """the whole Llama-3-8B gate_up projection (K = 4096, N = 28672: 448 chunks) on the native tensor -- the widest

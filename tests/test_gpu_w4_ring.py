@@ -39,6 +39,7 @@ def ring(monkeypatch):
     from neural_magic_vllm_amd import _lib
     monkeypatch.setenv("NMV_W4R", "1")
     monkeypatch.setenv("NMV_W4R_MIN_M", "17")
+    monkeypatch.setenv("NMV_W4R_MIN_WGS", "1")
     yield monkeypatch
     assert _lib.load().nmv_w4_ring_timeouts() == 0
 

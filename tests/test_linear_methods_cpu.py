@@ -119,7 +119,7 @@ def test_paged_attention_v1_v2_heuristic():
 def test_fused_attention_launch_form_and_native_copy_ranges():
     """this repo's own choices beside the reference's rules: the fused rope + cache + attention launch stays
     unpartitioned up to 896 tokens (measured on MI355X) and follows the reference's rule beyond; the
-    MFMA-native copy of the 4-bit weights serves calls of <= 16 and of 33 .. 64 rows"""
+    MFMA-native copy of the 4-bit weights serves every decode-sized call, up to 64 rows"""
     from types import SimpleNamespace
 
     from neural_magic_vllm_amd.attention.ops.paged_attn import PagedAttention
@@ -129,8 +129,31 @@ def test_fused_attention_launch_form_and_native_copy_ranges():
         assert PagedAttention.use_v1_fused(msl, ns, nh) == exp, (msl, ns, nh)
         assert PagedAttention.use_v1_fused(msl, ns, nh) or not PagedAttention.use_v1(msl, ns, nh)   # never stricter
     with_copy, without = SimpleNamespace(qweight_native=object()), SimpleNamespace()
-    assert [m for m in (1, 16, 17, 32, 33, 64, 65, 512) if LM._native(with_copy, m)] == [1, 16, 33, 64]
+    assert [m for m in (1, 16, 17, 32, 33, 64, 65, 512) if LM._native(with_copy, m)] == [1, 16, 17, 32, 33, 64]
     assert not any(LM._native(without, m) for m in (1, 16, 64))
+
+
+def test_deferred_reduce_admission_asks_the_method_with_the_layers_group_count(monkeypatch):
+    """linear.py's admission check for the deferred split-K forms goes through the LinearMethod's can_defer(layer, rows)
+    hook -- the planner apply_partial will run, with the layer's own scale-group count (a channelwise layer has ONE) --
+    and methods without the hook are asked through the splits query with that count, never with the group-128 default"""
+    from types import SimpleNamespace
+
+    import torch
+
+    from neural_magic_vllm_amd.model_executor.layers import linear
+    seen = []
+    monkeypatch.setattr(linear.ops, "gptq_marlin_gemm_partial_splits",
+                        lambda rows, n, k, groups=None: seen.append((rows, n, k, groups)) or 1)
+    channelwise = SimpleNamespace(scales=torch.zeros(1, 512))
+    grouped = SimpleNamespace(scales=torch.zeros(8, 512))
+    no_hook = SimpleNamespace()
+    assert linear._method_can_defer(no_hook, channelwise, 5, 512, 1024)
+    assert linear._method_can_defer(no_hook, grouped, 5, 512, 1024)
+    assert seen == [(5, 512, 1024, 1), (5, 512, 1024, 8)]
+    hooked = SimpleNamespace(can_defer=lambda layer, rows: rows <= 4)
+    assert linear._method_can_defer(hooked, grouped, 4, 512, 1024) and not linear._method_can_defer(hooked, grouped, 5, 512, 1024)
+    assert len(seen) == 2   # the hook decides alone
 
 
 def test_checkpoint_iterator_and_quant_config(tmp_path):

@@ -47,11 +47,11 @@ if __name__ == "__main__":
             print(f"  {role:8s} point {p}: min {v.min():6.2f}  med {np.median(v):6.2f}  max {v.max():6.2f}")
     # summed phase times in shader clocks (s_memtime): consumers 0 = compute + reads, 1 = waiting for FULL;
     # loaders 0 = waiting for FREE, 1 = DMA issue, 2 = vmcnt wait, 3 = publish + row sums
-    loop_us = np.median(us[:, 0:12, 4] - us[:, 0:12, 2])
-    tot = raw[:, 0:12, 8].mean() + raw[:, 0:12, 9].mean()
+    loop_us = np.median(us[:, 0:8, 4] - us[:, 0:8, 2])
+    tot = raw[:, 0:8, 8].mean() + raw[:, 0:8, 9].mean()
     print(f"  shader clock ~ {tot / loop_us / 1e3:.2f} GHz (consumer loop {loop_us:.2f} us = {tot:.0f} clocks)")
     names = {"consumer": ["compute+reads", "wait FULL"], "act loader": ["wait FREE", "DMA issue", "vmcnt wait", "publish"], "code loader": ["wait FREE", "DMA issue", "vmcnt wait", "publish"]}
-    for role, sl in (("consumer", slice(0, 12)), ("act loader", slice(12, 14)), ("code loader", slice(14, 16))):
+    for role, sl in (("consumer", slice(0, 8)), ("act loader", slice(8, 10)), ("code loader", slice(10, 12))):
         for k, nm in enumerate(names[role]):
             v = raw[:, sl, 8 + k].ravel()
             print(f"  {role:11s} {nm:14s}: mean {v.mean():9.0f} clocks  (min {v.min():9.0f}, max {v.max():9.0f})")

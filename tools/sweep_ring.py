@@ -13,7 +13,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 from bench_gemm import SHAPES, bench  # noqa: E402
 from neural_magic_vllm_amd import _lib  # noqa: E402
 
-KNOBS = ("NMV_W4R", "NMV_W4R_MIN_M", "NMV_W4R_SPLITS", "NMV_W4R_MAX_SPLITS", "NMV_W4R_MT")
+KNOBS = ("NMV_W4R", "NMV_W4R_MIN_M", "NMV_W4R_MIN_WGS", "NMV_W4R_SPLITS", "NMV_W4R_MAX_SPLITS", "NMV_W4R_MT")
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
@@ -38,6 +38,7 @@ if __name__ == "__main__":
                 res.append(f"stream {us:.1f}")
                 os.environ["NMV_W4R"] = "1"
                 os.environ["NMV_W4R_MIN_M"] = "17"
+                os.environ["NMV_W4R_MIN_WGS"] = "1"
                 for sp in [int(x) for x in args.splits.split(",")]:
                     if (k // 128) % sp or (k // 128) // sp > 32 or (md == 1 and sp > 1):
                         continue
