@@ -84,7 +84,7 @@ def gemm_roofline(runner, batch, dev, groups=32):
             k, n = m.input_size_per_partition, m.output_size_per_partition
             if as_model[0] and getattr(m, "gate_up_interleaved", False):
                 m.quant_method.apply_silu_mul(m, x)     # the LinearMethod's own entry points: MFMA-native copy when it keeps one
-            elif as_model[0] and j != 2 and ops.gptq_marlin_gemm_partial_splits(batch, n, k) >= 1:
+            elif as_model[0] and j != 2 and m.quant_method.can_defer(m, batch):
                 m.quant_method.apply_partial(m, x)
             else:
                 # gate_up weights may be column-interleaved for the silu epilogue: same bytes, same time
@@ -143,17 +143,46 @@ def gemm_roofline(runner, batch, dev, groups=32):
         with open(tpath) as f:
             t = json.load(f)
         traffic = t.get("by_batch", {}).get(str(batch))
-    kern = "w4a16_stream_kernel" if os.environ.get("NMV_W4S", "1") != "0" and batch <= 64 else "w4a16_gemm_tall_kernel"
-    return {"bound": "hbm", "kernel": f"{kern} (the 4 GEMM launches of one decoder layer, M={batch})",
-            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4),
-            # HBM bytes per launch group from the PMC counters (null when the committed summary has no entry for
-            # this batch size); the per-projection split is in traffic_detail
-            "traffic": traffic["bytes"] if traffic else None, "traffic_unit": "bytes per launch group",
-            "traffic_detail": traffic,
-            "algorithmic_bytes_per_launch_group": alg, "avg_us_per_launch_group": round(us, 2),
-            "launches_per_group": 4, "timing": "HIP events around a hipGraph replay", "per_gemm": per,
-            "in_model": in_model}
+    # The reference op (gptq_marlin_gemm on the Marlin interchange tensor, split-K reduced inside the launch) measured
+    # above; the kernel the decode step actually spends its time in is the same GEMM in the forms the step issues
+    # (MFMA-native tensor; qkv / o / down leave fp32 slabs to the next launch, gate_up applies silu * up), so THAT launch
+    # group is the `roofline` of this line and the reference op sits beside it.
+    ref_op = {"kernel": "w4a16_stream_kernel on the Marlin tensor (gptq_marlin_gemm, reduction inside the launch)",
+              "achieved": round(achieved, 1), "frac": round(achieved / HBM_PEAK_GBS, 4),
+              "avg_us_per_launch_group": round(us, 2), "per_gemm": per,
+              "traffic": traffic["bytes"] if traffic else None, "traffic_detail": traffic,
+              "traffic_source": "profiles/gemm_traffic.json (builder-run rocprofv3 PMC passes of round 3, not measured in this run)"}
+    if in_model is None:
+        return {"bound": "hbm", "kernel": ref_op["kernel"] + f", 4 launches of one decoder layer, M={batch}",
+                "achieved": ref_op["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ref_op["frac"],
+                "traffic": ref_op["traffic"], "traffic_unit": "bytes per launch group",
+                "traffic_source": ref_op["traffic_source"], "algorithmic_bytes_per_launch_group": alg,
+                "avg_us_per_launch_group": round(us, 2), "launches_per_group": 4,
+                "timing": "HIP events around a hipGraph replay", "per_gemm": per}
+    # algorithmic bytes of the step's forms: the fused gate_up writes [M, N / 2]
+    alg_step = alg - batch * mods[2].output_size_per_partition
+    step_us = in_model["avg_us_per_launch_group"]
+    step_ach = alg_step / (step_us * 1e-6) / 1e9
+    st = None
+    spath = os.path.join(ROOT, "profiles", "r04_step_gemm_traffic.json")
+    if os.path.exists(spath):
+        with open(spath) as f:
+            st = json.load(f).get(str(batch), {}).get("_group")
+    ring = 17 <= batch <= 64 and os.environ.get("NMV_W4R", "1") != "0"
+    kern = ("w4a16_ring_kernel (gate_up" + (", qkv, o, down" if batch <= 32 else "") + ")"
+            + (" + w4a16_stream_kernel (qkv, o, down)" if batch > 32 else "")) if ring else "w4a16_stream_kernel"
+    return {"bound": "hbm",
+            "kernel": f"{kern} on the MFMA-native tensor: the 4 GEMM launches of one decoder layer as the decode step "
+                      f"issues them (qkv / o / down deferred split-K, gate_up with the silu * up epilogue), M={batch}",
+            "achieved": round(step_ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(step_ach / HBM_PEAK_GBS, 4),
+            "traffic": st["bytes"] if st else None, "traffic_unit": "bytes per launch group",
+            "traffic_source": "profiles/r04_step_gemm_traffic.json (builder-run rocprofv3 FETCH_SIZE / WRITE_SIZE passes of "
+                              "tools/bench_step_gemms.py, not measured in this run)" if st else None,
+            "traffic_ratio_to_algorithmic": st["ratio_to_algorithmic"] if st else None,
+            "algorithmic_bytes_per_launch_group": alg_step, "avg_us_per_launch_group": step_us,
+            "launches_per_group": 4, "timing": "HIP events around a hipGraph replay",
+            "per_gemm_us": in_model["per_gemm_us"], "weights": in_model["weights"],
+            "reference_op": ref_op}
 
 
 @torch.inference_mode()
@@ -376,6 +405,7 @@ def launch_ranks(args) -> int:
 
 
 def main():
+    t_main = time.perf_counter()
     args = parse()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(launch_ranks(args))
@@ -556,6 +586,25 @@ def main():
             sweep[str(b)] = round(b * max(16, args.steps // 2) / d, 1)
         sweep[str(args.batch)] = round(value, 1)
         out["batch_sweep_tokens_per_s"] = sweep
+    if rank == 0 and world == 1 and not args.no_sweep and args.quant == "w4a16" and args.model == "llama3-8b":
+        # BASELINE.json's other single-GPU configurations, in the same driver-visible line: config 3 (w8a8 + fp8 KV) and
+        # config 1 (bf16), batch args.batch, 64 timed steps each; skipped when the run is already long
+        others = {}
+        for tag, q, kvd in (("llama3-8b w8a8 + fp8 KV", dict(method="w8a8", bits=8, group_size=-1), "fp8"),
+                            ("llama3-8b bf16", None, "auto")):
+            if time.perf_counter() - t_main > 75:
+                others[tag] = {"skipped": "the run had already taken more than 75 s"}
+                continue
+            try:
+                runner = None
+                torch.cuda.empty_cache()
+                runner = dr.DecodeRunner(arch, dev, torch.bfloat16, q, dr.CacheConfig(16, kvd))
+                d, g3 = measure(args.batch, 64, 4)
+                others[tag] = {"value": round(args.batch * 64 / d, 1), "unit": "tokens/s", "ms_per_step": round(d / 64 * 1e3, 4),
+                               "steps": 64, "batch": args.batch, "context_len": args.context, "hip_graph": g3}
+            except Exception as e:   # never take the headline number down
+                others[tag] = {"value": None, "error": repr(e)}
+        out["other_configs"] = others
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline(arch, args.batch, args.context)

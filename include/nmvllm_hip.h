@@ -489,6 +489,11 @@ int nmv_ar_destroy(void* state);
  * two-shot scratch, zeroed) and `rank_data` (device scratch for pointer tables) and exchanges the IPC handles of
  * meta and of every input buffer; peers read the inputs in place.  One-shot / two-shot by the reference's rule. */
 int64_t nmv_car_meta_size(void);
+/* `meta` as an uncached (fine-grained) allocation of the current device, zero-filled, with its IPC handle
+ * (nmv_ar_handle_bytes() bytes): what the Python CustomAllreduce wraps in its meta tensor, so that flag stores and polls
+ * of peers never sit in a cache another device cannot see.  nmv_car_meta_free releases it (after nmv_car_dispose). */
+int nmv_car_meta_alloc(int64_t nbytes, void** ptr_out, void* handle_out);
+int nmv_car_meta_free(void* ptr);
 int nmv_car_init(void** state_out, void* meta, void* rank_data, int64_t rank_data_bytes, const void* handles,
                  const int64_t* offsets, int world, int rank, int full_link);
 int nmv_car_register_buffer(void* state, const void* self, const void* handles, const int64_t* offsets);

@@ -666,6 +666,37 @@ extern "C" int nmv_ar_destroy(void* state) {
  * (neural_magic_vllm_amd/_torch_bindings.py) binds the reference's op names to these entry points. */
 extern "C" int64_t nmv_car_meta_size(void) { return (int64_t)sizeof(ArComm); }
 
+/* The flag block of the registered-buffer protocol as an UNCACHED allocation of the current device (fine-grained, as the
+ * staging communicator's: the peers' flag stores and this rank's polls then never sit in an L2 that another device cannot
+ * see), zero-filled, with its IPC handle (nmv_ar_handle_bytes() bytes).  The reference keeps `meta` in an ordinary torch
+ * tensor (custom_all_reduce.py:118-127): the Python class wraps this pointer in one.  Falls back to hipMalloc. */
+extern "C" int nmv_car_meta_alloc(int64_t nbytes, void** ptr_out, void* handle_out) {
+  NMV_CHECK(nbytes > 0 && ptr_out != nullptr && handle_out != nullptr, "car_meta_alloc: bad arguments");
+  void* p = nullptr;
+  hipError_t e = hipExtMallocWithFlags(&p, (size_t)nbytes, hipDeviceMallocUncached);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    e = hipMalloc(&p, (size_t)nbytes);
+  }
+  if (e != hipSuccess) {
+    ::nmv::set_error("car_meta_alloc: allocation failed: %s", hipGetErrorString(e));
+    return NMV_ERR_HIP;
+  }
+  AR_HIP(hipMemset(p, 0, (size_t)nbytes));
+  AR_HIP(hipDeviceSynchronize());
+  hipIpcMemHandle_t h;
+  AR_HIP(hipIpcGetMemHandle(&h, p));
+  std::memcpy(handle_out, &h, sizeof(h));
+  *ptr_out = p;
+  return NMV_OK;
+}
+extern "C" int nmv_car_meta_free(void* ptr) {
+  if (ptr == nullptr) return NMV_OK;
+  (void)hipDeviceSynchronize();
+  AR_HIP(hipFree(ptr));
+  return NMV_OK;
+}
+
 /* meta: this rank's tensor of nmv_car_meta_size() + max_size bytes (zeroed); rank_data: device scratch for the
  * pointer tables; handles: world x nmv_ar_handle_bytes() (IPC handles of every rank's meta allocation), offsets:
  * byte offset of meta inside that allocation.  custom_all_reduce.cu:12-34 */

@@ -70,8 +70,9 @@ __device__ unsigned long long g_w4r_stamps[256 * 16 * 16];   // 0..7 clock stamp
 
 namespace {
 
-constexpr int RW_KL = 2, RW_CB = 4;         // k-lanes x 32-column blocks
-constexpr int RW_CONS = RW_KL * RW_CB, RW_LOAD = 4, RW_NTHR = (RW_CONS + RW_LOAD) * 64;
+constexpr int RW_CB = 4, RW_LOAD = 4;       // 32-column blocks (consumer waves per k-lane), loader waves
+constexpr int ring_kl(int mt) { return mt >= 8 ? 1 : 2; }            // k-lanes: decode tiles 2, the 128-row prefill tile 1
+constexpr int ring_threads(int mt) { return (ring_kl(mt) * RW_CB + RW_LOAD) * 64; }
 constexpr int RW_GMAX = 32;                 // scale groups per workgroup (S image: RW_GMAX x rows floats)
 constexpr int RW_WB = 8192, RW_SB = 256;    // codes / scale row of one group and 128 columns
 constexpr int RW_OUT_LD = 132;              // floats per row of the epilogue image (128 + 4: 16-byte aligned, bank-shifted)
@@ -85,17 +86,19 @@ typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 // Two rings: activation slots (16 MT rows x 256 bytes, from L2: short latency) and code slots (8 KiB of 4-bit codes + the
 // scale row, from HBM: long latency, so the ring is deep).  A k-lane holds one slot of each while it works on a group.
 template <int MT> struct RingGeom {
+  static constexpr int KL = ring_kl(MT);
   static constexpr int MP = 16 * MT;
   static constexpr int ACT = MP * 256;          // activation slot
   static constexpr int WSL = RW_WB + RW_SB;     // code slot: codes, then the scale row
-  static constexpr int RA = 5, RW = 8;          // slots: RW_KL being read + the rest in flight
-  static constexpr int DA = RA - RW_KL, DW = RW - RW_KL;   // groups a loader keeps in flight
+  // slots: KL being read + the rest in flight (the 128-row tile: 32 KiB activation slots)
+  static constexpr int RA = MT >= 8 ? 3 : 5, RW = MT >= 8 ? 4 : 8;
+  static constexpr int DA = RA - KL, DW = RW - KL;   // groups a loader keeps in flight
   static_assert(DA - 1 <= 5 && DW - 1 <= 5 && 5 * (DW - 1) < 64 && 2 * MT * (DA - 1) < 64, "counted waits");
   static constexpr int W_OFF = RA * ACT;
   static constexpr int S_OFF = W_OFF + RW * WSL;
   static constexpr int F_OFF = S_OFF + RW_GMAX * MP * 4;
   static constexpr int LDS = F_OFF + RW_NFLAGS * 4;
-  static_assert(RW_KL * MP * RW_OUT_LD * 4 <= S_OFF, "the epilogue image fits the rings");
+  static_assert(KL * MP * RW_OUT_LD * 4 <= S_OFF, "the epilogue image fits the rings");
   static_assert(LDS <= 160 * 1024, "LDS");
 };
 
@@ -104,15 +107,21 @@ __device__ __forceinline__ void wait_vm() {
   static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
-// all but the pieces of the `rem` (uniform, <= 5) most recent groups have landed, PPG pieces per group
+// all but the pieces of the `rem` (uniform) most recent groups have landed, PPG pieces per group; a count the 6-bit counter
+// cannot express waits for the largest whole number of groups that it can (more than asked: safe)
+template <int PPG, int K>
+__device__ __forceinline__ void wait_vm_k() {
+  constexpr int KMAX = 63 / PPG;
+  wait_vm<(K < KMAX ? K : KMAX) * PPG>();
+}
 template <int PPG>
 __device__ __forceinline__ void wait_vm_groups(int rem) {
   if (rem <= 0) wait_vm<0>();
-  else if (rem == 1) wait_vm<PPG>();
-  else if (rem == 2) wait_vm<2 * PPG>();
-  else if (rem == 3) wait_vm<3 * PPG>();
-  else if (rem == 4) wait_vm<4 * PPG>();
-  else wait_vm<5 * PPG>();
+  else if (rem == 1) wait_vm_k<PPG, 1>();
+  else if (rem == 2) wait_vm_k<PPG, 2>();
+  else if (rem == 3) wait_vm_k<PPG, 3>();
+  else if (rem == 4) wait_vm_k<PPG, 4>();
+  else wait_vm_k<PPG, 5>();
 }
 
 // One LDS-DMA piece: 64 lanes x 16 bytes from buffer `rs` (per-lane byte offset `voff`, bounds-checked; uniform `soff`)
@@ -186,13 +195,15 @@ __device__ __forceinline__ f32x16_t mfma32(uint4 a, uint4 b, f32x16_t c) {
 // p.b: native[kstep][chunk][lane] (uint4), p.s: natural [groups, N]; p.k_per_wg = 128 * (groups per workgroup) <= 4096.
 // MT = 2 or 4 (32 or 64 rows: whole 32-row MFMA tiles).
 template <typename T, int MT>
-__global__ __launch_bounds__(RW_NTHR, 3) void w4a16_ring_kernel(const GemmParams p) {
+__global__ __launch_bounds__(ring_threads(MT), MT >= 8 ? 2 : 3) void w4a16_ring_kernel(const GemmParams p) {
   using GEO = RingGeom<MT>;
   constexpr int MP = GEO::MP, ACT = GEO::ACT, WSL = GEO::WSL, RA = GEO::RA, RW = GEO::RW, DA = GEO::DA, DW = GEO::DW;
   constexpr int MT2 = MT / 2;   // 32-row MFMA tiles
+  constexpr int RW_KL = GEO::KL, RW_CONS = RW_KL * RW_CB, RW_NTHR = ring_threads(MT);
+  constexpr bool STEPWISE = MT2 > 2;   // the 128-row tile reads its activation fragments k-step by k-step
   constexpr bool IS_F16 = std::is_same<T, F16>::value;
   constexpr float ZPC = W4N<T>::ZPC;
-  static_assert(MT == 2 || MT == 4, "whole 32-row tiles");
+  static_assert(MT == 2 || MT == 4 || MT == 8, "whole 32-row tiles");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -231,7 +242,7 @@ __global__ __launch_bounds__(RW_NTHR, 3) void w4a16_ring_kernel(const GemmParams
       const_cast<uint16_t*>(p.s), 0, (int)((int64_t)(p.K >> 7) * p.N * 2), 0x00020000);
 
   // consumer identity (also used by the epilogue): k-lane, 32-column block; lane = (column n5, k half kh)
-  const int kl = wave >> 2, cb = wave & 3;
+  const int kl = RW_KL == 1 ? 0 : wave >> 2, cb = wave & 3;
   const int n5 = lane & 31, kh = lane >> 5;
   f32x16_t acc[MT2];
 #pragma unroll
@@ -400,26 +411,49 @@ __global__ __launch_bounds__(RW_NTHR, 3) void w4a16_ring_kernel(const GemmParams
         for (int t = 0; t < 8; ++t) wq[t] = 0x88888888u;
       }
       lds_signal(lds0 + (uint32_t)(GEO::F_OFF + (RW_GMAX + 8 + slot_w) * 4));
-      // row sums of the group (zero-point term): taken by ONE of the four column-block waves that read the group, in turn
-      const bool summer = !(dbg & 1) && (((gi - kl) / RW_KL) & 3) == cb;   // uniform
+      // row sums of the group (zero-point term).  Decode tiles: taken by ONE of the four column-block waves that read the
+      // group, in turn, from the fragments it holds.  128-row tile: wave cb sums row tile cb of every group from a second
+      // read of that tile's fragment (a run-time register index would cost more than the read)
+      const bool summer = !STEPWISE && !(dbg & 1) && (((gi - kl) / RW_KL) & 3) == cb;   // uniform
       float rs[MT2];
 #pragma unroll
       for (int mt = 0; mt < MT2; ++mt) rs[mt] = 0.f;
-      u32x4_t af[8][MT2];   // vector loads: as a struct of four dwords hipcc splits a fragment into b96 + b32 reads
+      constexpr int NAF = STEPWISE ? 2 : 8;
+      u32x4_t af[NAF][MT2];   // vector loads: as a struct of four dwords hipcc splits a fragment into b96 + b32 reads
       const int a_slot = slot_a * ACT + a_base;
-#pragma unroll
-      for (int t = 0; t < 8; ++t)
+      auto rd_a = [&](int t, u32x4_t (&a)[MT2]) {
 #pragma unroll
         for (int mt = 0; mt < MT2; ++mt) {
-          if (dbg & 4) af[t][mt] = u32x4_t{0x3C003C00u, 0x3C003C00u, 0x3C003C00u, 0x3C003C00u};
-          else af[t][mt] = *reinterpret_cast<const u32x4_t*>(smem + ((a_slot ^ (t << 5)) + mt * 8192));
+          if (dbg & 4) a[mt] = u32x4_t{0x3C003C00u, 0x3C003C00u, 0x3C003C00u, 0x3C003C00u};
+          else a[mt] = *reinterpret_cast<const u32x4_t*>(smem + ((a_slot ^ (t << 5)) + mt * 8192));
         }
-      lds_signal(lds0 + (uint32_t)(GEO::F_OFF + (RW_GMAX + slot_a) * 4));
+      };
+      if constexpr (STEPWISE) {
+        rd_a(0, af[0]);
+      } else {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) rd_a(t, af[t]);
+        lds_signal(lds0 + (uint32_t)(GEO::F_OFF + (RW_GMAX + slot_a) * 4));
+      }
       // the eight k-steps: one straight-line body (a branch per step would end the scheduling region there: measured, the
       // loop took twice as long); each step is fenced so that hipcc expands a code dword next to its MFMAs instead of
       // expanding all eight ahead (32 more live registers)
 #pragma unroll
       for (int t = 0; t < 8; ++t) {
+        constexpr int dummy = 0;
+        (void)dummy;
+        const int ti = STEPWISE ? (t & 1) : t;
+        if constexpr (STEPWISE) {
+          if (t + 1 < 8) rd_a(t + 1, af[(t + 1) & 1]);
+          if (!(dbg & 1)) {
+            const u32x4_t as = *reinterpret_cast<const u32x4_t*>(smem + ((a_slot ^ (t << 5)) + cb * 8192));
+            rs[0] = T::dot2(as[0], ones2, rs[0]);
+            rs[0] = T::dot2(as[1], ones2, rs[0]);
+            rs[0] = T::dot2(as[2], ones2, rs[0]);
+            rs[0] = T::dot2(as[3], ones2, rs[0]);
+          }
+          if (t == 6) lds_signal(lds0 + (uint32_t)(GEO::F_OFF + (RW_GMAX + slot_a) * 4));   // the last read is out
+        }
         if (dbg & 8) {
           if (t == 0) {
 #pragma unroll
@@ -427,7 +461,7 @@ __global__ __launch_bounds__(RW_NTHR, 3) void w4a16_ring_kernel(const GemmParams
 #pragma unroll
               for (int i = 0; i < 16; ++i) accg[mt][i] = 0.f;
           }
-          asm volatile("" ::"v"(af[t][0][0]), "v"(wq[t]));
+          asm volatile("" ::"v"(af[ti][0][0]), "v"(wq[t]));
           continue;
         }
         const uint32_t x = wq[t];
@@ -438,7 +472,7 @@ __global__ __launch_bounds__(RW_NTHR, 3) void w4a16_ring_kernel(const GemmParams
 #pragma unroll
         for (int mt = 0; mt < MT2; ++mt) {
           if (dbg & 2) {
-            asm volatile("" ::"v"(af[t][mt][0]), "v"(af[t][mt][3]), "v"(w4.x), "v"(w4.y), "v"(w4.z), "v"(w4.w));
+            asm volatile("" ::"v"(af[ti][mt][0]), "v"(af[ti][mt][3]), "v"(w4.x), "v"(w4.y), "v"(w4.z), "v"(w4.w));
             if (t == 0) {
 #pragma unroll
               for (int i = 0; i < 16; ++i) accg[mt][i] = 0.f;
@@ -447,30 +481,39 @@ __global__ __launch_bounds__(RW_NTHR, 3) void w4a16_ring_kernel(const GemmParams
             f32x16_t z;
 #pragma unroll
             for (int i = 0; i < 16; ++i) z[i] = 0.f;
-            accg[mt] = mfma32<T>(af[0][mt], w4, z);
+            accg[mt] = mfma32<T>(af[ti][mt], w4, z);
           } else {
-            accg[mt] = mfma32<T>(af[t][mt], w4, accg[mt]);
+            accg[mt] = mfma32<T>(af[ti][mt], w4, accg[mt]);
           }
         }
         __builtin_amdgcn_sched_barrier(0);
       }
-      if (summer) {   // the fragments are still in registers: one branch per group
+      if constexpr (!STEPWISE) {
+        if (summer) {   // the fragments are still in registers: one branch per group
 #pragma unroll
-        for (int t = 0; t < 8; ++t)
+          for (int t = 0; t < 8; ++t)
 #pragma unroll
-          for (int mt = 0; mt < MT2; ++mt) {
-            rs[mt] = T::dot2(af[t][mt][0], ones2, rs[mt]);
-            rs[mt] = T::dot2(af[t][mt][1], ones2, rs[mt]);
-            rs[mt] = T::dot2(af[t][mt][2], ones2, rs[mt]);
-            rs[mt] = T::dot2(af[t][mt][3], ones2, rs[mt]);
-          }
+            for (int mt = 0; mt < MT2; ++mt) {
+              rs[mt] = T::dot2(af[t][mt][0], ones2, rs[mt]);
+              rs[mt] = T::dot2(af[t][mt][1], ones2, rs[mt]);
+              rs[mt] = T::dot2(af[t][mt][2], ones2, rs[mt]);
+              rs[mt] = T::dot2(af[t][mt][3], ones2, rs[mt]);
+            }
+        }
       }
       const float sf = T::to_float((uint16_t)sc);
 #pragma unroll
       for (int mt = 0; mt < MT2; ++mt)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[mt][i] = fmaf(sf, accg[mt][i], acc[mt][i]);
-      if (summer) {   // lane (row, k half) + its other half; the kh = 0 lanes store
+      // lane (row, k half) + its other half; the kh = 0 lanes store
+      if constexpr (STEPWISE) {
+        if (!(dbg & 1)) {
+          const float other = __builtin_bit_cast(
+              float, __builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, __builtin_bit_cast(int, rs[0])));
+          if (kh == 0) s_all[gi * MP + 32 * cb + n5] = -ZPC * (rs[0] + other);
+        }
+      } else if (summer) {
 #pragma unroll
         for (int mt = 0; mt < MT2; ++mt) {
           const float other = __builtin_bit_cast(
@@ -494,10 +537,13 @@ __global__ __launch_bounds__(RW_NTHR, 3) void w4a16_ring_kernel(const GemmParams
     //      fp32 value (bf16: a third part in a second MFMA; fp16: the value travels as z / 16 beside 16 s) ----
     {
       constexpr int NPASS = IS_F16 ? 1 : 2;
-      uint32_t zs0[4], zs1[4] = {0u, 0u, 0u, 0u};
-      ld_zs(0, zs0);
-      if (ZR > 1 && 8 * (kl + RW_KL) < G) ld_zs(1, zs1);
-      static_assert(ZR <= 2, "two rounds of zero-point scales per k-lane");
+      uint32_t zs[ZR][4];
+#pragma unroll
+      for (int rr = 0; rr < ZR; ++rr) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) zs[rr][e] = 0u;
+        if (8 * (kl + RW_KL * rr) < G) ld_zs(rr, zs[rr]);
+      }
       spin_ge(sdone, RW_CONS, flags, lane);   // every consumer has written its last row sum
 #pragma unroll
       for (int rr = 0; rr < ZR; ++rr) {
@@ -506,7 +552,7 @@ __global__ __launch_bounds__(RW_NTHR, 3) void w4a16_ring_kernel(const GemmParams
         uint32_t sd[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          uint32_t s16 = rr == 0 ? zs0[e] : zs1[e];
+          uint32_t s16 = zs[rr][e];
           if constexpr (IS_F16) s16 = T::from_float(16.0f * T::to_float((uint16_t)s16));
           sd[e] = s16 | (s16 << 16);
         }
@@ -630,10 +676,11 @@ static int env_r(const char* name, int dflt) {
 // per CU; no more than NMV_W4R_MAX_SPLITS slices (each costs M * N * 8 bytes of slab traffic).
 bool w4r_make_plan(int M, int N, int K, int64_t tickets_len, bool unsplit, W4RingPlan* out) {
   if (!env_r("NMV_W4R", 1)) return false;
-  if (M < env_r("NMV_W4R_MIN_M", 17) || M > env_r("NMV_W4R_MAX_M", 64) || N % 64 != 0 || K % 128 != 0) return false;
+  if (M < env_r("NMV_W4R_MIN_M", 17) || M > env_r("NMV_W4R_MAX_M", 1 << 20) || N % 64 != 0 || K % 128 != 0) return false;
   W4RingPlan pl;
-  pl.mt = env_r("NMV_W4R_MT", M <= 32 ? 2 : 4);
-  if (pl.mt != 2 && pl.mt != 4) return false;
+  // 17..32 rows: one 32-row tile; 33..64: two; from 65 rows on: row blocks of the 128-row prefill tile
+  pl.mt = env_r("NMV_W4R_MT", M <= 32 ? 2 : M <= 64 ? 4 : 8);
+  if (pl.mt != 2 && pl.mt != 4 && pl.mt != 8) return false;
   const int mp = 16 * pl.mt;
   pl.m_blocks = (M + mp - 1) / mp;
   pl.n_blocks = (N / 64 + 1) / 2;
@@ -643,9 +690,14 @@ bool w4r_make_plan(int M, int N, int K, int64_t tickets_len, bool unsplit, W4Rin
   // every Llama-3-8B projection (gate_up 18.5 us against 25.8 at M = 32, o_proj 6.6 against 7.6 as the step issues it).
   // 33..64 rows: it wins where one k range per workgroup fills the chip (gate_up: 224 strips, 28.8 us against 32.1 at
   // M = 64) and ties on the narrow projections, whose launches are prologue and epilogue: those keep the stream kernel.
-  if (M > 32 && base < env_r("NMV_W4R_MIN_WGS", 160)) return false;
+  if (M > 32 && M <= 64 && base < env_r("NMV_W4R_MIN_WGS", 160)) return false;
+  // 65 rows and more (row blocks of the 128-row tile): parity-green (tests/test_gpu_w4_ring.py) but not faster than the
+  // tall kernel on the Marlin tensor (profiles/r04_ring_sweep.txt: gate_up M = 512 221 us against 156, qkv 50 against 52):
+  // off unless asked for
+  if (M > 64 && !env_r("NMV_W4R_PREFILL", 0)) return false;
   const int target = env_r("NMV_W4R_WGS", 256);
-  const int max_splits = unsplit ? 1 : env_r("NMV_W4R_MAX_SPLITS", 8);
+  // prompt-sized calls: a slab costs M * N * 8 bytes of traffic, as much as the codes from M = K / 16 on: at most two
+  const int max_splits = unsplit ? 1 : env_r("NMV_W4R_MAX_SPLITS", M > 64 ? (base < 128 ? 2 : 1) : 8);
   const int forced = unsplit ? 0 : env_r("NMV_W4R_SPLITS", 0);
   int best = 0, best_dist = INT_MAX;
   for (int s = 1; s <= groups && s <= max_splits; ++s) {
@@ -661,7 +713,7 @@ bool w4r_make_plan(int M, int N, int K, int64_t tickets_len, bool unsplit, W4Rin
   if (best == 0) return false;
   pl.splits = best;
   pl.k_per_wg = (groups / best) * 128;
-  pl.lds_bytes = pl.mt == 4 ? RingGeom<4>::LDS : RingGeom<2>::LDS;
+  pl.lds_bytes = pl.mt == 8 ? RingGeom<8>::LDS : pl.mt == 4 ? RingGeom<4>::LDS : RingGeom<2>::LDS;
   *out = pl;
   return true;
 }
@@ -686,7 +738,7 @@ static int w4r_launch_one(const W4RingPlan& pl, const GemmParams& p, hipStream_t
         hipSuccess)
       return -2;
   }
-  dim3 grid(pl.n_blocks, pl.splits, pl.m_blocks), block(RW_NTHR);
+  dim3 grid(pl.n_blocks, pl.splits, pl.m_blocks), block(ring_threads(MT));
   hipLaunchKernelGGL(kern, grid, block, pl.lds_bytes, s, p);
   return 0;
 }
@@ -698,6 +750,7 @@ int w4r_launch(const W4RingPlan& pl, const GemmParams& p0, bool f16, hipStream_t
   switch (pl.mt) {
     case 2: return f16 ? w4r_launch_one<F16, 2>(pl, p, s) : w4r_launch_one<BF16, 2>(pl, p, s);
     case 4: return f16 ? w4r_launch_one<F16, 4>(pl, p, s) : w4r_launch_one<BF16, 4>(pl, p, s);
+    case 8: return f16 ? w4r_launch_one<F16, 8>(pl, p, s) : w4r_launch_one<BF16, 8>(pl, p, s);
     default: return -1;
   }
 }

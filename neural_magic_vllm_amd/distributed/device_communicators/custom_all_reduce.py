@@ -15,11 +15,12 @@ The decode harness of this repository does not use this class (it has the stagin
 ../custom_all_reduce.py, fused with residual-add + RMSNorm); this is the drop-in form.
 
 Platform notes.  Peer reachability comes from the HIP runtime (xGMI is a full mesh inside an MI355X node), not from
-NVML.  IPC handles travel as latin-1 strings.  The flag block lives in ordinary device memory: cross-device
-visibility of the flags relies on the kernels' system-scope release / acquire, and -- unlike the staging
-communicator, whose block is allocated uncached -- HAS ONLY RUN WITH ALL RANKS ON ONE DEVICE so far.  The
-constructor therefore runs a self-test (eager one-shot and two-shot sizes against the rank-order sum computed on the
-CPU, verdict agreed over the group) and disables itself on any mismatch: the caller then keeps the process group."""
+NVML.  IPC handles travel as latin-1 strings.  The flag block (`meta`) is an UNCACHED allocation of the library
+(nmv_car_meta_alloc: hipExtMallocWithFlags(hipDeviceMallocUncached), as the staging communicator's), wrapped in a torch
+tensor through `__cuda_array_interface__`: a peer's flag store and this rank's poll never sit in an L2 the other device
+cannot see; the kernels' system-scope release / acquire order the payload.  It has still only RUN WITH ALL RANKS ON ONE
+DEVICE, so the constructor keeps its self-test (eager one-shot and two-shot sizes against the rank-order sum computed on
+the CPU, verdict agreed over the group) and disables itself on any mismatch: the caller then keeps the process group."""
 import enum
 from contextlib import contextmanager
 from typing import Any, List, Optional, Sequence, Tuple, Union
@@ -29,10 +30,59 @@ import torch.distributed as dist
 from torch.distributed import ProcessGroup
 
 from ... import _custom_ops as ops
+from ... import _lib
 
 
-def _mesh_is_full(devices: Sequence[int]) -> bool:
-    return all(a == b or torch.cuda.can_device_access_peer(a, b) for a in devices for b in devices)
+class _UncachedBlock:
+    """owner of an uncached device allocation of libnmvllm_hip.so (nmv_car_meta_alloc), viewable as a uint8 tensor"""
+
+    def __init__(self, nbytes: int, device: torch.device) -> None:
+        import ctypes
+        self.nbytes, self.device = nbytes, device
+        ptr = ctypes.c_void_p()
+        handle = ctypes.create_string_buffer(64)
+        with torch.cuda.device(device):
+            _lib.check(_lib.load().nmv_car_meta_alloc(nbytes, ctypes.byref(ptr), handle), "car_meta_alloc")
+        self.ptr = int(ptr.value)
+        self.ipc_handle = handle.raw.decode("latin-1")
+        self.__cuda_array_interface__ = {"shape": (nbytes, ), "typestr": "|u1", "data": (self.ptr, False), "version": 2}
+
+    def tensor(self) -> torch.Tensor:
+        return torch.as_tensor(self, device=self.device)
+
+    def free(self) -> None:
+        if self.ptr:
+            with torch.cuda.device(self.device):
+                _lib.load().nmv_car_meta_free(self.ptr)
+            self.ptr = 0
+
+
+def _visible_physical_ids() -> List[int]:
+    """physical device ids behind this process's ordinals 0 .. n-1: HIP_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES when set
+    (the reference maps its peer check through CUDA_VISIBLE_DEVICES for the same reason, custom_all_reduce.py:23-33,
+    _can_p2p), the identity otherwise; non-numeric entries (UUIDs) make the mapping unknown (empty list)"""
+    import os
+    n = torch.cuda.device_count()
+    for var in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        raw_ids = os.environ.get(var)
+        if raw_ids is not None and raw_ids.strip() != "":
+            try:
+                ids = [int(x) for x in raw_ids.split(",") if x.strip() != ""]
+            except ValueError:
+                return []
+            return ids[:n]
+    return list(range(n))
+
+
+def _mesh_is_full(physical: Sequence[int], visible: Sequence[int]):
+    """True / False: every pair of the ranks' PHYSICAL devices is (not) peer-reachable, asked of the runtime through this
+    process's ordinals; None: some rank's device is not visible to this process (one device per rank), so the runtime
+    cannot be asked here -- the caller then does not claim a full mesh.  Ranks that share a physical device (tests) are
+    trivially reachable."""
+    local = {p: i for i, p in enumerate(visible)}
+    if any(p not in local for p in physical):
+        return None
+    return all(a == b or torch.cuda.can_device_access_peer(local[a], local[b]) for a in physical for b in physical)
 
 
 class _Mode(enum.Enum):
@@ -56,19 +106,27 @@ class CustomAllreduce:
             return
         self.device = torch.device(f"cuda:{device}") if isinstance(device, int) else torch.device(device)
         self.max_size = max_size
-        self.full_nvlink = _mesh_is_full(self._everyones(self.device.index))
+        # local ordinals mean nothing across processes (with one visible device per rank every ordinal is 0): compare
+        # physical ids, and when the peers' devices cannot be queried from here do not claim a full mesh
+        visible = _visible_physical_ids()
+        mine = visible[self.device.index] if self.device.index is not None and self.device.index < len(visible) else -1 - self.rank
+        mesh = _mesh_is_full(self._everyones(mine), visible)
+        self.full_nvlink = bool(mesh)
         if self.world_size > 2 and not self.full_nvlink:
-            self.disabled_reason = "no peer access between every pair of devices"
+            self.disabled_reason = ("peer reachability of the ranks' devices cannot be established from this process "
+                                    "(device visibility differs per rank)" if mesh is None
+                                    else "no peer access between every pair of devices")
             return
         def raw(nbytes: int, zeroed: bool = False) -> torch.Tensor:
             make = torch.zeros if zeroed else torch.empty
             return make(nbytes, dtype=torch.uint8, device=self.device)
 
-        self.meta = raw(ops.meta_size() + max_size, zeroed=True)      # flag block + two-shot scratch
+        self._meta_block = _UncachedBlock(ops.meta_size() + max_size, self.device)   # flag block + two-shot scratch, zeroed
+        self.meta = self._meta_block.tensor()
         self.buffer = raw(max_size)                                   # registered staging area of the eager path
         self.rank_data = raw(8 << 20)                                 # pointer tables
         torch.cuda.synchronize(self.device)              # the flag block is zero before a peer can map it
-        handles, offsets = self._exchange(self._ipc_of(self.meta))
+        handles, offsets = self._exchange((self._meta_block.ipc_handle, 0))
         self._ptr = ops.init_custom_ar(self.meta, self.rank_data, handles, offsets, self.rank, self.full_nvlink)
         self.disabled, self.disabled_reason = False, ""
         self.register_buffer(self.buffer)
@@ -163,6 +221,11 @@ class CustomAllreduce:
         if self._ptr:
             ops.dispose(self._ptr)
             self._ptr = 0
+        block = getattr(self, "_meta_block", None)
+        if block is not None:      # after dispose: the library no longer touches the flag block
+            self.meta = None
+            block.free()
+            self._meta_block = None
 
     def __del__(self):
         self.close()

@@ -398,17 +398,25 @@ class DecodeRunner:
             torch.cuda.synchronize(self.device)
             get_tp_group().barrier()
         try:
+            # tests: inject a failure on one rank BEFORE the eager warm-up -- the hard case: its peers enter the warm-up
+            # without it.  Their first P2P collective runs into its bounded wait once; every later rendezvous of the
+            # communicator returns at once (csrc/custom_all_reduce.hip: ar_rendezvous fails fast on the sticky error word),
+            # and the error word is read after the FIRST eager step, so a lost peer costs about one bound, not one per
+            # collective of every warm-up step (~65 each)
+            if os.environ.get("NMV_TEST_FAIL_CAPTURE_RANK") == str(self.tp_rank):
+                raise RuntimeError("injected capture failure (NMV_TEST_FAIL_CAPTURE_RANK)")
             s = torch.cuda.Stream(device=self.device)
             s.wait_stream(prev_stream)
             with torch.cuda.stream(s):
-                for _ in range(warmup):  # first touch: marlin repack, workspace moves, allocator
+                for w in range(warmup):  # first touch: marlin repack, workspace moves, allocator
                     self._step_body()
+                    if w == 0 and self.tp_size > 1:
+                        torch.cuda.synchronize(self.device)
+                        car = getattr(get_tp_group(), "custom_ar", None)
+                        if car is not None and car.enabled and car.local_error():
+                            raise RuntimeError("a P2P all-reduce of the warm-up timed out (a peer is missing)")
             prev_stream.wait_stream(s)
             torch.cuda.synchronize(self.device)
-            # tests: inject a capture failure on one rank -- after the eager warm-up, which every rank has to take part
-            # in (a rank missing from it would leave its peers in the P2P collectives' bounded waits, 2 s each)
-            if os.environ.get("NMV_TEST_FAIL_CAPTURE_RANK") == str(self.tp_rank):
-                raise RuntimeError("injected capture failure (NMV_TEST_FAIL_CAPTURE_RANK)")
             graph = torch.cuda.CUDAGraph()
             # thread_local: helper threads of the process group (watchdog, event polling) may call
             # into the runtime while this thread captures

@@ -134,9 +134,13 @@ def test_native_silu_mul_on_a_split_shape(gpu_device, m):
     ops.silu_and_mul(want, plain)
     got = native_gemm(a, LM._interleave_gate_up(q_w), LM._interleave_gate_up(s), k, n, gpu_device, 1)
     assert rel_err(got, want) < 1e-3
-    ulps = (got.view(torch.int16).int() - want.view(torch.int16).int()).abs()
-    # gate and up are each rounded before silu * up: one ulp in either moves the product by at most a few
-    assert int(ulps.max()) <= 4 and float((ulps > 0).float().mean()) < 0.05
+    # gate and up are each rounded to the model dtype before silu * up: an ulp (2^-8 relative) in either moves the product
+    # by a few ulps of its own magnitude; products near zero are bounded absolutely (an ulp of gate there is an ulp of
+    # the typical gate, not of the product)
+    g, w = got.float(), want.float()
+    bound = 4 * 2.0 ** -8 * w.abs() + 2.0 ** -8 * w.abs().mean()
+    assert bool(((g - w).abs() <= bound).all())
+    assert float((got.view(torch.int16) != want.view(torch.int16)).float().mean()) < 0.05
 
 
 @pytest.mark.parametrize("m", [1, 16, 48, 64])

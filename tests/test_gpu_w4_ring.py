@@ -40,6 +40,7 @@ def ring(monkeypatch):
     monkeypatch.setenv("NMV_W4R", "1")
     monkeypatch.setenv("NMV_W4R_MIN_M", "17")
     monkeypatch.setenv("NMV_W4R_MIN_WGS", "1")
+    monkeypatch.setenv("NMV_W4R_PREFILL", "1")
     yield monkeypatch
     assert _lib.load().nmv_w4_ring_timeouts() == 0
 
@@ -64,6 +65,37 @@ def test_ring_gemm(gpu_device, ring, k, n, m, dtype):
     e = rel_err(out, ref)
     assert e < 0.04 and e < 6e-3, e
     assert (out.float() - ref).abs().max().item() < 0.04 * ref.abs().max().item() + 1e-2
+
+
+@pytest.mark.parametrize("k,n", [(256, 64), (1024, 448), (4096, 6144), (14336, 4096)])
+@pytest.mark.parametrize("m", [65, 128, 129, 200, 512])
+@pytest.mark.parametrize("dtype", [torch.half, torch.bfloat16])
+def test_ring_gemm_prompt_sized(gpu_device, ring, k, n, m, dtype):
+    """65 rows and more: row blocks of the 128-row tile (one k-lane, activation fragments read k-step by k-step, row
+    tile cb summed by column-block wave cb)"""
+    a, q_w, s, w_ref = problem(11, m, k, n, dtype)
+    out = native_gemm(a, q_w, s, k, n, gpu_device).cpu()
+    ref = (a.double() @ w_ref.double()).float()
+    e = rel_err(out, ref)
+    assert e < 0.04 and e < 6e-3, e
+    assert (out.float() - ref).abs().max().item() < 0.04 * ref.abs().max().item() + 1e-2
+
+
+def test_ring_gemm_prompt_sized_one_hot_and_modes(gpu_device, ring):
+    k, n, m = 512, 448, 150
+    _, q_w, s, _ = problem(12, 1, k, n, torch.bfloat16)
+    rows = [(37 * i) % k for i in range(m)]
+    a = torch.zeros((m, k), dtype=torch.bfloat16)
+    for i, r in enumerate(rows):
+        a[i, r] = 1.0
+    out = native_gemm(a, q_w, s, k, n, gpu_device)
+    want = ((q_w[rows].float() - 8) * s.float()[[r // 128 for r in rows]]).to(torch.bfloat16)
+    assert torch.equal(out.cpu().view(torch.int16), want.view(torch.int16))
+    slab = native_gemm(a, q_w, s, k, n, gpu_device, 2)
+    acc = torch.zeros_like(slab[0])
+    for i in range(slab.shape[0]):
+        acc = acc + slab[i]
+    assert torch.equal(acc.to(torch.bfloat16).view(torch.int16), out.view(torch.int16))
 
 
 @pytest.mark.parametrize("splits", [1, 2, 4, 8, 16])

@@ -156,6 +156,30 @@ def test_deferred_reduce_admission_asks_the_method_with_the_layers_group_count(m
     assert len(seen) == 2   # the hook decides alone
 
 
+def test_custom_allreduce_mesh_check_uses_physical_device_ids(monkeypatch):
+    """CustomAllreduce.full_nvlink (round-3 ADVICE): ranks exchange PHYSICAL device ids (through HIP_VISIBLE_DEVICES /
+    CUDA_VISIBLE_DEVICES, as the reference's _can_p2p does), and a peer device this process cannot see makes the answer
+    'unknown' (None), never 'full mesh' -- with one visible device per rank every local ordinal is 0"""
+    import torch
+
+    from neural_magic_vllm_amd.distributed.device_communicators import custom_all_reduce as car
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 2)
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "5,2")
+    assert car._visible_physical_ids() == [5, 2]
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES")
+    monkeypatch.setenv("CUDA_VISIBLE_DEVICES", "3")
+    assert car._visible_physical_ids() == [3]
+    monkeypatch.setenv("CUDA_VISIBLE_DEVICES", "GPU-deadbeef")
+    assert car._visible_physical_ids() == []
+    monkeypatch.delenv("CUDA_VISIBLE_DEVICES")
+    assert car._visible_physical_ids() == [0, 1]
+    asked = []
+    monkeypatch.setattr(torch.cuda, "can_device_access_peer", lambda a, b: asked.append((a, b)) or (a, b) != (0, 1))
+    assert car._mesh_is_full([5, 2], [5, 2]) is False and (0, 1) in asked     # asked with LOCAL ordinals of physical 5, 2
+    assert car._mesh_is_full([2, 2, 2, 2], [5, 2]) is True                    # ranks time-sharing one device (tests)
+    assert car._mesh_is_full([0, 1, 2, 3], [1]) is None                       # one visible device per rank: unknown
+
+
 def test_checkpoint_iterator_and_quant_config(tmp_path):
     """model_loader: every tensor of every safetensors shard comes back under its name; the quantisation
     config is config.json's `quantization_config` when present, else quantize_config.json

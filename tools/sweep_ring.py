@@ -34,11 +34,16 @@ if __name__ == "__main__":
                 for kk in KNOBS:
                     os.environ.pop(kk, None)
                 os.environ["NMV_W4R"] = "0"
-                us, _ = bench(name, k, n, m, dev, iters=args.iters, native=md)
-                res.append(f"stream {us:.1f}")
+                if m <= 64:
+                    us, _ = bench(name, k, n, m, dev, iters=args.iters, native=md)
+                    res.append(f"stream {us:.1f}")
+                else:   # prompt-sized: the tall kernel on the Marlin tensor is what the ring replaces
+                    us, _ = bench(name, k, n, m, dev, iters=args.iters, native=None, mode=md)
+                    res.append(f"tall(marlin) {us:.1f}")
                 os.environ["NMV_W4R"] = "1"
                 os.environ["NMV_W4R_MIN_M"] = "17"
                 os.environ["NMV_W4R_MIN_WGS"] = "1"
+                os.environ["NMV_W4R_PREFILL"] = "1"
                 for sp in [int(x) for x in args.splits.split(",")]:
                     if (k // 128) % sp or (k // 128) // sp > 32 or (md == 1 and sp > 1):
                         continue
