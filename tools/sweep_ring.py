@@ -22,6 +22,7 @@ if __name__ == "__main__":
     ap.add_argument("--modes", default="0,2")
     ap.add_argument("--splits", default="1,2,4,7,8,14,16")
     ap.add_argument("--iters", type=int, default=16)
+    ap.add_argument("--mt", default="", help="force the row tile (NMV_W4R_MT): 2 = row blocks of 32, 4 = 64")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     lib = _lib.load()
@@ -42,6 +43,8 @@ if __name__ == "__main__":
                     res.append(f"tall(marlin) {us:.1f}")
                 os.environ["NMV_W4R"] = "1"
                 os.environ["NMV_W4R_MIN_M"] = "17"
+                if args.mt:
+                    os.environ["NMV_W4R_MT"] = args.mt
                 os.environ["NMV_W4R_MIN_WGS"] = "1"
                 os.environ["NMV_W4R_PREFILL"] = "1"
                 for sp in [int(x) for x in args.splits.split(",")]:
