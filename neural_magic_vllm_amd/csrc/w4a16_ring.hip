@@ -373,6 +373,8 @@ __global__ __launch_bounds__(ring_threads(MT), MT >= 8 ? 2 : 3) void w4a16_ring_
 
     f32x16_t accg[MT2];
     uint32_t wq[8];
+    uint4 w4n = make_uint4(0, 0, 0, 0);
+    (void)w4n;
     // the scales of the zero-point pass after the loop (this k-lane's rounds of 8 groups, below) are fetched after the loop,
     // under the wait for the other consumers' row sums (requesting them before the loop costs four registers the loop
     // does not have: the 64-row tile sits at the 128-register limit of four waves per SIMD)
@@ -401,10 +403,11 @@ __global__ __launch_bounds__(ring_threads(MT), MT >= 8 ? 2 : 3) void w4a16_ring_
       // rows: the kernel runs three waves per SIMD, 168 registers) -- and both slots are handed back before the first MFMA:
       // the LDS latency is paid once per group, not once per k-step, and a slot is held for the length of the issue only
       if (!(dbg & 4)) {
+        const int w_slot = slot_w * WSL + w_base;   // one address register, eight immediate offsets
 #pragma unroll
         for (int t2 = 0; t2 < 4; ++t2) {   // k-steps 2 t2 (offset 0) and 2 t2 + 1 (+ 512 bytes) of 32-k step t2 (2 KiB apart)
-          wq[2 * t2] = *reinterpret_cast<const uint32_t*>(sl + w_base + t2 * 2048);
-          wq[2 * t2 + 1] = *reinterpret_cast<const uint32_t*>(sl + w_base + t2 * 2048 + 512);
+          wq[2 * t2] = *reinterpret_cast<const uint32_t*>(smem + w_slot + t2 * 2048);
+          wq[2 * t2 + 1] = *reinterpret_cast<const uint32_t*>(smem + w_slot + t2 * 2048 + 512);
         }
       } else {
 #pragma unroll
@@ -464,11 +467,21 @@ __global__ __launch_bounds__(ring_threads(MT), MT >= 8 ? 2 : 3) void w4a16_ring_
           asm volatile("" ::"v"(af[ti][0][0]), "v"(wq[t]));
           continue;
         }
-        const uint32_t x = wq[t];
         constexpr int P0 = W4N<T>::POS;
-        const uint4 w4 = make_uint4(and_or(P0 == 0 ? x : x << P0, kmask, kmagic),
-                                    and_or(4 >= P0 ? x >> (4 - P0) : x << (P0 - 4), kmask, kmagic),
-                                    and_or(x >> (8 - P0), kmask, kmagic), and_or(x >> (12 - P0), kmask, kmagic));
+        auto expand = [&](uint32_t x) -> uint4 {
+          return make_uint4(and_or(P0 == 0 ? x : x << P0, kmask, kmagic),
+                            and_or(4 >= P0 ? x >> (4 - P0) : x << (P0 - 4), kmask, kmagic),
+                            and_or(x >> (8 - P0), kmask, kmagic), and_or(x >> (12 - P0), kmask, kmagic));
+        };
+#ifdef NMV_W4R_PIPE
+        // software-pipelined expansion: the NEXT k-step's code dword is expanded in the shadow of this step's MFMAs
+        // (one MFMA, half of the expansion, the other MFMA, the rest: pinned for the machine scheduler)
+        if (t == 0) w4n = expand(wq[0]);
+        const uint4 w4 = w4n;
+        if (t + 1 < 8) w4n = expand(wq[t + 1]);
+#else
+        const uint4 w4 = expand(wq[t]);
+#endif
 #pragma unroll
         for (int mt = 0; mt < MT2; ++mt) {
           if (dbg & 2) {
@@ -486,6 +499,14 @@ __global__ __launch_bounds__(ring_threads(MT), MT >= 8 ? 2 : 3) void w4a16_ring_
             accg[mt] = mfma32<T>(af[ti][mt], w4, accg[mt]);
           }
         }
+#ifdef NMV_W4R_PIPE
+        if (t + 1 < 8 && !(dbg & 10)) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
+          __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);   // its share of the next expansion
+          __builtin_amdgcn_sched_group_barrier(0x008, MT2 - 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+        }
+#endif
         __builtin_amdgcn_sched_barrier(0);
       }
       if constexpr (!STEPWISE) {
