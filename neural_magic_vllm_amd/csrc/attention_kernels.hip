@@ -32,7 +32,6 @@
 namespace nmv {
 
 constexpr int PA_WIN = 64;  // tokens per wave-iteration
-constexpr int PA_TAIL = 32; // most leftover tokens of a wave's run that its last full window takes along ("tail fold")
 constexpr int PA_PARTITION = 512;
 
 template <int HEAD_SIZE, int BLOCK_SIZE, int HG, bool FP8>
@@ -132,7 +131,7 @@ __global__ __launch_bounds__(NW * WAVE, (PAGeom<HEAD_SIZE, BLOCK_SIZE, HG, FP8>:
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 
   __shared__ __attribute__((aligned(16))) uint32_t q_s[HG * HEAD_SIZE / 2];
-  __shared__ __attribute__((aligned(16))) uint32_t p_s[NW][HG][(PA_WIN + PA_TAIL) / 2];
+  __shared__ __attribute__((aligned(16))) uint32_t p_s[NW][HG][PA_WIN / 2];
   __shared__ float red_m[NW][HG];
   __shared__ float red_l[NW][HG];
   __shared__ float out_red[NW][HG][HEAD_SIZE];
@@ -285,30 +284,13 @@ __global__ __launch_bounds__(NW * WAVE, (PAGeom<HEAD_SIZE, BLOCK_SIZE, HG, FP8>:
   };
   int phys = w_tok0 < w_tok1 ? phys_of(w_tok0) : 0;
 
-  // Tail fold: a window is a chain of dependent round trips (block table -> K -> softmax -> V) that costs the same
-  // ~11 us whether it holds 64 tokens or 16, so a run of 9 or 10 blocks (a third window of one or two blocks) set the
-  // time of the workgroup: 43.6 us against 32.2 in the decode step.  When at least one full window precedes them,
-  // leftover tokens of up to PA_TAIL ride along in the LAST full window: lanes 0..PA_TAIL-1 carry a second token through
-  // the same round trips (their K chunks, their logit, their probability), P.V walks the extra block(s).  Exactly the
-  // same softmax (one more max / sum term per lane), so the parity tests are unchanged.  Not for the block-sparse form.
-  const int run_tokens = w_tok1 - w_tok0;
-  const int n_full = run_tokens / PA_WIN;
-  const int left = run_tokens - n_full * PA_WIN;
-  const bool fold = !SPARSE && n_full >= 1 && left > 0 && left <= PA_TAIL;     // wave-uniform
-  const int w_loop_end = fold ? w_tok0 + n_full * PA_WIN : w_tok1;
-  const int tail_tok0 = w_loop_end;                                            // first folded token
-  const int lane_t = lane & (PA_TAIL - 1);
-  int phys2 = 0;
-  if (fold) phys2 = block_table[min(tail_tok0 + lane_t, w_tok1 - 1) / BLOCK_SIZE];
-
-  for (int wstart = w_tok0; wstart < w_loop_end; wstart += PA_WIN) {
-    const bool last_fold = fold && wstart + PA_WIN >= w_loop_end;              // wave-uniform
+  for (int wstart = w_tok0; wstart < w_tok1; wstart += PA_WIN) {
     const int tok = wstart + lane;
     const bool valid = tok < w_tok1;
     const int tok_c = valid ? tok : w_tok1 - 1;
     const int boff = tok_c % BLOCK_SIZE;
     // block-table lookup of the NEXT window issued before this window's loads are consumed
-    const int phys_next = (wstart + PA_WIN < w_loop_end) ? phys_of(wstart + PA_WIN) : 0;
+    const int phys_next = (wstart + PA_WIN < w_tok1) ? phys_of(wstart + PA_WIN) : 0;
 
     // block-sparse: a window none of whose tokens any head of the group attends to is skipped before its K / V are
     // loaded (the reference skips masked blocks the same way, attention_kernels.cu:209-251).  Exact: such a window
@@ -343,7 +325,6 @@ __global__ __launch_bounds__(NW * WAVE, (PAGeom<HEAD_SIZE, BLOCK_SIZE, HG, FP8>:
     float s[HG];
 #pragma unroll
     for (int h = 0; h < HG; ++h) s[h] = 0.f;
-    auto qk_token = [&](const uint8_t* kp, float (&s)[HG]) {
 #pragma unroll
     for (int c0 = 0; c0 < G::NKC; c0 += G::KG) {
       uint4 kc[G::KG];
@@ -388,10 +369,8 @@ __global__ __launch_bounds__(NW * WAVE, (PAGeom<HEAD_SIZE, BLOCK_SIZE, HG, FP8>:
         }
         // block-sparse form: left alone, the LDS reads of the queries of ALL chunks are issued first (256 VGPRs, then
         // spills); the empty asm pins the dot products of a pair of chunks before the next pair's reads
-        // round 4: pinned in the dense form too -- with the tail fold's second pass over the chunks in the same region the
-        // unpinned schedule spilled 1.5 KB per lane; pinned, the dense kernel measured the same in round 3 (26.2 vs 26.1 us)
 #ifndef NMV_PA_PIN
-#define NMV_PA_PIN 1
+#define NMV_PA_PIN 0
 #endif
         if constexpr (SPARSE || NMV_PA_PIN) {
           if ((j & 1) == 1) {
@@ -401,27 +380,13 @@ __global__ __launch_bounds__(NW * WAVE, (PAGeom<HEAD_SIZE, BLOCK_SIZE, HG, FP8>:
         }
       }
     }
-    };
-    qk_token(kp, s);
-    // the folded tail: lanes 0 .. PA_TAIL-1 take a second token (the other lanes repeat their addresses: no more traffic)
-    float s2[HG];
-#pragma unroll
-    for (int h = 0; h < HG; ++h) s2[h] = 0.f;
-    const int tok2 = tail_tok0 + lane_t;
-    const bool valid2 = last_fold && lane < PA_TAIL && tok2 < w_tok1;
-    if (last_fold) {
-      const int tok2_c = min(tok2, w_tok1 - 1);
-      qk_token(k_cache + (int64_t)phys2 * block_stride_bytes + head_off_bytes + (tok2_c % BLOCK_SIZE) * 16, s2);
-    }
 
     // the first V group of the window does not depend on the probabilities: its loads are issued here and land
     // under the softmax (max reduction, exp, LDS strip) instead of after it (measured: -1..2 % at B = 64,
     // -4..6 % at B = 8; 172 VGPRs instead of 148, still two waves per SIMD)
     constexpr int VG = G::NVL < NMV_PA_VG ? G::NVL : NMV_PA_VG;  // V wave-loads in flight per lane
     auto load_vgroup = [&](int b, int i0, uint32_t (&vraw)[VG][4]) {
-      // blocks past the window's own are the folded tail's (their table entries sit in phys2, by tail token)
-      const int physb = b < G::WB ? __builtin_amdgcn_readlane(phys, (b < G::WB ? b : 0) * BLOCK_SIZE)
-                                  : __builtin_amdgcn_readlane(phys2, ((b >= G::WB ? b - G::WB : 0) * BLOCK_SIZE) & (PA_TAIL - 1));
+      const int physb = __builtin_amdgcn_readlane(phys, b * BLOCK_SIZE);
       const uint8_t* vp = v_cache + (int64_t)physb * block_stride_bytes + head_off_bytes + (int64_t)cpr_idx * G::VB;
 #pragma unroll
       for (int ii = 0; ii < VG; ++ii) {
@@ -461,25 +426,18 @@ __global__ __launch_bounds__(NW * WAVE, (PAGeom<HEAD_SIZE, BLOCK_SIZE, HG, FP8>:
       if constexpr (SPARSE)
         attend = valid && (sp_u ? att_u[h] : (kb_local || (kb + sp_off[h]) % sp.vert_stride == 0));
       sv = attend ? sv : -INFINITY;
-      float sv2 = -INFINITY;
-      if (last_fold) {   // wave-uniform
-        sv2 = s2[h] * qk_scale + ((slope[h] != 0.f) ? slope[h] * (float)(tok2 - seq_len + 1) : 0.f);
-        sv2 = valid2 ? sv2 : -INFINITY;
-      }
-      const float m_new = fmaxf(m_run[h], wave_max(fmaxf(sv, sv2)));
+      const float m_new = fmaxf(m_run[h], wave_max(sv));
       // exp(-inf) = 0 on the first window; a window in which this head attends to nothing (block-sparse) leaves
       // m_new at -inf: nothing has been accumulated yet, 0 keeps it so (and avoids exp(-inf + inf))
       const float alpha = m_new == -INFINITY ? 0.f : __expf(m_run[h] - m_new);
       const float p = attend ? __expf(sv - m_new) : 0.f;
-      const float p2 = valid2 ? __expf(sv2 - m_new) : 0.f;
-      l_lane[h] = l_lane[h] * alpha + p + p2;
+      l_lane[h] = l_lane[h] * alpha + p;
       m_run[h] = m_new;
 #pragma unroll
       for (int i = 0; i < G::NVL; ++i) acc[h][i] *= alpha;
       // probabilities are rounded to the cache's compute dtype before P.V, as the reference
       // does (attention_kernels.cu:398-400 from_float(logits_vec, ...))
       reinterpret_cast<uint16_t*>(&p_s[wave][h][0])[lane] = T::from_float(p);
-      if (last_fold && lane < PA_TAIL) reinterpret_cast<uint16_t*>(&p_s[wave][h][0])[PA_WIN + lane] = T::from_float(p2);
     }
     // p_s is private to this wave: LDS ops of one wave execute in order, only the compiler
     // has to be kept from reordering the stores above past the loads below.
@@ -488,11 +446,10 @@ __global__ __launch_bounds__(NW * WAVE, (PAGeom<HEAD_SIZE, BLOCK_SIZE, HG, FP8>:
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
     // ================= P.V : lanes re-mapped onto V's [row][token] layout =================
-    const int win_tokens = last_fold ? w_tok1 - wstart : min(w_tok1 - wstart, PA_WIN);   // up to PA_WIN + PA_TAIL
+    const int win_tokens = min(w_tok1 - wstart, PA_WIN);
     const int nb = (win_tokens + BLOCK_SIZE - 1) / BLOCK_SIZE;
-    constexpr int WBX = G::WB + (SPARSE ? 0 : (PA_TAIL + BLOCK_SIZE - 1) / BLOCK_SIZE);
 #pragma unroll
-    for (int b = 0; b < WBX; ++b) {
+    for (int b = 0; b < G::WB; ++b) {
       if (b >= nb) break;  // wave-uniform
       // tokens of this lane's chunk: t0 .. t0+TPCV-1 (window-relative)
       const int t0 = b * BLOCK_SIZE + cpr_idx * G::TPCV;

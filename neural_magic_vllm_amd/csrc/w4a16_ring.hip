@@ -473,7 +473,7 @@ __global__ __launch_bounds__(ring_threads(MT), MT >= 8 ? 2 : 3) void w4a16_ring_
                             and_or(4 >= P0 ? x >> (4 - P0) : x << (P0 - 4), kmask, kmagic),
                             and_or(x >> (8 - P0), kmask, kmagic), and_or(x >> (12 - P0), kmask, kmagic));
         };
-#ifdef NMV_W4R_PIPE
+#ifndef NMV_W4R_NO_PIPE
         // software-pipelined expansion: the NEXT k-step's code dword is expanded in the shadow of this step's MFMAs
         // (one MFMA, half of the expansion, the other MFMA, the rest: pinned for the machine scheduler)
         if (t == 0) w4n = expand(wq[0]);
@@ -499,7 +499,7 @@ __global__ __launch_bounds__(ring_threads(MT), MT >= 8 ? 2 : 3) void w4a16_ring_
             accg[mt] = mfma32<T>(af[ti][mt], w4, accg[mt]);
           }
         }
-#ifdef NMV_W4R_PIPE
+#ifndef NMV_W4R_NO_PIPE
         if (t + 1 < 8 && !(dbg & 10)) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
           __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);   // its share of the next expansion
