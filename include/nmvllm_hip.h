@@ -505,6 +505,12 @@ int nmv_car_set_algo(void* state, int algo);
 int nmv_car_error(void* state);
 int nmv_car_dispose(void* state);
 
+/* Infinity-Cache prefetch (not an op of nm-vllm 0.5.1): reads `bytes` bytes at `ptr` (16-byte aligned) once with
+ * `workgroups` (0: 64) workgroups of 256 threads on `stream` and stores nothing -- launched on a side stream it pulls the
+ * NEXT decoder layer's weights into the 256 MiB on-die cache while the current layer computes (small batches: the layer
+ * leaves HBM idle most of the time).  A hint: results never depend on it. */
+int nmv_prefetch_l3(const void* ptr, int64_t bytes, int workgroups, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

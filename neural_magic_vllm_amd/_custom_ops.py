@@ -428,6 +428,11 @@ def rotary_embedding_and_cache_partial(positions: torch.Tensor, slab: torch.Tens
                                                  kv_cache_dtype, kv_scale, dtype)
 
 
+def prefetch_l3(t: torch.Tensor, workgroups: int = 0) -> None:
+    from neural_magic_vllm_amd import _torch_bindings as tb
+    tb.prefetch_l3(t, workgroups)
+
+
 def greedy_sample_shard(logits: torch.Tensor, index_offset: int) -> torch.Tensor:
     from neural_magic_vllm_amd import _torch_bindings as tb
     return tb.greedy_sample_shard(logits, index_offset)

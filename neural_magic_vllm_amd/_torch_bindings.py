@@ -655,6 +655,14 @@ def gptq_marlin_gemm_silu_mul(a, b_q_weight, b_scales, workspace, size_m, size_n
     return c
 
 
+def prefetch_l3(t: torch.Tensor, workgroups: int = 0) -> None:
+    """read tensor `t` once on the current stream and store nothing (include/nmvllm_hip.h: nmv_prefetch_l3): a cache hint"""
+    _req(t.is_cuda and t.is_contiguous(), "prefetch_l3: a contiguous device tensor")
+    nbytes = t.numel() * t.element_size()
+    with device_guard(t):
+        check(_lib.load().nmv_prefetch_l3(ptr(t), nbytes - nbytes % 16, workgroups, stream_of(t)))
+
+
 def greedy_sample_advance(logits, input_ids=None, positions=None, seq_lens=None, slot_mapping=None,
                           block_tables=None, block_size=0) -> torch.Tensor:
     """argmax over logits [B, V] (ties -> lowest index) -> int64 [B]; with the state tensors also

@@ -219,3 +219,39 @@ extern "C" int nmv_greedy_sample_finish(int64_t* next_tokens, const void* gather
   NMV_LAUNCH_CHECK();
   return NMV_OK;
 }
+
+
+/* ------------------------------------------------------------------------------------------------
+ * Infinity-Cache prefetch (MI355X-first, not an op of nm-vllm 0.5.1).  At small batches a decoder layer streams
+ * its weights once and leaves HBM idle most of the time (60 us per layer for 112.6 MB at B = 1: 35 % of 8 TB/s), while
+ * each of its GEMM launches pays an HBM round trip before its first MFMA.  The 256 MiB Infinity Cache holds two layers'
+ * codes: this kernel, launched on a SIDE stream while layer L computes, reads layer L + 1's weight tensors once (plain
+ * loads, default cache policy, nothing stored), so that layer L + 1's GEMMs find them on-die -- measured on the GEMMs
+ * alone (tools/bench_gemm.py, NMV_BENCH_NCOPY=1): 38.3 -> 31.5 us per layer at M = 1.  A hint only: results never depend
+ * on it. */
+__global__ __launch_bounds__(256) void prefetch_l3_kernel(const uint4* __restrict__ p, int64_t n_vec) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  uint32_t keep = 0;
+  // 8 independent 16-byte loads in flight per lane
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  for (; i + 7 * stride < n_vec; i += 8 * stride) {
+    uint4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = p[i + u * stride];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) keep ^= v[u].x ^ v[u].w;
+  }
+  for (; i < n_vec; i += stride) keep ^= p[i].x;
+  asm volatile("" ::"v"(keep));   // the loads must happen; their values go nowhere
+}
+
+extern "C" int nmv_prefetch_l3(const void* ptr, int64_t bytes, int workgroups, void* stream) {
+  NMV_CHECK(bytes >= 0 && workgroups >= 0, "prefetch_l3: negative size");
+  NMV_CHECK(((uintptr_t)ptr & 15) == 0, "prefetch_l3: the pointer must be 16-byte aligned");
+  const int64_t n_vec = bytes / 16;
+  if (ptr == nullptr || n_vec == 0) return NMV_OK;
+  const int wgs = workgroups > 0 ? workgroups : 64;
+  hipLaunchKernelGGL(prefetch_l3_kernel, dim3((unsigned)wgs), dim3(256), 0, (hipStream_t)stream, (const uint4*)ptr, n_vec);
+  NMV_LAUNCH_CHECK();
+  return NMV_OK;
+}

@@ -1431,6 +1431,8 @@ extern "C" int64_t nmv_gptq_marlin_gemm_scratch_bytes(int size_m, int size_n, in
     if (w4s_make_plan(size_m, size_n, size_k, INT64_MAX, false, true, &sp)) max_splits = std::max(max_splits, sp.splits);
     W4RingPlan rp;   // the native tensor's calls size their scratch with this function too
     if (w4r_make_plan(size_m, size_n, size_k, INT64_MAX, false, &rp)) max_splits = std::max(max_splits, rp.splits);
+    W4PrefillPlan pp;
+    if (w4p_make_plan(size_m, size_n, size_k, INT64_MAX, false, &pp)) max_splits = std::max(max_splits, pp.splits);
   }
   // ... and of the generic kernel that takes the remaining variants (8-bit groups of 32 / 64, act-order on a K
   // shard): its gathered activations + slabs
@@ -1483,6 +1485,40 @@ static int marlin_gemm_impl(void* c, const void* a, const int32_t* b_q_weight, c
     NMV_CHECK(rc == 0, "gptq_marlin_gemm: generic path launch failed");
     NMV_LAUNCH_CHECK();
     return NMV_OK;
+  }
+  // prompt-sized calls on the native tensor: 256 x 128 tiles with the codes expanded once per workgroup (w4a16_prefill.hip)
+  if (native && num_bits == 4 && !has_act_order && group_size == 128 && b_zeros == nullptr) {
+    W4PrefillPlan pp;
+    if (w4p_make_plan(size_m, size_n, size_k, epi == 2 ? INT64_MAX : (workspace ? workspace_len : 0), epi == 1, &pp) &&
+        (epi != 1 || (pp.splits == 1 && size_n % 128 == 0))) {
+      const int64_t need = (pp.splits > 1 || epi == 2) ? (int64_t)pp.splits * size_m * size_n * 4 : 0;
+      NMV_CHECK(need < (int64_t)1 << 31, "w4_native_gemm: split-K slab too large");
+      NMV_CHECK(scratch_bytes >= need && (need == 0 || scratch != nullptr),
+                "w4_native_gemm: scratch too small (%lld < %lld)", (long long)scratch_bytes, (long long)need);
+      GemmParams p;
+      p.a = (const uint16_t*)a;
+      p.b = (const uint4*)b_q_weight;
+      p.s = (const uint16_t*)b_scales;
+      p.zp = nullptr;
+      p.perm = nullptr;
+      p.c = (uint16_t*)c;
+      p.slab = (float*)scratch;
+      p.tickets = workspace;
+      p.M = size_m; p.N = size_n; p.K = size_k;
+      p.bits = 4;
+      p.group_size = 128;
+      p.k_per_wg = pp.k_per_wg;
+      p.splits = pp.splits;
+      p.native = 1;
+      p.fp8 = 0;
+      p.epi = epi;
+      p.g_stage = 0;
+      p.n_stages = 0;
+      const int rc = w4p_launch(pp, p, dtype == NMV_F16, (hipStream_t)stream);
+      NMV_CHECK(rc == 0, "w4_native_gemm: prefill kernel launch failed for splits=%d (rc %d)", pp.splits, rc);
+      NMV_LAUNCH_CHECK();
+      return NMV_OK;
+    }
   }
   // 17..64 rows on the native tensor: loader / consumer waves over an LDS-DMA ring (w4a16_ring.hip)
   if (native && num_bits == 4 && !has_act_order && group_size == 128 && b_zeros == nullptr) {
@@ -1720,6 +1756,9 @@ extern "C" int nmv_w4_native_repack(const int32_t* qweight, const int32_t* perm,
 extern "C" int nmv_w4_native_gemm_splits(int size_m, int size_n, int size_k, int num_groups) {
   if (size_m <= 0 || size_n <= 0 || size_k <= 0 || size_n % 64 != 0 || size_k % 256 != 0) return 0;
   // group 128 takes w4a16_ring.hip (17..64 rows) or w4a16_stream.hip (as nmv_gptq_marlin_gemm_partial_splits)
+  W4PrefillPlan pp;
+  if (num_groups > 1 && size_k / num_groups == 128 && w4p_make_plan(size_m, size_n, size_k, INT64_MAX, false, &pp))
+    return pp.splits;
   W4RingPlan rp;
   if (num_groups > 1 && size_k / num_groups == 128 && w4r_make_plan(size_m, size_n, size_k, INT64_MAX, false, &rp))
     return rp.splits;

@@ -179,6 +179,51 @@ def test_fused_glue_is_bit_identical(gpu_device, monkeypatch, quant, wide_mlp):
         assert torch.equal(a.view(torch.int16), b.view(torch.int16))
 
 
+@pytest.mark.parametrize("use_graph", [False, True], ids=["eager", "hipgraph"])
+def test_weight_prefetch_hint_changes_no_result(gpu_device, monkeypatch, use_graph):
+    """the Infinity-Cache prefetch of the next layer's weights (models/llama.py: LlamaModel.forward, a side stream of
+    load-only launches) is a hint: same tokens, same KV cache with and without it, eagerly and as a branch of the graph"""
+    import dataclasses
+    from neural_magic_vllm_amd.worker import decode_runner as dr
+    from neural_magic_vllm_amd import _custom_ops as ops
+    arch = dataclasses.replace(dr.TINY, num_hidden_layers=3)
+    quant = dict(method="gptq_marlin", bits=4, group_size=128)
+    outs, calls = {}, {}
+    real = ops.prefetch_l3
+    for on in (True, False):
+        monkeypatch.setenv("NMV_PREFETCH", "1" if on else "0")
+        n = [0]
+
+        def counted(t, wgs=0, n=n):
+            n[0] += 1
+            real(t, wgs)
+        monkeypatch.setattr(ops, "prefetch_l3", counted)
+        _, _, runner = build(quant, gpu_device, arch)
+        runner.setup_batch(5, 40, 8)
+        runner.fill_context()
+        if use_graph:
+            assert runner.capture()
+        toks = [runner.decode_step().clone() for _ in range(4)]
+        torch.cuda.synchronize()
+        outs[on], calls[on] = (torch.stack(toks).cpu(), [kv.clone() for kv in runner.kv_caches]), n[0]
+    assert calls[True] > 0 and calls[False] == 0
+    assert torch.equal(outs[True][0], outs[False][0])
+    for a, b in zip(outs[True][1], outs[False][1]):
+        assert torch.equal(a.view(torch.int16), b.view(torch.int16))
+
+
+def test_prefetch_l3_reads_any_tail_and_refuses_misaligned_pointers(gpu_device):
+    from neural_magic_vllm_amd import _custom_ops as ops
+    for n in (0, 1, 15, 16, 4097, 1 << 20, (1 << 22) + 24):
+        t = torch.zeros(n, dtype=torch.uint8, device=gpu_device)
+        ops.prefetch_l3(t)
+        ops.prefetch_l3(t, 7)
+    torch.cuda.synchronize()
+    t = torch.zeros(4096, dtype=torch.uint8, device=gpu_device)[4:]
+    with pytest.raises(Exception, match="aligned"):
+        ops.prefetch_l3(t)
+
+
 def test_runner_refuses_to_run_past_its_tables(gpu_device):
     """positions index the rotary table and the block tables on the device: the runner must stop on the
     host instead (a context beyond max_position_embeddings or a step beyond max_new_tokens would be an

@@ -27,7 +27,8 @@ def bench(name, k, n, m, dev, iters=40, gs=128, native=None, mode=0):
     """native: None = the Marlin ops (mode 0 gptq_marlin_gemm, 1 ..._silu_mul, 2 ..._partial);
     0 / 1 / 2 = nmv_w4_native_gemm in that mode"""
     nbytes = k * n // 2
-    ncopy = max(2, (600 << 20) // nbytes)
+    # NMV_BENCH_NCOPY=1: the same weight tensor every call -- served by the 256 MiB Infinity Cache, not HBM
+    ncopy = int(os.environ.get("NMV_BENCH_NCOPY", max(2, (600 << 20) // nbytes)))
     g = torch.Generator(device=dev).manual_seed(0)
     ws = [torch.randint(-2**31, 2**31 - 1, (k // 16, n * 2), dtype=torch.int32, device=dev, generator=g)
           for _ in range(ncopy)]
