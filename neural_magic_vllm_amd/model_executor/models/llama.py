@@ -284,11 +284,15 @@ class LlamaModel(nn.Module):
     prefetch_workgroups = int(os.environ.get("NMV_PREFETCH_WGS", "64"))
 
     def _prefetch_stream(self, hidden_states: torch.Tensor):
-        """the side stream, or None when the hint is off: NMV_PREFETCH=0, a CPU tensor, or more rows than a layer leaves HBM
-        idle for (measured: bench.py --batch 1/8/16 gain, --batch 64 does not: its KV reads fill the cache and the bus)"""
+        """the side stream, or None when the hint is off (the default: NMV_PREFETCH=1 turns it on), for a CPU tensor, or
+        for more rows than a layer leaves HBM idle for.  Measured on MI355X, round 4 (tools/debug/ab_prefetch.sh,
+        profiles/r04_prefetch_branch.txt): the GEMMs alone gain 38.3 -> 31.5 us per layer at M = 1 when their weights are
+        cache-resident, but as a second branch of the step's hipGraph the load-only launches cost more than that: the
+        runtime splits a forked graph into segments on several queues with 50-100 us gaps between them (B = 1: 2.10 ->
+        3.4-3.6 ms per step at 64 / 256 / 1024 workgroups).  Off until the prefetch can ride inside the step's own launches."""
         if not hidden_states.is_cuda or hidden_states.shape[0] > self.prefetch_max_rows:
             return None
-        if os.environ.get("NMV_PREFETCH", "1") == "0":
+        if os.environ.get("NMV_PREFETCH", "0") != "1":
             return None
         s = getattr(self, "_side_stream", None)
         if s is None or s.device != hidden_states.device:
