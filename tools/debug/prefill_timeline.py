@@ -28,12 +28,12 @@ if __name__ == "__main__":
         ops.w4_native_gemm(a, ws[i], sc, wsp, m, n, k, mode)
     torch.cuda.synchronize()
     lib = _lib.load()
-    nwg = min(256, (n + 127) // 128)
+    nwg = min(256, (n + 255) // 256)
     buf = (ctypes.c_ulonglong * (256 * 8 * 16))()
     lib.w4p_dbg_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
     assert lib.w4p_dbg_stamps(buf, 256 * 8 * 16) == 0
     raw = np.frombuffer(buf, dtype=np.uint64).reshape(256, 8, 16)[:nwg].astype(np.float64)
-    stages = k // 64
+    stages = k // 32
     loop_us = raw[:, :, 8].mean() / 100.0
     print(f"K={k} N={n} M={m} mode={mode}: {nwg} workgroups of row block 0, {stages} stages; loop {loop_us:.1f} us "
           f"= {loop_us / stages * 1e3:.0f} ns per stage; shader clock ~ {raw[:, :, 7].mean() / loop_us / 1e3:.2f} GHz")
