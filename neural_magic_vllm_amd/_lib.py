@@ -28,7 +28,7 @@ class NmvError(RuntimeError):
 
 
 _lib: Optional[ctypes.CDLL] = None
-ABI_VERSION = 6   # nmv_abi_version() of the library this table describes (csrc/capi_common.hip)
+ABI_VERSION = 7   # nmv_abi_version() of the library this table describes (csrc/capi_common.hip)
 
 _P = c_void_p
 _I = c_int
@@ -79,6 +79,7 @@ SIGNATURES = {
     "nmv_w4_native_gemm": (_I, [_P, _P, _P, _P, _P, _L, _P, _L, _I, _I, _I, _I, _I, _I, _P]),
     "nmv_w4_ring_timeouts": (_I, []),
     "nmv_prefetch_l3": (_I, [_P, _L, _I, _P]),
+    "nmv_w4_native_prefill_plan": (_I, [_I, _I, _I]),
     "nmv_car_meta_size": (_L, []),
     "nmv_car_meta_alloc": (_I, [_L, _P, _P]),
     "nmv_car_meta_free": (_I, [_P]),

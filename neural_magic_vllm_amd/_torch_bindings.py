@@ -711,6 +711,11 @@ def w4_native_gemm_splits(size_m, size_n, size_k, num_groups=None) -> int:
     return int(_lib.load().nmv_w4_native_gemm_splits(size_m, size_n, size_k, num_groups))
 
 
+def w4_native_prefill_plan(size_m, size_n, size_k) -> bool:
+    """does the prompt-sized kernel on the native tensor serve a call of these sizes by the library's default rule"""
+    return bool(_lib.load().nmv_w4_native_prefill_plan(size_m, size_n, size_k))
+
+
 def w4_native_gemm(a, b_native, scales, workspace, size_m, size_n, size_k, mode=0) -> torch.Tensor:
     """mode 0: [M, N]; 1: silu(gate) * up -> [M, N/2]; 2: fp32 split-K slabs [splits, M, N] (deferred reduction)"""
     _req(a.is_contiguous() and a.shape == (size_m, size_k) and a.dtype in (torch.float16, torch.bfloat16),

@@ -1769,6 +1769,11 @@ extern "C" int nmv_w4_native_gemm_splits(int size_m, int size_n, int size_k, int
   return (pl.tall && pl.mt <= 4) ? pl.splits : 0;
 }
 
+extern "C" int nmv_w4_native_prefill_plan(int size_m, int size_n, int size_k) {
+  W4PrefillPlan pp;
+  return (size_m > 0 && size_n > 0 && size_k > 0 && w4p_make_plan(size_m, size_n, size_k, INT64_MAX, true, &pp)) ? 1 : 0;
+}
+
 extern "C" int nmv_w4_native_gemm(void* c, const void* a, const int32_t* b_native, const void* b_scales,
                                   int32_t* workspace, int64_t workspace_len, void* scratch, int64_t scratch_bytes,
                                   int size_m, int size_n, int size_k, int num_groups, nmv_dtype_t dtype, int mode,

@@ -74,7 +74,7 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 constexpr int PF_BM = 256, PF_BN = 256, PF_BK = 32;
 constexpr int PF_NTHR = 512;
 constexpr int PF_NA = 3, PF_NB = 2, PF_NC = 6, PF_NS = 3;   // ring depths: activations (64-k double stages), expanded weights, codes, scales
-constexpr int PF_DA = 2, PF_DC = 5;                          // ahead: activations (double stages), codes (stages)
+constexpr int PF_DA = 2, PF_DC = 4;                          // ahead: activations (double stages), codes (stages)
 constexpr int PF_A_BYTES = PF_BM * 128, PF_B_BYTES = PF_BN * 64, PF_C_BYTES = 4096, PF_S_BYTES = 512;
 constexpr int PF_A_OFF = 0;
 constexpr int PF_B_OFF = PF_A_OFF + PF_NA * PF_A_BYTES;
@@ -192,35 +192,33 @@ __global__ __launch_bounds__(PF_NTHR, 2) void w4a16_prefill_kernel(const GemmPar
       const_cast<uint4*>(p.b), 0, (int)(((int64_t)p.K * p.N) >> 1), 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_s = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<uint16_t*>(p.s), 0, (int)((int64_t)(p.K >> 7) * p.N * 2), 0x00020000);
-  // activations: a double stage (64 k) is 32 pieces of 8 rows x 128 B; wave 4 + v moves rows 64 v .. 64 v + 63 of it, the
-  // pieces of rows + 32 h .. + 32 h + 31 in the iteration of half h.  lane = (row i >> 3, slot i & 7); source chunk =
-  // slot ^ ((row >> 1) & 7) with (row >> 1) & 7 = (4 (u & 1) + (i >> 4)) & 7 for piece u of the four.
+  // activations: a double stage (64 k) is 32 pieces of 8 rows x 128 B; wave w moves rows 32 w .. 32 w + 31 of it, the two
+  // pieces of rows + 16 h .. + 16 h + 15 in the iteration of half h.  lane = (row i >> 3, slot i & 7); source chunk =
+  // slot ^ ((row >> 1) & 7) with (row >> 1) & 7 = (4 u + (i >> 4)) & 7 for piece u of the two.
   // Rows past M: the buffer's bounds return zeros only past the END of the matrix, so clamp them out explicitly.
-  uint32_t a_voff[2][4];
+  uint32_t a_voff[2][2];
 #pragma unroll
   for (int h = 0; h < 2; ++h)
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int row = m0 + 64 * (wave & 3) + 32 * h + 8 * u + (lane >> 3);
-      const uint32_t chunk = (uint32_t)((lane & 7) ^ ((4 * (u & 1) + (lane >> 4)) & 7));
+    for (int u = 0; u < 2; ++u) {
+      const int row = m0 + 32 * wave + 16 * h + 8 * u + (lane >> 3);
+      const uint32_t chunk = (uint32_t)((lane & 7) ^ ((4 * u + (lane >> 4)) & 7));
       a_voff[h][u] = row < p.M ? (uint32_t)(((int64_t)row * p.K + k_wg0) * 2) + chunk * 16 : PF_OOB;
     }
-  const uint32_t a_lds = lds0 + PF_A_OFF + (uint32_t)((wave & 3) * 8192);  // + slot * 32 KiB + h * 4 KiB + u * 1 KiB
-  // codes and scales: waves 0..3, wave w the native row (k-step = stage, chunk chunk0 + w) = 1 KiB and the 64 scales of
-  // that chunk (8 lanes x 16 bytes per group) -- the wave that loads them is the wave that expands them: its own
-  // `s_waitcnt vmcnt` is all the synchronisation the codes need, and the stream from HBM never holds up the activations'
-  const bool chunk_ok = chunk0 + (wave & 3) < n_chunks;
-  const uint32_t c_voff = chunk_ok ? (uint32_t)((chunk0 + (wave & 3)) * 1024 + lane * 16) : PF_OOB;
+  const uint32_t a_lds = lds0 + PF_A_OFF + (uint32_t)(wave * 4096);        // + slot * 32 KiB + h * 2 KiB + u * 1 KiB
+  // codes: waves 0..3, wave w the native row (k-step = stage, chunk chunk0 + w) = 1 KiB
+  const uint32_t c_voff = (wave < 4 && chunk0 + wave < n_chunks) ? (uint32_t)((chunk0 + wave) * 1024 + lane * 16) : PF_OOB;
   const uint32_t c_lds = lds0 + PF_C_OFF + (uint32_t)((wave & 3) * 1024);
-  const uint32_t s_voff = (lane < 8 && chunk_ok) ? (uint32_t)(((chunk0 + (wave & 3)) * 64 + lane * 8) * 2) : PF_OOB;
-  const uint32_t s_lds = lds0 + PF_S_OFF + (uint32_t)((wave & 3) * 128);
+  // scales: wave 4, lanes 0..31: 256 columns x 2 bytes of one group
+  const uint32_t s_voff = (lane < 32 && chunk0 * 64 + lane * 8 < p.N) ? (uint32_t)((chunk0 * 64 + lane * 8) * 2) : PF_OOB;
+  const uint32_t s_lds = lds0 + PF_S_OFF;
 
-  auto issue_a = [&](int ta, int h) {   // waves 4..7: half h (rows) of this wave's share of double stage ta: 4 pieces
+  auto issue_a = [&](int ta, int h) {   // half h (rows) of this wave's share of double stage ta: 2 pieces
     if constexpr (abl & 1) return;
     const bool live = 2 * ta < T_ST;
-    const uint32_t slot = a_lds + (uint32_t)((ta % PF_NA) * PF_A_BYTES + h * 4096);
+    const uint32_t slot = a_lds + (uint32_t)((ta % PF_NA) * PF_A_BYTES + h * 2048);
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int u = 0; u < 2; ++u)
       pf_dma16(rs_a, live ? a_voff[h][u] : PF_OOB, (uint32_t)(ta * 128), slot + (uint32_t)(u * 1024));
   };
   auto issue_c = [&](int t) {   // waves 0..3: stage t of the codes
@@ -228,30 +226,19 @@ __global__ __launch_bounds__(PF_NTHR, 2) void w4a16_prefill_kernel(const GemmPar
     pf_dma16(rs_b, t < T_ST ? c_voff : PF_OOB, (uint32_t)(((k_wg0 >> 5) + t) * n_chunks * 1024),
              c_lds + (uint32_t)((t % PF_NC) * PF_C_BYTES));
   };
-  auto issue_s = [&](int g) {   // waves 0..3: the chunk's scales of the workgroup's group g (8 lanes x 16 bytes: the other
-    if constexpr (abl & 2) return;   // lanes would zero-fill what lies behind)
-    if (lane < 8)
+  auto issue_s = [&](int g) {   // wave 4: scale row of the workgroup's group g (32 lanes x 16 bytes: the other lanes would
+    if constexpr (abl & 2) return;   // zero-fill what lies behind the slot)
+    if (lane < 32)
       pf_dma16(rs_s, 4 * g < T_ST ? s_voff : PF_OOB, (uint32_t)(((k_wg0 >> 7) + g) * p.N * 2), s_lds + (uint32_t)((g % PF_NS) * PF_S_BYTES));
   };
 
-  // expansion: wave w (0..3) turns native row chunk w -- 4 dwords per lane -- into 4 x 16 bytes of the expanded image;
-  // lane = (r = column within 16, g = k octet of the 32-k stage); dword j = column 64 w + 16 j + r
+  // expansion: wave w turns dwords j = 2 (w & 1), + 1 of native row chunk ce = w >> 1 into 2 x 16 bytes of the expanded image;
+  // lane = (r = column within 16, g = k octet of the 32-k stage); dword j = column 64 ce + 16 j + r
+  const int ce = wave >> 1, jp = wave & 1;
   const int er = lane & 15, eg = lane >> 4;
-  const uint32_t e_src = (uint32_t)(PF_C_OFF + (wave & 3) * 1024 + lane * 16);
-  const uint32_t e_col = (uint32_t)(64 * (wave & 3) + er);                                           // + 16 j
-  const uint32_t e_dst = (uint32_t)(PF_B_OFF) + e_col * 64 + (uint32_t)((eg ^ ((er >> 2) & 3)) << 4);   // + 1024 j
-  auto expand_stage = [&](int t) {   // codes of stage t -> expanded image slot t % PF_NB
-    if constexpr (abl & 4) return;
-    const uint4 x = *reinterpret_cast<const uint4*>(smem + e_src + (t % PF_NC) * PF_C_BYTES);
-    const uint16_t* sc = reinterpret_cast<const uint16_t*>(smem + PF_S_OFF + ((t >> 2) % PF_NS) * PF_S_BYTES) + e_col;
-    unsigned char* dst = smem + e_dst + (t % PF_NB) * PF_B_BYTES;
-    const uint32_t xs[4] = {x.x, x.y, x.z, x.w};
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float sj = T::to_float(sc[16 * j]);
-      *reinterpret_cast<u32x4_t*>(dst + j * 1024) = pf_expand<T>(xs[j], sj, -8.0f * sj);
-    }
-  };
+  const uint32_t e_src = (uint32_t)(PF_C_OFF + ce * 1024 + lane * 16 + 8 * jp);
+  const uint32_t e_col = (uint32_t)(64 * ce + 32 * jp + er);                                        // + 16 for the second dword
+  const uint32_t e_dst = (uint32_t)(PF_B_OFF) + e_col * 64 + (uint32_t)((eg ^ ((er >> 2) & 3)) << 4);   // + 1024 for the second dword
 
   f32x16_t acc[2][4];
 #pragma unroll
@@ -261,95 +248,134 @@ __global__ __launch_bounds__(PF_NTHR, 2) void w4a16_prefill_kernel(const GemmPar
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  auto ld_frags = [&](uint32_t a_base, uint32_t b_base, int ks, u32x4_t* af, u32x4_t* bf) {
+  // One stage of one wave, written out in issue order: 16 MFMAs, and in the shadow of each (a 32x32x16 MFMA holds the
+  // matrix pipe for 32 clocks, the wave may issue ~6 other instructions meanwhile) a slice of everything else -- the 6
+  // operand reads of the second k-step, the expansion of this wave's two dwords of stage t + 1 (2 x 23 VALU), its LDS
+  // reads and writes.  On this machine side work does NOT hide behind the MFMAs of the SIMD's other wave (measured,
+  // profiles/r04_prefill_v3_v6.txt: per SIMD, MFMA time and 4 clocks per other instruction add up), only behind the
+  // wave's own: `sched_barrier` fences pin the order written here.
+#define PF_FENCE() __builtin_amdgcn_sched_barrier(0)
+  auto rd = [&](uint32_t addr) -> u32x4_t {
     if constexpr (abl & 8) {
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        af[i] = u32x4_t{a_base, b_base, (uint32_t)ks, (uint32_t)i};
-        asm volatile("" : "+v"(af[i]));
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        bf[j] = u32x4_t{b_base, a_base, (uint32_t)j, (uint32_t)ks};
-        asm volatile("" : "+v"(bf[j]));
-      }
+      u32x4_t v = {addr, addr, addr, addr};
+      asm volatile("" : "+v"(v));
+      return v;
     } else {
-#pragma unroll
-      for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const u32x4_t*>(smem + ((a_base ^ (uint32_t)(ks << 5)) + i * 4096));
-#pragma unroll
-      for (int j = 0; j < 4; ++j) bf[j] = *reinterpret_cast<const u32x4_t*>(smem + ((b_base ^ (uint32_t)(ks << 5)) + j * 2048));
+      return *reinterpret_cast<const u32x4_t*>(smem + addr);
     }
   };
-  auto multiply_stage = [&](int t) {
-    const uint32_t a_base = ((uint32_t)(PF_A_OFF + ((t >> 1) % PF_NA) * PF_A_BYTES) + a_frag) ^ (uint32_t)((t & 1) << 6);
-    const uint32_t b_base = (uint32_t)(PF_B_OFF + (t % PF_NB) * PF_B_BYTES) + b_frag;
-    u32x4_t af[2][2], bf[2][4];
-    ld_frags(a_base, b_base, 0, af[0], bf[0]);
-    ld_frags(a_base, b_base, 1, af[1], bf[1]);
-    __builtin_amdgcn_sched_barrier(0);   // all 12 operand reads in flight before the first MFMA
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      if constexpr (abl & 16) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) asm volatile("" :: "v"(af[ks][i]));
-#pragma unroll
-        for (int j = 0; j < 4; ++j) asm volatile("" :: "v"(bf[ks][j]));
-      } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int i = 0; i < 2; ++i) acc[i][j] = pf_mfma<T>(af[ks][i], bf[ks][j], acc[i][j]);
-      }
+  auto mm = [&](f32x16_t& c, const u32x4_t& a, const u32x4_t& b) {
+    if constexpr (abl & 16) asm volatile("" :: "v"(a), "v"(b));
+    else c = pf_mfma<T>(a, b, c);
+  };
+  auto cvt8 = [&](uint32_t x, float* q) {   // native dword -> 8 codes as floats, k order
+    uint32_t e = x & 0x0f0f0f0fu;          // bytes: k0, k4, k1, k5
+    uint32_t o = (x >> 4) & 0x0f0f0f0fu;   // bytes: k2, k6, k3, k7
+    asm volatile("" : "+v"(e), "+v"(o));   // keep the byte form: one v_cvt_f32_ubyteN per code
+    q[0] = (float)(e & 0xffu); q[4] = (float)((e >> 8) & 0xffu); q[1] = (float)((e >> 16) & 0xffu); q[5] = (float)(e >> 24);
+    q[2] = (float)(o & 0xffu); q[6] = (float)((o >> 8) & 0xffu); q[3] = (float)((o >> 16) & 0xffu); q[7] = (float)(o >> 24);
+  };
+  auto stage = [&](int t, int s) {   // s = t & 3 as a compile-time constant of the unrolled loop
+    const uint32_t a0 = ((uint32_t)(PF_A_OFF + ((t >> 1) % PF_NA) * PF_A_BYTES) + a_frag) ^ (uint32_t)((t & 1) << 6);
+    const uint32_t b0 = (uint32_t)(PF_B_OFF + (t % PF_NB) * PF_B_BYTES) + b_frag;
+    const uint32_t a1 = a0 ^ 32u, b1 = b0 ^ 32u;
+    // expansion inputs of stage t + 1 and the first k-step's operands
+    uint2 x = make_uint2(0u, 0u);
+    uint32_t s0b = 0, s1b = 0;
+    if constexpr (!(abl & 4)) {
+      x = *reinterpret_cast<const uint2*>(smem + e_src + ((t + 1) % PF_NC) * PF_C_BYTES);
+      const uint16_t* sc = reinterpret_cast<const uint16_t*>(smem + PF_S_OFF + (((t + 1) >> 2) % PF_NS) * PF_S_BYTES) + e_col;
+      s0b = sc[0];
+      s1b = sc[16];
     }
+    unsigned char* dst = smem + e_dst + ((t + 1) % PF_NB) * PF_B_BYTES;
+    u32x4_t af0[2], bf0[4], af1[2], bf1[4];
+    af0[0] = rd(a0); bf0[0] = rd(b0); af0[1] = rd(a0 + 4096); bf0[1] = rd(b0 + 2048); bf0[2] = rd(b0 + 4096); bf0[3] = rd(b0 + 6144);
+    PF_FENCE();
+    float q[8], w[8];
+    float sA, cA;
+    // ---- k-step 0: operand reads of k-step 1, expansion of dword 0 ----
+    mm(acc[0][0], af0[0], bf0[0]); af1[0] = rd(a1); sA = T::to_float((uint16_t)s0b); cA = -8.0f * sA; PF_FENCE();
+    mm(acc[1][0], af0[1], bf0[0]); af1[1] = rd(a1 + 4096); if constexpr (!(abl & 4)) cvt8(x.x, q); PF_FENCE();
+    mm(acc[0][1], af0[0], bf0[1]); bf1[0] = rd(b1); PF_FENCE();
+    mm(acc[1][1], af0[1], bf0[1]); bf1[1] = rd(b1 + 2048);
+    if constexpr (!(abl & 4)) { w[0] = pf_fma(q[0], sA, cA); w[1] = pf_fma(q[1], sA, cA); w[2] = pf_fma(q[2], sA, cA); w[3] = pf_fma(q[3], sA, cA); }
+    PF_FENCE();
+    mm(acc[0][2], af0[0], bf0[2]); bf1[2] = rd(b1 + 4096);
+    if constexpr (!(abl & 4)) { w[4] = pf_fma(q[4], sA, cA); w[5] = pf_fma(q[5], sA, cA); w[6] = pf_fma(q[6], sA, cA); w[7] = pf_fma(q[7], sA, cA); }
+    PF_FENCE();
+    mm(acc[1][2], af0[1], bf0[2]); bf1[3] = rd(b1 + 6144);
+    u32x4_t wv;
+    if constexpr (!(abl & 4)) { wv[0] = T::pack2(w[0], w[1]); wv[1] = T::pack2(w[2], w[3]); wv[2] = T::pack2(w[4], w[5]); wv[3] = T::pack2(w[6], w[7]); }
+    PF_FENCE();
+    mm(acc[0][3], af0[0], bf0[3]);
+    if constexpr (!(abl & 4)) *reinterpret_cast<u32x4_t*>(dst) = wv;
+    PF_FENCE();
+    mm(acc[1][3], af0[1], bf0[3]); sA = T::to_float((uint16_t)s1b); cA = -8.0f * sA; PF_FENCE();
+    // ---- k-step 1: expansion of dword 1 ----
+    mm(acc[0][0], af1[0], bf1[0]); if constexpr (!(abl & 4)) cvt8(x.y, q); PF_FENCE();
+    mm(acc[1][0], af1[1], bf1[0]); issue_a((t >> 1) + PF_DA, s & 1); PF_FENCE();
+    mm(acc[0][1], af1[0], bf1[1]);
+    if constexpr (!(abl & 4)) { w[0] = pf_fma(q[0], sA, cA); w[1] = pf_fma(q[1], sA, cA); w[2] = pf_fma(q[2], sA, cA); w[3] = pf_fma(q[3], sA, cA); }
+    PF_FENCE();
+    mm(acc[1][1], af1[1], bf1[1]);
+    if constexpr (!(abl & 4)) { w[4] = pf_fma(q[4], sA, cA); w[5] = pf_fma(q[5], sA, cA); w[6] = pf_fma(q[6], sA, cA); w[7] = pf_fma(q[7], sA, cA); }
+    PF_FENCE();
+    mm(acc[0][2], af1[0], bf1[2]);
+    if constexpr (!(abl & 4)) { wv[0] = T::pack2(w[0], w[1]); wv[1] = T::pack2(w[2], w[3]); wv[2] = T::pack2(w[4], w[5]); wv[3] = T::pack2(w[6], w[7]); }
+    PF_FENCE();
+    mm(acc[1][2], af1[1], bf1[2]);
+    if constexpr (!(abl & 4)) *reinterpret_cast<u32x4_t*>(dst + 1024) = wv;
+    PF_FENCE();
+    mm(acc[0][3], af1[0], bf1[3]);
+    if (wave < 4) issue_c(t + PF_DC);
+    else if (wave == 4 && s == 0) issue_s((t >> 2) + 1);
+    PF_FENCE();
+    mm(acc[1][3], af1[1], bf1[3]); PF_FENCE();
+  };
+  auto expand_first = [&]() {   // stage 0, before the loop
+    if constexpr (abl & 4) return;
+    const uint2 x = *reinterpret_cast<const uint2*>(smem + e_src);
+    const uint16_t* sc = reinterpret_cast<const uint16_t*>(smem + PF_S_OFF) + e_col;
+    const float s0 = T::to_float(sc[0]), s1 = T::to_float(sc[16]);
+    *reinterpret_cast<u32x4_t*>(smem + e_dst) = pf_expand<T>(x.x, s0, -8.0f * s0);
+    *reinterpret_cast<u32x4_t*>(smem + e_dst + 1024) = pf_expand<T>(x.y, s1, -8.0f * s1);
   };
 
-  // ---- prologue: activations of stages 0 .. PF_DA - 1, codes of stages 0 .. PF_DC - 1, scales of groups 0, 1 ----
-  if (wave >= 4) {
+  // ---- prologue: activations of double stages 0 .. PF_DA - 1, codes of stages 0 .. PF_DC - 1, scale row of group 0 ----
 #pragma unroll
-    for (int ta = 0; ta < PF_DA; ++ta) {
-      issue_a(ta, 0);
-      issue_a(ta, 1);
-    }
-  } else {
-    issue_s(0);
-    issue_s(1);
+  for (int ta = 0; ta < PF_DA; ++ta) {
+    issue_a(ta, 0);
+    issue_a(ta, 1);
+  }
+  if (wave < 4) {
 #pragma unroll
     for (int t = 0; t < PF_DC; ++t) issue_c(t);
+  } else if (wave == 4) {
+    issue_s(0);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
-  if (wave < 4) expand_stage(0);
+  expand_first();
   pf_barrier();
 
-  // ---- main loop: iteration t multiplies stage t.  Waves 4..7 issue a half of the activations' double stage
-  // t / 2 + PF_DA after making sure that what they issued two iterations ago or earlier has landed; waves 0..3 issue
-  // codes(t + PF_DC) (and, when that stage opens a group, the group's scales), wait for THEIR OWN codes(t + 1) and expand
-  // stage t + 1 into the other half of the expanded ring. ----
+  // ---- main loop: iteration t multiplies stage t and expands stage t + 1; in the shadows of its later MFMAs a wave issues
+  // its half of the activations' double stage t / 2 + PF_DA, waves 0..3 codes(t + PF_DC), wave 4 at the first stage of a
+  // group the scale row of the next group.  At the bottom it makes sure that what it issued two iterations ago or earlier
+  // has landed (the pieces of this and the previous iteration may stay in flight), and the barrier publishes: at the end of
+  // an odd iteration the double stage (t + 1) / 2 of the activations; codes(t + 2) (issued at t - 2, expanded at t + 1);
+  // the expanded stage t + 1. ----
   W4P_T0();
   for (int t4 = 0; t4 < T_ST; t4 += 4) {
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       const int t = t4 + s;
-      if (wave >= 4) {
-        // what this wave issued two iterations ago or earlier has landed (the 4 pieces of the previous one may stay in
-        // flight): at the top of an odd iteration that completes double stage (t + 1) / 2, which the barrier publishes
-        pf_wait_vm<4>();
-        W4P_ACC(3);
-        issue_a((t >> 1) + PF_DA, s & 1);
-        W4P_ACC(0);
-      } else {
-        if (s == 3) issue_s((t + PF_DC) >> 2);   // stage t + PF_DC = 4 (g): first of its group
-        issue_c(t + PF_DC);
-        W4P_ACC(0);
-        // codes(t + 1) were issued PF_DC - 1 iterations ago: the PF_DC - 1 pieces since, and a scale piece among them
-        // when one of those iterations had s == 3 (always, with PF_DC - 1 = 4 iterations), may stay in flight
-        pf_wait_vm<PF_DC - 1 + 1>();
-        W4P_ACC(3);
-        expand_stage(t + 1);
-        W4P_ACC(2);
-      }
-      multiply_stage(t);
+      stage(t, s);
       W4P_ACC(1);
+      if (wave < 4) pf_wait_vm<6>();
+      else if (wave == 4 && s < 2) pf_wait_vm<5>();
+      else pf_wait_vm<4>();
+      W4P_ACC(3);
       pf_barrier();
       W4P_ACC(4);
     }
@@ -434,11 +460,15 @@ static int env_p(const char* name, int dflt) {
   return v ? atoi(v) : dflt;
 }
 
-// Plan: 256 x 128 tiles; split-K (whole 128-k groups per slice) where the tiles alone leave most of the 256 CUs idle.
-// A slice costs M * N * 8 bytes of slab traffic and a prologue: the estimate below weighs rounds of workgroups x k range
-// against both.
+// Plan: 256 x 256 tiles; split-K (whole 128-k groups per slice) where the tiles alone leave most of the 256 CUs idle.
+// NMV_W4P: 0 = never, 2 = every call of NMV_W4P_MIN_M (65) rows and more, 1 (default) = where the kernel was measured to win
+// over the tall kernel on the Marlin tensor (MI355X, tools/sweep_prefill.py, profiles/r04_prefill_sweep.txt): calls of at
+// least 256 rows with 160 tiles or more, or 128 tiles and K >= 8192 -- Llama-3-8B: gate_up from M = 512 (M = 512: 128 us
+// against 165-173), qkv / down from M = 2048 (112 against 144, 248 against 297), everything from M = 4096.  Few tiles
+// (o_proj, qkv and down at M = 512) need 4-8 slices whose fp32 slabs cost what the tile saves: those stay where they were.
 bool w4p_make_plan(int M, int N, int K, int64_t tickets_len, bool unsplit, W4PrefillPlan* out) {
-  if (!env_p("NMV_W4P", 1)) return false;
+  const int mode = env_p("NMV_W4P", 1);
+  if (mode <= 0) return false;
   if (M < env_p("NMV_W4P_MIN_M", 65) || N % 64 != 0 || K % 128 != 0) return false;
   if ((int64_t)M * K * 2 >= ((int64_t)1 << 31) || (((int64_t)K * N) >> 1) >= ((int64_t)1 << 31)) return false;
   W4PrefillPlan pl;
@@ -446,6 +476,7 @@ bool w4p_make_plan(int M, int N, int K, int64_t tickets_len, bool unsplit, W4Pre
   pl.n_blocks = (N + PF_BN - 1) / PF_BN;
   const int groups = K / 128;
   const int64_t tiles = (int64_t)pl.m_blocks * pl.n_blocks;
+  if (mode == 1 && (M < 256 || !(tiles >= 160 || (tiles >= 128 && K >= 8192)))) return false;
   const int forced = unsplit ? 0 : env_p("NMV_W4P_SPLITS", 0);
   const int max_splits = unsplit ? 1 : env_p("NMV_W4P_MAX_SPLITS", 8);
   int best = 0;
@@ -458,9 +489,9 @@ bool w4p_make_plan(int M, int N, int K, int64_t tickets_len, bool unsplit, W4Pre
       continue;
     }
     const int64_t rounds = (tiles * s + 255) / 256;
-    // k-steps of 64 per round, + 6 stages' worth of prologue / epilogue; slabs: 8 bytes per element and slice at 3 TB/s
-    // against ~0.45 us per stage
-    const double cost = (double)rounds * (K / 64 / s + 6) + (s > 1 ? (double)M * N * 8.0 * s / 3e12 / 0.45e-6 : 0.0);
+    // in us: a 32-k stage takes about 1, prologue + epilogue about 12 stages' worth; a slice writes and re-reads
+    // M * N * 4 bytes of slab at ~3 TB/s
+    const double cost = (double)rounds * (K / 32 / s + 12) + (s > 1 ? (double)M * N * 8.0 * s / 3e6 : 0.0);
     if (cost < best_cost) { best_cost = cost; best = s; }
   }
   if (best == 0) return false;

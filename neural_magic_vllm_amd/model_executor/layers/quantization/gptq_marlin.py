@@ -290,11 +290,15 @@ class GPTQMarlinLinearMethod(LinearMethodBase):
         """measured on MI355X (tools/bench_gemm.py --native, tools/sweep_ring.py): every decode-sized call takes the native
         tensor -- up to 16 rows csrc/w4a16_stream.hip's resident form (3-7 % over the Marlin form), 17..32 rows the ring
         kernel (csrc/w4a16_ring.hip: gate_up 18.5 us against 25.8 on the Marlin tensor at M = 32), 33..64 rows the ring on the
-        wide projection and the stream kernel's native form elsewhere.  The Marlin tensor serves prompt-sized calls and
-        the reference op."""
+        wide projection and the stream kernel's native form elsewhere.  Prompt-sized calls take it where the 256 x 256-tile
+        kernel (csrc/w4a16_prefill.hip) was measured to win -- 160 tiles and more: gate_up from 512 rows (M = 512: 128 us against
+        165-173 on the Marlin tensor), every projection from 4096 -- which the library decides
+        (nmv_w4_native_prefill_plan); the Marlin tensor serves the other prompt-sized calls and the reference op."""
         if getattr(layer, "qweight_native", None) is None:
             return False
-        return size_m <= cls.NATIVE_MAX_M
+        if size_m <= cls.NATIVE_MAX_M:
+            return True
+        return ops.w4_native_prefill_plan(size_m, layer.output_size_per_partition, layer.input_size_per_partition)
 
     # ---- deferred split-K: the GEMM leaves fp32 slabs, the following launch sums them ------------------------------
     def can_defer_reduce(self, layer: torch.nn.Module) -> bool:
@@ -364,7 +368,7 @@ class GPTQMarlinLinearMethod(LinearMethodBase):
         m, n, k = rows.shape[0], layer.output_size_per_partition, layer.input_size_per_partition
         # narrow fused launches (112 .. 223 chunks, resident form without split-K): the native tensor only wins up to a
         # few rows (M = 1: 15.5 vs 16.8 us; M = 16: 16.2 vs 12.2; M = 64: 19.0 vs 16.5)
-        if self._native(layer, m) and (n // 64 >= 224 or m <= 8):
+        if self._native(layer, m) and (m > self.NATIVE_MAX_M or n // 64 >= 224 or m <= 8):
             y = ops.w4_native_gemm(rows, layer.qweight_native, layer.scales_native, layer.workspace, m, n, k, mode=1)
         else:
             y = ops.gptq_marlin_gemm_silu_mul(rows, layer.qweight, layer.scales, layer.workspace, m, n, k)

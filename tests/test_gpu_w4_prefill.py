@@ -36,7 +36,7 @@ def native_gemm(a, q_w, s, k, n, dev, mode=0):
 @pytest.fixture()
 def prefill(monkeypatch):
     """every call of 65 rows and more takes the prefill kernel"""
-    monkeypatch.setenv("NMV_W4P", "1")
+    monkeypatch.setenv("NMV_W4P", "2")
     monkeypatch.setenv("NMV_W4P_MIN_M", "65")
     yield monkeypatch
 

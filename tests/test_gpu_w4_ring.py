@@ -41,6 +41,7 @@ def ring(monkeypatch):
     monkeypatch.setenv("NMV_W4R_MIN_M", "17")
     monkeypatch.setenv("NMV_W4R_MIN_WGS", "1")
     monkeypatch.setenv("NMV_W4R_PREFILL", "1")
+    monkeypatch.setenv("NMV_W4P", "0")   # prompt-sized calls: this kernel's 128-row variant, not csrc/w4a16_prefill.hip
     yield monkeypatch
     assert _lib.load().nmv_w4_ring_timeouts() == 0
 

@@ -116,7 +116,7 @@ def test_paged_attention_v1_v2_heuristic():
     assert PagedAttention.get_kv_cache_shape(10, 16, 8, 128) == (2, 10, 16 * 8 * 128)
 
 
-def test_fused_attention_launch_form_and_native_copy_ranges():
+def test_fused_attention_launch_form_and_native_copy_ranges(monkeypatch):
     """this repo's own choices beside the reference's rules: the fused rope + cache + attention launch stays
     unpartitioned up to 896 tokens (measured on MI355X) and follows the reference's rule beyond; the
     MFMA-native copy of the 4-bit weights serves every decode-sized call, up to 64 rows"""
@@ -128,9 +128,17 @@ def test_fused_attention_launch_form_and_native_copy_ranges():
                                (897, 17, 32): True, (4096, 1, 32): False, (8193, 64, 32): False}.items():
         assert PagedAttention.use_v1_fused(msl, ns, nh) == exp, (msl, ns, nh)
         assert PagedAttention.use_v1_fused(msl, ns, nh) or not PagedAttention.use_v1(msl, ns, nh)   # never stricter
-    with_copy, without = SimpleNamespace(qweight_native=object()), SimpleNamespace()
-    assert [m for m in (1, 16, 17, 32, 33, 64, 65, 512) if LM._native(with_copy, m)] == [1, 16, 17, 32, 33, 64]
-    assert not any(LM._native(without, m) for m in (1, 16, 64))
+    # prompt-sized calls: where the library's 256 x 256-tile kernel takes them (160 tiles and more: Llama-3-8B gate_up from 512
+    # rows, the narrow projections only at thousands of rows) -- the Marlin tensor keeps the rest
+    def layer(n, k, **kw):
+        return SimpleNamespace(output_size_per_partition=n, input_size_per_partition=k, **kw)
+    gate_up, o_proj = layer(28672, 4096, qweight_native=object()), layer(4096, 4096, qweight_native=object())
+    assert [m for m in (1, 16, 17, 32, 33, 64, 65, 255, 256, 512, 4096) if LM._native(gate_up, m)] == \
+        [1, 16, 17, 32, 33, 64, 512, 4096]
+    assert [m for m in (1, 16, 17, 32, 33, 64, 65, 512, 2048, 4096) if LM._native(o_proj, m)] == [1, 16, 17, 32, 33, 64, 4096]
+    monkeypatch.setenv("NMV_W4P", "0")
+    assert not LM._native(gate_up, 512)
+    assert not any(LM._native(layer(28672, 4096), m) for m in (1, 16, 64, 512))
 
 
 def test_deferred_reduce_admission_asks_the_method_with_the_layers_group_count(monkeypatch):

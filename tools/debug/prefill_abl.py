@@ -17,7 +17,7 @@ if __name__ == "__main__":
     m = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
     if os.environ.get("PF_ABL_CHILD"):
         dev = torch.device("cuda:0")
-        os.environ["NMV_W4P"] = "1"
+        os.environ["NMV_W4P"] = "2"
         os.environ["NMV_W4P_SPLITS"] = "1"
         out = []
         for name in shapes.split(","):

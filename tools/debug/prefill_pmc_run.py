@@ -11,7 +11,7 @@ from neural_magic_vllm_amd import _custom_ops as ops  # noqa: E402
 k, n, m = (int(x) for x in (sys.argv[1:4] if len(sys.argv) > 3 else (4096, 28672, 2048)))
 mode = int(sys.argv[4]) if len(sys.argv) > 4 else 1
 dev = torch.device("cuda:0")
-os.environ["NMV_W4P"] = "1"
+os.environ["NMV_W4P"] = "2"
 os.environ["NMV_W4P_SPLITS"] = "1"
 g = torch.Generator(device=dev).manual_seed(0)
 ws = [torch.randint(-2**31, 2**31 - 1, (k // 8 * n,), dtype=torch.int32, device=dev, generator=g) for _ in range(4)]

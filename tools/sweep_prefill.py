@@ -29,7 +29,7 @@ if __name__ == "__main__":
             os.environ["NMV_W4P"] = "0"
             us, _ = bench(name, k, n, m, dev, iters=args.iters, native=None, mode=md)
             res = [f"tall(marlin) {us:.1f} ({flop / us / 1e9:.2f} PF/s)"]
-            os.environ["NMV_W4P"] = "1"
+            os.environ["NMV_W4P"] = "2"
             os.environ["NMV_W4P_MIN_M"] = "65"
             for sp in [int(x) for x in args.splits.split(",")]:
                 if sp and ((k // 128) % sp or (md == 1 and sp > 1)):
