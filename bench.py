@@ -76,6 +76,15 @@ def gemm_roofline(runner, batch, dev, groups=32):
           for m in mods]
 
     as_model = [False]  # second pass: the launches exactly as the model issues them
+    marlin_cache = {}
+
+    def marlin_like(li, j, k, n):
+        key = (li, j)
+        if key not in marlin_cache:
+            g = torch.Generator(device=dev).manual_seed(1000 + 7 * li + j)
+            marlin_cache[key] = (torch.randint(-2**31, 2**31 - 1, (k // 16, n * 2), dtype=torch.int32, device=dev, generator=g),
+                                 (torch.rand((k // 128, n), device=dev, generator=g) * 0.01).to(runner.dtype))
+        return marlin_cache[key]
 
     def run(li, only=None):
         for j, (m, x) in enumerate(zip(mods_of(layers[li % len(layers)]), xs)):
@@ -87,9 +96,10 @@ def gemm_roofline(runner, batch, dev, groups=32):
             elif as_model[0] and j != 2 and m.quant_method.can_defer(m, batch):
                 m.quant_method.apply_partial(m, x)
             else:
-                # gate_up weights may be column-interleaved for the silu epilogue: same bytes, same time
-                ops.gptq_marlin_gemm(x, m.qweight, m.scales, m.g_idx, m.g_idx_sort_indices,
-                                     m.workspace, 4, batch, n, k, m.is_k_full)
+                # the reference op on a Marlin tensor of the same shape (random codes: same bytes, same time -- the layers
+                # themselves keep only the native tensor)
+                qw, sc = marlin_like(li % len(layers), j, k, n)
+                ops.gptq_marlin_gemm(x, qw, sc, m.g_idx, m.g_idx_sort_indices, m.workspace, 4, batch, n, k, m.is_k_full)
 
     def timed(only):
         run(0, only)
@@ -116,7 +126,7 @@ def gemm_roofline(runner, batch, dev, groups=32):
     algs = []
     for m in mods:
         k, n = m.input_size_per_partition, m.output_size_per_partition
-        algs.append(k * n // 2 + m.scales.numel() * 2 + 2 * batch * k + 2 * batch * n)
+        algs.append(k * n // 2 + (k // 128) * n * 2 + 2 * batch * k + 2 * batch * n)
     alg = sum(algs)
     us = timed(None)
     per = {nm: {"us": round(timed(j), 2), "algorithmic_bytes": algs[j]} for j, nm in enumerate(names)}
@@ -364,10 +374,10 @@ def weights_fit(arch, quant: str, world: int, batch: int, max_context: int, kv_d
     kvh = max(arch.num_key_value_heads // world, 1)
     qkv = h * (arch.num_attention_heads // world + 2 * kvh) * arch.head_dim
     per_layer = qkv + (arch.num_attention_heads // world) * arch.head_dim * h + 3 * h * inter // world
-    # w4a16: the Marlin tensor + group-128 scales, and (unless NMV_W4_NATIVE=0) the MFMA-native copy of the codes that
-    # serves the decode-sized calls (GPTQMarlinLinearMethod, + 0.5 byte per weight + a second scale tensor)
-    native = os.environ.get("NMV_W4_NATIVE", "1") != "0"
-    bytes_per_w = {"w4a16": (0.5 + 2 / 128) * (2 if native else 1), "w8a8": 1.0, "bf16": 2.0}[quant]
+    # w4a16: ONE tensor of codes + group-128 scales (GPTQMarlinLinearMethod keeps the MFMA-native tensor only); two when
+    # NMV_W4_KEEP_MARLIN=1 keeps the Marlin tensor beside it
+    both = os.environ.get("NMV_W4_NATIVE", "1") != "0" and os.environ.get("NMV_W4_KEEP_MARLIN", "0") == "1"
+    bytes_per_w = {"w4a16": (0.5 + 2 / 128) * (2 if both else 1), "w8a8": 1.0, "bf16": 2.0}[quant]
     weights = layers * per_layer * bytes_per_w + 2 * (arch.vocab_size // world) * h * 2 + (2 * layers + 1) * h * 2
     kv = 2 * layers * batch * max_context * kvh * arch.head_dim * (1 if kv_dtype.startswith("fp8") else 2)
     total = weights + kv
@@ -523,7 +533,8 @@ def main():
         out["sustained"] = {"steps": long_steps, "timed_region_s": round(d2, 4),
                             "value": round(args.batch * long_steps / d2, 1),
                             "ms_per_step": round(d2 / long_steps * 1e3, 4)}
-    out["config"]["weights_gb_per_rank"] = round(fit["weights_gb"], 2)
+    # measured after the steps (derived tensors built, released ones gone), not the estimate `fit` was made from
+    out["config"]["weights_gb_per_rank"] = round(runner.resident_weight_bytes() / 1e9, 2)
     if world > 1:
         # what a reader needs to audit a multi-GPU line from its own content: how many ranks took part, which
         # device each one bound, whether its P2P start-up self-test passed, and the collective library's version

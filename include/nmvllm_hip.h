@@ -436,9 +436,10 @@ int64_t nmv_get_max_shared_memory_per_block_device_attribute(int64_t device_id);
 int nmv_w4_native_repack(const int32_t* qweight, const int32_t* perm, int32_t* out, int size_k, int size_n,
                          void* stream);
 int nmv_w4_native_gemm_splits(int size_m, int size_n, int size_k, int num_groups);
-/* 1 when a call of these sizes on the native tensor (group 128) is served by the prompt-sized kernel (csrc/w4a16_prefill.hip:
- * 256 x 256 tiles, codes expanded once per workgroup) under the library's default rule (NMV_W4P), else 0: the caller then
- * keeps the Marlin tensor and nmv_gptq_marlin_gemm for that call. */
+/* For a caller that holds BOTH tensors of a weight: 1 when nmv_w4_native_gemm (its prompt-sized kernels, csrc/w4a16_prefill.hip:
+ * 256 x 256 or 128 x 128 tiles, codes expanded once per workgroup) was measured ahead of nmv_gptq_marlin_gemm on the Marlin
+ * tensor for a call of these sizes, else 0.  nmv_w4_native_gemm itself serves every row count: a caller that keeps only
+ * the native tensor (GPTQMarlinLinearMethod by default) never asks. */
 int nmv_w4_native_prefill_plan(int size_m, int size_n, int size_k);
 int nmv_w4_native_gemm(void* c, const void* a, const int32_t* b_native, const void* b_scales, int32_t* workspace,
                        int64_t workspace_len, void* scratch, int64_t scratch_bytes, int size_m, int size_n,

@@ -215,12 +215,15 @@ bool w4r_make_plan(int M, int N, int K, int64_t tickets_len, bool unsplit, W4Rin
 int w4r_launch(const W4RingPlan& pl, const GemmParams& p, bool f16, hipStream_t s);
 // ---- w4a16_prefill.hip: 256 x 128 tiles, codes expanded once per workgroup (native tensor, prompt-sized calls) ----
 struct W4PrefillPlan {
+  int small;                    // 0: 256 x 256 tiles, 1: 128 x 128 tiles
   int splits, k_per_wg, n_blocks, m_blocks;
   int lds_bytes;
 };
 // false: outside the kernel's domain
 bool w4p_make_plan(int M, int N, int K, int64_t tickets_len, bool unsplit, W4PrefillPlan* out);
 int w4p_launch(const W4PrefillPlan& pl, const GemmParams& p, bool f16, hipStream_t s);
+// true: measured ahead of the tall kernel on a Marlin tensor of the same weights (what a caller that holds both should do)
+bool w4p_wins(int M, int N, int K);
 // the > 64 KiB dynamic-LDS opt-in (hipFuncSetAttribute) holds for the device that is current when it is made: one bit
 // per device ordinal in *mask; true = this device has not opted in yet (ordinals past 63: always true)
 bool lds_optin_needed(unsigned long long* mask, int device);

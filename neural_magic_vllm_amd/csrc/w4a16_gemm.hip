@@ -1770,8 +1770,7 @@ extern "C" int nmv_w4_native_gemm_splits(int size_m, int size_n, int size_k, int
 }
 
 extern "C" int nmv_w4_native_prefill_plan(int size_m, int size_n, int size_k) {
-  W4PrefillPlan pp;
-  return (size_m > 0 && size_n > 0 && size_k > 0 && w4p_make_plan(size_m, size_n, size_k, INT64_MAX, true, &pp)) ? 1 : 0;
+  return (size_m > 0 && size_n > 0 && size_k > 0 && w4p_wins(size_m, size_n, size_k)) ? 1 : 0;
 }
 
 extern "C" int nmv_w4_native_gemm(void* c, const void* a, const int32_t* b_native, const void* b_scales,

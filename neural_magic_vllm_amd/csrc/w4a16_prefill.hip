@@ -454,57 +454,339 @@ __global__ __launch_bounds__(PF_NTHR, 2) void w4a16_prefill_kernel(const GemmPar
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// The small tile: 128 rows x 128 columns, 64-k stages -- for calls whose 256 x 256 tiles would be too few to fill 256 CUs
+// without slicing K (Llama-3-8B at 512 rows: qkv 48 tiles, o_proj and down 32; an fp32 slab costs what the large tile
+// saves).  Same discipline as above: 8 alike waves (4 x 2, each 32 rows x 64 columns = 2 accumulator tiles, 8 MFMAs per
+// stage), every wave expands 2 dwords per stage, moves 2 activation pieces (8 rows x 128 B: full lines), waves 0..3 a
+// piece of codes, wave 4 the scale row of a group every other stage; all of it in the shadows of the wave's own MFMAs, one
+// wait and one barrier per stage.  Twice the side work per MFMA of the large tile (8 other instructions per MFMA):
+// expected and measured slower per flop, faster per call where it avoids the slabs.
+// LDS: A 4 x 16 KiB, expanded B 2 x 16 KiB ([column][64 k], slot = chunk ^ ((column >> 1) & 7)), codes 6 x 4 KiB, scales
+// 3 x 256 B = 121 KiB.
+namespace {
+constexpr int PS_BM = 128, PS_BN = 128, PS_BK = 64;
+constexpr int PS_NA = 4, PS_NB = 2, PS_NC = 6, PS_NS = 3;
+constexpr int PS_DA = 3, PS_DC = 4;
+constexpr int PS_A_BYTES = PS_BM * 128, PS_B_BYTES = PS_BN * 128, PS_C_BYTES = 4096, PS_S_BYTES = 256;
+constexpr int PS_A_OFF = 0;
+constexpr int PS_B_OFF = PS_A_OFF + PS_NA * PS_A_BYTES;
+constexpr int PS_C_OFF = PS_B_OFF + PS_NB * PS_B_BYTES;
+constexpr int PS_S_OFF = PS_C_OFF + PS_NC * PS_C_BYTES;
+constexpr int PS_T_OFF = PS_S_OFF + PS_NS * PS_S_BYTES;
+constexpr int PS_LDS = PS_T_OFF + 64;
+static_assert(PF_NTHR * 16 <= PS_B_OFF, "the split-K reduction's scratch fits the dead activation ring");
+static_assert(PS_NA > PS_DA && PS_NC > PS_DC + 1, "a slot is refilled only after the stage that read it");
+}  // namespace
+
+// 1-D grid as above with 128-row blocks and 128-column blocks; p.k_per_wg: a multiple of 128.
+template <typename T>
+__global__ __launch_bounds__(PF_NTHR, 2) void w4a16_prefill_small_kernel(const GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n_chunks = p.N >> 6;
+  const int n_blocks = (n_chunks + 1) >> 1, m_blocks = (p.M + PS_BM - 1) / PS_BM;
+  const int G = m_blocks >= 8 ? 8 : m_blocks >= 4 ? 4 : m_blocks >= 2 ? 2 : 1, XQ = 8 / G;
+  const int units = n_blocks * p.splits, units_pad = (units + XQ - 1) / XQ * XQ;
+  const int L = blockIdx.x, per_round = G * units_pad;
+  const int rnd = L / per_round, rem = L - rnd * per_round;
+  const int xcd = rem & 7;
+  const int unit = (rem >> 3) * XQ + xcd / G;
+  const int m_block = rnd * G + xcd % G;
+  if (m_block >= m_blocks || unit >= units) return;     // uniform: padding of the last round / of the unit count
+  const int n_block = unit % n_blocks, split = unit / n_blocks;
+  const int chunk0 = n_block * 2;
+  const int m0 = m_block * PS_BM;
+  const int k_wg0 = split * p.k_per_wg;
+  const int T_ST = min(p.k_per_wg, p.K - k_wg0) >> 6;     // 64-k stages of this workgroup (uniform, even)
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+
+  // consumer identity: 32-row block wm, 64-column block (= chunk of the strip) wn; lane = (row / column n5, k half kh)
+  const int wm = wave & 3, wn = wave >> 2;
+  const int n5 = lane & 31, kh = lane >> 5;
+  // both images: row * 128 + ((2 ks + kh) ^ ((row >> 1) & 7)) * 16 = base ^ (ks << 5), ks = 0..3
+  const uint32_t frag_sw = (uint32_t)((kh ^ ((n5 >> 1) & 7)) << 4);
+  const uint32_t a_frag = (uint32_t)((32 * wm + n5) * 128) + frag_sw;
+  const uint32_t b_frag = (uint32_t)((64 * wn + n5) * 128) + frag_sw;      // + 4096 for the second 32-column tile
+
+  const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint16_t*>(p.a), 0, (int)((int64_t)p.M * p.K * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint4*>(p.b), 0, (int)(((int64_t)p.K * p.N) >> 1), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_s = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint16_t*>(p.s), 0, (int)((int64_t)(p.K >> 7) * p.N * 2), 0x00020000);
+  // activations: a stage is 16 pieces of 8 rows x 128 B; wave w moves rows 16 w .. 16 w + 15; lane = (row i >> 3, slot i & 7),
+  // source chunk = slot ^ ((row >> 1) & 7) with (row >> 1) & 7 = (4 u + (i >> 4)) & 7 for piece u
+  uint32_t a_voff[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int row = m0 + 16 * wave + 8 * u + (lane >> 3);
+    const uint32_t chunk = (uint32_t)((lane & 7) ^ ((4 * u + (lane >> 4)) & 7));
+    a_voff[u] = row < p.M ? (uint32_t)(((int64_t)row * p.K + k_wg0) * 2) + chunk * 16 : PF_OOB;
+  }
+  const uint32_t a_lds = lds0 + PS_A_OFF + (uint32_t)(wave * 2048);
+  // codes: waves 0..3, wave w the native row (k-step 2 t + (w >> 1), chunk chunk0 + (w & 1)) = 1 KiB
+  const uint32_t c_voff = (wave < 4 && chunk0 + (wave & 1) < n_chunks) ? (uint32_t)((chunk0 + (wave & 1)) * 1024 + lane * 16) : PF_OOB;
+  const uint32_t c_lds = lds0 + PS_C_OFF + (uint32_t)((wave & 3) * 1024);
+  // scales: wave 4, lanes 0..15: 128 columns x 2 bytes of one group
+  const uint32_t s_voff = (lane < 16 && chunk0 * 64 + lane * 8 < p.N) ? (uint32_t)((chunk0 * 64 + lane * 8) * 2) : PF_OOB;
+  const uint32_t s_lds = lds0 + PS_S_OFF;
+
+  auto issue_a = [&](int t) {
+    const bool live = t < T_ST;
+    const uint32_t slot = a_lds + (uint32_t)((t % PS_NA) * PS_A_BYTES);
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+      pf_dma16(rs_a, live ? a_voff[u] : PF_OOB, (uint32_t)(t * 128), slot + (uint32_t)(u * 1024));
+  };
+  auto issue_c = [&](int t) {   // waves 0..3
+    pf_dma16(rs_b, t < T_ST ? c_voff : PF_OOB, (uint32_t)(((k_wg0 >> 5) + 2 * t + ((wave >> 1) & 1)) * n_chunks * 1024),
+             c_lds + (uint32_t)((t % PS_NC) * PS_C_BYTES));
+  };
+  auto issue_s = [&](int g) {   // wave 4: scale row of the workgroup's group g (16 lanes x 16 bytes)
+    if (lane < 16)
+      pf_dma16(rs_s, 2 * g < T_ST ? s_voff : PF_OOB, (uint32_t)(((k_wg0 >> 7) + g) * p.N * 2), s_lds + (uint32_t)((g % PS_NS) * PS_S_BYTES));
+  };
+
+  // expansion: wave w turns dwords j = 2 (w & 1), + 1 of the stage's native row w >> 1 (k-step kk = w >> 2, chunk ch = (w >> 1) & 1);
+  // lane = (r = column within 16, g = k octet of the 32-k step); dword j = column 64 ch + 16 j + r, chunk of the row 4 kk + g
+  const int kk = wave >> 2, ch = (wave >> 1) & 1, jp = wave & 1;
+  const int er = lane & 15, eg = lane >> 4;
+  const uint32_t e_src = (uint32_t)(PS_C_OFF + (wave >> 1) * 1024 + lane * 16 + 8 * jp);
+  const uint32_t e_col = (uint32_t)(64 * ch + 32 * jp + er);                                            // + 16 for the second dword
+  const uint32_t e_dst = (uint32_t)(PS_B_OFF) + e_col * 128 + (uint32_t)(((4 * kk + eg) ^ ((er >> 1) & 7)) << 4);   // + 2048
+
+  f32x16_t acc[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  auto rd = [&](uint32_t addr) -> u32x4_t { return *reinterpret_cast<const u32x4_t*>(smem + addr); };
+  auto cvt8 = [&](uint32_t x, float* q) {   // native dword -> 8 codes as floats, k order
+    uint32_t e = x & 0x0f0f0f0fu;          // bytes: k0, k4, k1, k5
+    uint32_t o = (x >> 4) & 0x0f0f0f0fu;   // bytes: k2, k6, k3, k7
+    asm volatile("" : "+v"(e), "+v"(o));
+    q[0] = (float)(e & 0xffu); q[4] = (float)((e >> 8) & 0xffu); q[1] = (float)((e >> 16) & 0xffu); q[5] = (float)(e >> 24);
+    q[2] = (float)(o & 0xffu); q[6] = (float)((o >> 8) & 0xffu); q[3] = (float)((o >> 16) & 0xffu); q[7] = (float)(o >> 24);
+  };
+  auto stage = [&](int t, int s) {   // s = t & 1 as a compile-time constant of the unrolled loop
+    const uint32_t a0 = (uint32_t)(PS_A_OFF + (t % PS_NA) * PS_A_BYTES) + a_frag;
+    const uint32_t b0 = (uint32_t)(PS_B_OFF + (t % PS_NB) * PS_B_BYTES) + b_frag;
+    const uint2 x = *reinterpret_cast<const uint2*>(smem + e_src + ((t + 1) % PS_NC) * PS_C_BYTES);
+    const uint16_t* sc = reinterpret_cast<const uint16_t*>(smem + PS_S_OFF + (((t + 1) >> 1) % PS_NS) * PS_S_BYTES) + e_col;
+    const uint32_t s0b = sc[0], s1b = sc[16];
+    unsigned char* dst = smem + e_dst + ((t + 1) % PS_NB) * PS_B_BYTES;
+    u32x4_t af[4], bf[4][2];
+    af[0] = rd(a0); bf[0][0] = rd(b0); bf[0][1] = rd(b0 + 4096);
+    PF_FENCE();
+    float q[8], w[8], sA, cA;
+    u32x4_t wv;
+    // M0
+    acc[0] = pf_mfma<T>(af[0], bf[0][0], acc[0]);
+    af[1] = rd(a0 ^ 32u); bf[1][0] = rd(b0 ^ 32u); bf[1][1] = rd((b0 ^ 32u) + 4096);
+    sA = T::to_float((uint16_t)s0b); cA = -8.0f * sA;
+    PF_FENCE();
+    // M1
+    acc[1] = pf_mfma<T>(af[0], bf[0][1], acc[1]);
+    cvt8(x.x, q);
+    PF_FENCE();
+    // M2
+    acc[0] = pf_mfma<T>(af[1], bf[1][0], acc[0]);
+    af[2] = rd(a0 ^ 64u); bf[2][0] = rd(b0 ^ 64u); bf[2][1] = rd((b0 ^ 64u) + 4096);
+    w[0] = pf_fma(q[0], sA, cA); w[1] = pf_fma(q[1], sA, cA); w[2] = pf_fma(q[2], sA, cA); w[3] = pf_fma(q[3], sA, cA);
+    issue_a(t + PS_DA);
+    PF_FENCE();
+    // M3
+    acc[1] = pf_mfma<T>(af[1], bf[1][1], acc[1]);
+    w[4] = pf_fma(q[4], sA, cA); w[5] = pf_fma(q[5], sA, cA); w[6] = pf_fma(q[6], sA, cA); w[7] = pf_fma(q[7], sA, cA);
+    wv[0] = T::pack2(w[0], w[1]); wv[1] = T::pack2(w[2], w[3]); wv[2] = T::pack2(w[4], w[5]); wv[3] = T::pack2(w[6], w[7]);
+    PF_FENCE();
+    // M4
+    acc[0] = pf_mfma<T>(af[2], bf[2][0], acc[0]);
+    af[3] = rd(a0 ^ 96u); bf[3][0] = rd(b0 ^ 96u); bf[3][1] = rd((b0 ^ 96u) + 4096);
+    *reinterpret_cast<u32x4_t*>(dst) = wv;
+    sA = T::to_float((uint16_t)s1b); cA = -8.0f * sA;
+    PF_FENCE();
+    // M5
+    acc[1] = pf_mfma<T>(af[2], bf[2][1], acc[1]);
+    cvt8(x.y, q);
+    PF_FENCE();
+    // M6
+    acc[0] = pf_mfma<T>(af[3], bf[3][0], acc[0]);
+    w[0] = pf_fma(q[0], sA, cA); w[1] = pf_fma(q[1], sA, cA); w[2] = pf_fma(q[2], sA, cA); w[3] = pf_fma(q[3], sA, cA);
+    w[4] = pf_fma(q[4], sA, cA); w[5] = pf_fma(q[5], sA, cA); w[6] = pf_fma(q[6], sA, cA); w[7] = pf_fma(q[7], sA, cA);
+    if (wave < 4) issue_c(t + PS_DC);
+    else if (wave == 4 && s == 0) issue_s((t >> 1) + 2);
+    PF_FENCE();
+    // M7
+    acc[1] = pf_mfma<T>(af[3], bf[3][1], acc[1]);
+    wv[0] = T::pack2(w[0], w[1]); wv[1] = T::pack2(w[2], w[3]); wv[2] = T::pack2(w[4], w[5]); wv[3] = T::pack2(w[6], w[7]);
+    *reinterpret_cast<u32x4_t*>(dst + 2048) = wv;
+    PF_FENCE();
+  };
+
+  // ---- prologue: activations of stages 0 .. PS_DA - 1, codes of stages 0 .. PS_DC - 1, scale rows of groups 0, 1 ----
+#pragma unroll
+  for (int t = 0; t < PS_DA; ++t) issue_a(t);
+  if (wave < 4) {
+#pragma unroll
+    for (int t = 0; t < PS_DC; ++t) issue_c(t);
+  } else if (wave == 4) {
+    issue_s(0);
+    issue_s(1);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  {   // stage 0 expanded before the loop
+    const uint2 x = *reinterpret_cast<const uint2*>(smem + e_src);
+    const uint16_t* sc = reinterpret_cast<const uint16_t*>(smem + PS_S_OFF) + e_col;
+    const float s0 = T::to_float(sc[0]), s1 = T::to_float(sc[16]);
+    *reinterpret_cast<u32x4_t*>(smem + e_dst) = pf_expand<T>(x.x, s0, -8.0f * s0);
+    *reinterpret_cast<u32x4_t*>(smem + e_dst + 2048) = pf_expand<T>(x.y, s1, -8.0f * s1);
+  }
+  pf_barrier();
+
+  // ---- main loop: as above; at the bottom of iteration t what the wave issued at t - 2 or earlier has landed (the pieces of
+  // this and the previous iteration may stay in flight); the barrier publishes A(t + 1) (issued at t - 2), codes(t + 2)
+  // (issued at t - 2, expanded at t + 1) and the expanded stage t + 1.  Wave 4 issues a scale row at even t. ----
+  for (int t2 = 0; t2 < T_ST; t2 += 2) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      stage(t2 + s, s);
+      if (wave < 4) pf_wait_vm<6>();
+      else if (wave == 4) pf_wait_vm<5>();
+      else pf_wait_vm<4>();
+      pf_barrier();
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the tail's zero-filled pieces
+
+  // ---- epilogue.  D[m][n] of a 32x32 tile: column = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) ----
+  const int n_wave = chunk0 * 64 + 64 * wn;
+  const int row_l = m0 + 32 * wm + 4 * kh;
+  if (p.splits == 1 && p.epi != 2) {
+    if (p.epi) {
+      if (n_wave >= p.N) return;
+      uint16_t* cp = p.c + (n_wave >> 1) + n5;
+      const int ldc = p.N >> 1;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = row_l + (r & 3) + 8 * (r >> 2);
+        if (row >= p.M) continue;
+        const float gb = round_trip<T>(acc[0][r]), ub = round_trip<T>(acc[1][r]);
+        cp[(int64_t)row * ldc] = T::from_float(round_trip<T>(gb / (1.0f + expf(-gb))) * ub);
+      }
+      return;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n_wave + 32 * j + n5;
+      if (col >= p.N) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = row_l + (r & 3) + 8 * (r >> 2);
+        if (row < p.M) p.c[(int64_t)row * p.N + col] = T::from_float(acc[j][r]);
+      }
+    }
+    return;
+  }
+  const int64_t slab_bytes = (int64_t)p.splits * p.M * p.N * 4;
+  __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p.slab, 0, (int)slab_bytes, 0x00020000);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int col = n_wave + 32 * j + n5;
+    if (col >= p.N) continue;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = row_l + (r & 3) + 8 * (r >> 2);
+      if (row >= p.M) continue;
+      const int off = (int)((((int64_t)split * p.M + row) * p.N + col) * 4);
+      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[j][r]), rs, off, 0, 16);
+    }
+  }
+  if (p.epi == 2) return;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  int* ticket_s = reinterpret_cast<int*>(smem + PS_T_OFF);
+  __syncthreads();
+  const int tile = m_block * n_blocks + n_block;
+  if (tid == 0)
+    *ticket_s = __hip_atomic_fetch_add(p.tickets + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  if (*ticket_s != p.splits - 1) return;
+  if (tid == 0) __hip_atomic_store(p.tickets + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  splitk_reduce_tile<T, PF_NTHR>(p, rs, m0, PS_BM, chunk0 * 64, PS_BN, reinterpret_cast<f32x4_t*>(smem));
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Host side.
 static int env_p(const char* name, int dflt) {
   const char* v = getenv(name);
   return v ? atoi(v) : dflt;
 }
 
-// Plan: 256 x 256 tiles; split-K (whole 128-k groups per slice) where the tiles alone leave most of the 256 CUs idle.
-// NMV_W4P: 0 = never, 2 = every call of NMV_W4P_MIN_M (65) rows and more, 1 (default) = where the kernel was measured to win
-// over the tall kernel on the Marlin tensor (MI355X, tools/sweep_prefill.py, profiles/r04_prefill_sweep.txt): calls of at
-// least 256 rows with 160 tiles or more, or 128 tiles and K >= 8192 -- Llama-3-8B: gate_up from M = 512 (M = 512: 128 us
-// against 165-173), qkv / down from M = 2048 (112 against 144, 248 against 297), everything from M = 4096.  Few tiles
-// (o_proj, qkv and down at M = 512) need 4-8 slices whose fp32 slabs cost what the tile saves: those stay where they were.
+// Plan: the tile (256 x 256, or 128 x 128 where the large one would leave most of the 256 CUs idle or need fp32 slabs to
+// fill them) and the split-K count (whole 128-k groups per slice) by an estimate from the measured main-loop rates.
+// NMV_W4P=0 turns the kernels off (native calls of more than 64 rows then take w4n_gemm_kernel's 64-row tiles);
+// NMV_W4P_TILE / NMV_W4P_SPLITS force a choice (tests, tools/sweep_prefill.py).
+// Against the tall kernel on a Marlin tensor (MI355X, profiles/r04_prefill_sweep.txt, Llama-3-8B): level at 65 .. 256
+// rows except o_proj (+ 3-7 us), ahead from 512 rows on the wide projection (gate_up M = 512: 128 us against 165-173)
+// and from 1024 on the others (M = 1024: o 52 against 66, down 127 against 152; M = 2048: qkv 112 against 144).
+// w4p_wins(): the calls a holder of BOTH tensors should send here (nmv_w4_native_prefill_plan).
+bool w4p_wins(int M, int N, int K) {
+  if (env_p("NMV_W4P", 1) <= 0 || M < 512 || N % 64 != 0 || K % 128 != 0) return false;
+  const int64_t big_tiles = (int64_t)((M + PF_BM - 1) / PF_BM) * ((N + PF_BN - 1) / PF_BN);
+  return big_tiles >= 64;
+}
+
 bool w4p_make_plan(int M, int N, int K, int64_t tickets_len, bool unsplit, W4PrefillPlan* out) {
   const int mode = env_p("NMV_W4P", 1);
   if (mode <= 0) return false;
   if (M < env_p("NMV_W4P_MIN_M", 65) || N % 64 != 0 || K % 128 != 0) return false;
   if ((int64_t)M * K * 2 >= ((int64_t)1 << 31) || (((int64_t)K * N) >> 1) >= ((int64_t)1 << 31)) return false;
-  W4PrefillPlan pl;
-  pl.m_blocks = (M + PF_BM - 1) / PF_BM;
-  pl.n_blocks = (N + PF_BN - 1) / PF_BN;
   const int groups = K / 128;
-  const int64_t tiles = (int64_t)pl.m_blocks * pl.n_blocks;
-  if (mode == 1 && (M < 256 || !(tiles >= 160 || (tiles >= 128 && K >= 8192)))) return false;
   const int forced = unsplit ? 0 : env_p("NMV_W4P_SPLITS", 0);
   const int max_splits = unsplit ? 1 : env_p("NMV_W4P_MAX_SPLITS", 8);
-  int best = 0;
+  const int tile_env = env_p("NMV_W4P_TILE", 0);   // 0: by the estimate below, 1: 128 x 128, 2: 256 x 256
+  W4PrefillPlan best_pl;
   double best_cost = 1e30;
-  for (int s = 1; s <= groups && s <= max_splits; ++s) {
-    if (groups % s != 0) continue;
-    if (s > 1 && tiles > tickets_len) break;
-    if (forced) {
-      if (s == forced) { best = s; break; }
-      continue;
+  bool found = false;
+  for (int small = 0; small < 2; ++small) {
+    if (tile_env && (tile_env == 1) != (small == 1)) continue;
+    const int bm = small ? PS_BM : PF_BM, bn = small ? PS_BN : PF_BN;
+    W4PrefillPlan pl;
+    pl.small = small;
+    pl.m_blocks = (M + bm - 1) / bm;
+    pl.n_blocks = (N + bn - 1) / bn;
+    const int64_t tiles = (int64_t)pl.m_blocks * pl.n_blocks;
+    for (int s = 1; s <= groups && s <= max_splits; ++s) {
+      if (groups % s != 0) continue;
+      if (s > 1 && tiles > tickets_len) break;
+      if (forced && s != forced) continue;
+      const int64_t rounds = (tiles * s + 255) / 256;
+      // in us: PF_US_BIG / PF_US_SMALL per 64 k of a tile (measured main-loop rates), prologue + epilogue; a slice writes
+      // and re-reads M * N * 4 bytes of slab at ~3 TB/s
+      const double per64 = small ? 0.72 : 1.86, fixed = small ? 6.0 : 12.0;
+      const double cost = (double)rounds * (K / 64 / s * per64 + fixed) + (s > 1 ? (double)M * N * 8.0 * s / 3e6 : 0.0);
+      if (cost < best_cost) {
+        best_cost = cost;
+        best_pl = pl;
+        best_pl.splits = s;
+        found = true;
+      }
     }
-    const int64_t rounds = (tiles * s + 255) / 256;
-    // in us: a 32-k stage takes about 1, prologue + epilogue about 12 stages' worth; a slice writes and re-reads
-    // M * N * 4 bytes of slab at ~3 TB/s
-    const double cost = (double)rounds * (K / 32 / s + 12) + (s > 1 ? (double)M * N * 8.0 * s / 3e6 : 0.0);
-    if (cost < best_cost) { best_cost = cost; best = s; }
   }
-  if (best == 0) return false;
-  pl.splits = best;
-  pl.k_per_wg = (groups / best) * 128;
-  pl.lds_bytes = PF_LDS;
-  *out = pl;
+  if (!found) return false;
+  best_pl.k_per_wg = (groups / best_pl.splits) * 128;
+  best_pl.lds_bytes = best_pl.small ? PS_LDS : PF_LDS;
+  *out = best_pl;
   return true;
 }
 
-template <typename T>
+template <typename T, bool SMALL>
 static int w4p_launch_one(const W4PrefillPlan& pl, const GemmParams& p, hipStream_t s) {
-  auto kern = w4a16_prefill_kernel<T>;
+  auto kern = SMALL ? w4a16_prefill_small_kernel<T> : w4a16_prefill_kernel<T>;
   static unsigned long long optin = 0;   // per instantiation
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return -2;
@@ -513,7 +795,7 @@ static int w4p_launch_one(const W4PrefillPlan& pl, const GemmParams& p, hipStrea
         hipSuccess)
       return -2;
   }
-  // the kernel's XCD-aware decomposition of the 1-D grid (see its head): rounds of G row blocks x padded units
+  // the kernels' XCD-aware decomposition of the 1-D grid (see their heads): rounds of G row blocks x padded units
   const int G = pl.m_blocks >= 8 ? 8 : pl.m_blocks >= 4 ? 4 : pl.m_blocks >= 2 ? 2 : 1, XQ = 8 / G;
   const int units = pl.n_blocks * pl.splits, units_pad = (units + XQ - 1) / XQ * XQ;
   const int rounds = (pl.m_blocks + G - 1) / G;
@@ -524,7 +806,8 @@ static int w4p_launch_one(const W4PrefillPlan& pl, const GemmParams& p, hipStrea
 
 int w4p_launch(const W4PrefillPlan& pl, const GemmParams& p, bool f16, hipStream_t s) {
   if (!p.native) return -1;
-  return f16 ? w4p_launch_one<F16>(pl, p, s) : w4p_launch_one<BF16>(pl, p, s);
+  if (pl.small) return f16 ? w4p_launch_one<F16, true>(pl, p, s) : w4p_launch_one<BF16, true>(pl, p, s);
+  return f16 ? w4p_launch_one<F16, false>(pl, p, s) : w4p_launch_one<BF16, false>(pl, p, s);
 }
 
 }  // namespace nmv

@@ -228,15 +228,24 @@ class GPTQMarlinLinearMethod(LinearMethodBase):
             _overwrite(layer.g_idx_sort_indices, order)
         else:
             layer.g_idx, layer.g_idx_sort_indices = _empty_index(dev), _empty_index(dev)
-        if self.native_eligible(layer):   # built from the same GPTQ words, beside the Marlin tensor
+        if self.native_eligible(layer):   # built from the same GPTQ words
             # buffers, not plain attributes: module.to() / memory accounting see them; persistent=False keeps them out of
-            # the state dict (they are derived data).  + 0.5 byte per weight and a second scale tensor, resident for good
+            # the state dict (they are derived data)
             for name, t in (("qweight_native", ops.w4_native_repack(layer.qweight.data, None, k, n)),
                             ("scales_native", layer.scales.data.clone())):     # natural [groups, N]
                 if name in layer._buffers:
                     layer._buffers[name] = t
                 else:
                     layer.register_buffer(name, t, persistent=False)
+            if os.environ.get("NMV_W4_KEEP_MARLIN", "0") != "1":
+                # ONE weight tensor: nmv_w4_native_gemm serves every row count (decode: stream / ring kernels; prompt-sized:
+                # csrc/w4a16_prefill.hip), so the Marlin tensor and its permuted scales are not built and the GPTQ words
+                # are released -- 0.5 byte per weight on the rank instead of 1.  (NMV_W4_KEEP_MARLIN=1 keeps both and
+                # sends each call where it was measured faster: 3-6 % on 65 .. 256-row calls.)
+                layer.qweight.data = torch.empty(0, dtype=layer.qweight.dtype, device=dev)
+                layer.scales.data = torch.empty(0, dtype=layer.scales.dtype, device=dev)
+                layer.marlin_dropped = True
+                return
             extra = layer.qweight_native.numel() * 4 + layer.scales_native.numel() * layer.scales_native.element_size()
             type(self).native_extra_bytes = getattr(type(self), "native_extra_bytes", 0) + extra
         _overwrite(layer.qweight, ops.gptq_marlin_repack(layer.qweight, layer.g_idx_sort_indices, k, n, cfg.weight_bits))
@@ -290,13 +299,14 @@ class GPTQMarlinLinearMethod(LinearMethodBase):
         """measured on MI355X (tools/bench_gemm.py --native, tools/sweep_ring.py): every decode-sized call takes the native
         tensor -- up to 16 rows csrc/w4a16_stream.hip's resident form (3-7 % over the Marlin form), 17..32 rows the ring
         kernel (csrc/w4a16_ring.hip: gate_up 18.5 us against 25.8 on the Marlin tensor at M = 32), 33..64 rows the ring on the
-        wide projection and the stream kernel's native form elsewhere.  Prompt-sized calls take it where the 256 x 256-tile
-        kernel (csrc/w4a16_prefill.hip) was measured to win -- 160 tiles and more: gate_up from 512 rows (M = 512: 128 us against
-        165-173 on the Marlin tensor), every projection from 4096 -- which the library decides
-        (nmv_w4_native_prefill_plan); the Marlin tensor serves the other prompt-sized calls and the reference op."""
+        wide projection and the stream kernel's native form elsewhere.  Prompt-sized calls: csrc/w4a16_prefill.hip (256 x 256
+        or 128 x 128 tiles; gate_up M = 512: 128 us against 165-173 on the Marlin tensor, level with it on the narrow
+        projections).  By default the layer keeps ONLY the native tensor and every call comes here; with
+        NMV_W4_KEEP_MARLIN=1 it keeps both and a prompt-sized call goes where it was measured faster
+        (nmv_w4_native_prefill_plan)."""
         if getattr(layer, "qweight_native", None) is None:
             return False
-        if size_m <= cls.NATIVE_MAX_M:
+        if size_m <= cls.NATIVE_MAX_M or getattr(layer, "marlin_dropped", False):
             return True
         return ops.w4_native_prefill_plan(size_m, layer.output_size_per_partition, layer.input_size_per_partition)
 

@@ -488,8 +488,26 @@ class DecodeRunner:
     def weight_bytes_per_step(self) -> int:
         """bytes of parameters one decode step has to stream (this rank)"""
         total = 0
-        for n, p in self.model.named_parameters():
-            if p.device.type == "meta" or n.endswith("g_idx") or "embed_tokens" in n:
+        for n, p in list(self.model.named_parameters()) + list(self.model.named_buffers()):
+            if p.device.type == "meta" or n.endswith("g_idx") or "embed_tokens" in n or n.endswith("workspace"):
                 continue
+            if (n.endswith(".qweight") or n.endswith(".scales")) and (n.rsplit(".", 1)[0] + ".qweight_native") in self._native_names():
+                continue   # a decode step reads the native copy of this layer, not a Marlin tensor kept beside it
+            total += p.numel() * p.element_size()
+        return total
+
+    def _native_names(self):
+        got = getattr(self, "_native_name_set", None)
+        if got is None:
+            got = self._native_name_set = {n for n, _ in self.model.named_buffers() if n.endswith("_native")}
+        return got
+
+    def resident_weight_bytes(self) -> int:
+        """bytes of parameters and buffers this rank holds (after the first call: derived tensors built, released ones gone)"""
+        seen, total = set(), 0
+        for n, p in list(self.model.named_parameters()) + list(self.model.named_buffers()):
+            if p.device.type == "meta" or p.data_ptr() in seen:
+                continue
+            seen.add(p.data_ptr())
             total += p.numel() * p.element_size()
         return total

@@ -33,11 +33,12 @@ def native_gemm(a, q_w, s, k, n, dev, mode=0):
     return out
 
 
-@pytest.fixture()
-def prefill(monkeypatch):
-    """every call of 65 rows and more takes the prefill kernel"""
+@pytest.fixture(params=["tile128", "tile256"])
+def prefill(monkeypatch, request):
+    """every call of 65 rows and more takes the prefill kernel, with its 128 x 128 or its 256 x 256 tile"""
     monkeypatch.setenv("NMV_W4P", "2")
     monkeypatch.setenv("NMV_W4P_MIN_M", "65")
+    monkeypatch.setenv("NMV_W4P_TILE", "1" if request.param == "tile128" else "2")
     yield monkeypatch
 
 

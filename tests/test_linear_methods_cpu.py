@@ -128,14 +128,17 @@ def test_fused_attention_launch_form_and_native_copy_ranges(monkeypatch):
                                (897, 17, 32): True, (4096, 1, 32): False, (8193, 64, 32): False}.items():
         assert PagedAttention.use_v1_fused(msl, ns, nh) == exp, (msl, ns, nh)
         assert PagedAttention.use_v1_fused(msl, ns, nh) or not PagedAttention.use_v1(msl, ns, nh)   # never stricter
-    # prompt-sized calls: where the library's 256 x 256-tile kernel takes them (160 tiles and more: Llama-3-8B gate_up from 512
-    # rows, the narrow projections only at thousands of rows) -- the Marlin tensor keeps the rest
+    # a layer that keeps BOTH tensors (NMV_W4_KEEP_MARLIN=1) sends a prompt-sized call to the native tensor where its
+    # kernels were measured ahead (512 rows and 64 large tiles or more: Llama-3-8B gate_up from 512 rows, the narrow
+    # projections from 1024 / 2048); a layer that dropped the Marlin tensor (the default) sends everything there
     def layer(n, k, **kw):
         return SimpleNamespace(output_size_per_partition=n, input_size_per_partition=k, **kw)
     gate_up, o_proj = layer(28672, 4096, qweight_native=object()), layer(4096, 4096, qweight_native=object())
     assert [m for m in (1, 16, 17, 32, 33, 64, 65, 255, 256, 512, 4096) if LM._native(gate_up, m)] == \
         [1, 16, 17, 32, 33, 64, 512, 4096]
-    assert [m for m in (1, 16, 17, 32, 33, 64, 65, 512, 2048, 4096) if LM._native(o_proj, m)] == [1, 16, 17, 32, 33, 64, 4096]
+    assert [m for m in (1, 16, 17, 32, 33, 64, 65, 512, 2048, 4096) if LM._native(o_proj, m)] == [1, 16, 17, 32, 33, 64, 2048, 4096]
+    only = layer(4096, 4096, qweight_native=object(), marlin_dropped=True)
+    assert all(LM._native(only, m) for m in (1, 64, 65, 100, 512, 100000))
     monkeypatch.setenv("NMV_W4P", "0")
     assert not LM._native(gate_up, 512)
     assert not any(LM._native(layer(28672, 4096), m) for m in (1, 16, 64, 512))

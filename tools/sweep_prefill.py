@@ -18,6 +18,7 @@ if __name__ == "__main__":
     ap.add_argument("--ms", default="512,2048")
     ap.add_argument("--shapes", default="qkv,o,gate_up,down")
     ap.add_argument("--splits", default="0,1,2,4,8", help="0 = the plan's own choice")
+    ap.add_argument("--tiles", default="1,2", help="NMV_W4P_TILE: 0 = the plan's choice, 1 = 128 x 128, 2 = 256 x 256")
     ap.add_argument("--iters", type=int, default=8)
     args = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -31,10 +32,12 @@ if __name__ == "__main__":
             res = [f"tall(marlin) {us:.1f} ({flop / us / 1e9:.2f} PF/s)"]
             os.environ["NMV_W4P"] = "2"
             os.environ["NMV_W4P_MIN_M"] = "65"
-            for sp in [int(x) for x in args.splits.split(",")]:
-                if sp and ((k // 128) % sp or (md == 1 and sp > 1)):
-                    continue
-                os.environ["NMV_W4P_SPLITS"] = str(sp)
-                us, _ = bench(name, k, n, m, dev, iters=args.iters, native=md)
-                res.append(f"prefill/sp{sp} {us:.1f} ({flop / us / 1e9:.2f})")
+            for tile in [int(x) for x in args.tiles.split(",")]:
+                os.environ["NMV_W4P_TILE"] = str(tile)
+                for sp in [int(x) for x in args.splits.split(",")]:
+                    if sp and ((k // 128) % sp or (md == 1 and sp > 1)):
+                        continue
+                    os.environ["NMV_W4P_SPLITS"] = str(sp)
+                    us, _ = bench(name, k, n, m, dev, iters=args.iters, native=md)
+                    res.append(f"{('auto', 't128', 't256')[tile]}/sp{sp} {us:.1f} ({flop / us / 1e9:.2f})")
             print(f"{name:8s} M={m:4d} mode={md} | " + "  ".join(res), flush=True)
