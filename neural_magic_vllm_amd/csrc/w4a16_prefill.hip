@@ -765,10 +765,11 @@ bool w4p_make_plan(int M, int N, int K, int64_t tickets_len, bool unsplit, W4Pre
       if (s > 1 && tiles > tickets_len) break;
       if (forced && s != forced) continue;
       const int64_t rounds = (tiles * s + 255) / 256;
-      // in us: PF_US_BIG / PF_US_SMALL per 64 k of a tile (measured main-loop rates), prologue + epilogue; a slice writes
-      // and re-reads M * N * 4 bytes of slab at ~3 TB/s
-      const double per64 = small ? 0.72 : 1.86, fixed = small ? 6.0 : 12.0;
-      const double cost = (double)rounds * (K / 64 / s * per64 + fixed) + (s > 1 ? (double)M * N * 8.0 * s / 3e6 : 0.0);
+      // in us, from the measured main-loop rates (profiles/r04_prefill_sweep.txt): 1.86 / 0.72 per 64 k of a large / small
+      // tile, ~5 of prologue + epilogue; a slice's fp32 slab is written in the shadow of the next tiles but read back
+      // (by the last workgroup of the tile, or by the consumer launch in deferred mode) at ~4 TB/s
+      const double per64 = small ? 0.72 : 1.86;
+      const double cost = (double)rounds * (K / 64 / s * per64 + 5.0) + (s > 1 ? (double)M * N * 4.0 * s / 4e6 + 2.0 : 0.0);
       if (cost < best_cost) {
         best_cost = cost;
         best_pl = pl;

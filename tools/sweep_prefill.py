@@ -19,13 +19,14 @@ if __name__ == "__main__":
     ap.add_argument("--shapes", default="qkv,o,gate_up,down")
     ap.add_argument("--splits", default="0,1,2,4,8", help="0 = the plan's own choice")
     ap.add_argument("--tiles", default="1,2", help="NMV_W4P_TILE: 0 = the plan's choice, 1 = 128 x 128, 2 = 256 x 256")
+    ap.add_argument("--deferred", action="store_true", help="qkv / o / down as the model issues them: fp32 slabs only (mode 2)")
     ap.add_argument("--iters", type=int, default=8)
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     for name in args.shapes.split(","):
         k, n = SHAPES[name]
         for m in [int(x) for x in args.ms.split(",")]:
-            md = 1 if name.startswith("gate_up") else 0   # the step issues gate_up with the silu epilogue
+            md = 1 if name.startswith("gate_up") else (2 if args.deferred else 0)   # the step issues gate_up with the silu epilogue
             flop = 2.0 * m * k * n
             os.environ["NMV_W4P"] = "0"
             us, _ = bench(name, k, n, m, dev, iters=args.iters, native=None, mode=md)
