@@ -200,6 +200,164 @@ __global__ __launch_bounds__(MM_THREADS) void scaled_mm_kernel(const MMParams p)
 }
 
 
+// ---------------------------------------------------------------------------------------------
+// 17 .. 64 rows: the waves of a workgroup split N, not K, and share the activations through LDS.
+// In scaled_mm_kernel every wave re-reads its own k slice of all rows from L2: a workgroup covers 16 NT columns, so the
+// activation bytes through the CU's vector-memory path are 64 / (16 NT) x the weight bytes (o_proj at M = 64: 4 x) -- and
+// that path, not HBM, is what the kernel runs at (weights + activations = 5.2 TB/s on every projection, the same number
+// as the weights alone at M = 1).  Here a workgroup covers 64 NT columns (wave w: tiles w NT .. w NT + NT - 1)
+// and one k range; a 256-byte chunk of all its rows is staged ONCE (global -> registers one chunk ahead -> LDS, XOR
+// swizzled on 16-byte slots so that the 16 lanes of an MFMA operand read hit 16 different slots), read as MFMA operands
+// by the four waves, while each wave streams its own weights straight into operand registers one chunk ahead.
+// Activation bytes / weight bytes = 16 MT / (64 NT): 1/4 at NT = 4.  No cross-wave reduction; split-K as above.
+template <typename T, bool FP8, int MT, int NT>
+__global__ __launch_bounds__(MM_THREADS) void scaled_mm_wide_kernel(const MMParams p) {
+  constexpr int D = NT == 4 ? 2 : 3;   // chunks of weights in registers: the one being multiplied and D - 1 on their way
+  using A = Acc<FP8>;
+  constexpr int ROWS = 16 * MT, STAGE = ROWS * 256, XPT = ROWS / 16;   // 16-byte pieces per thread and chunk
+  __shared__ __attribute__((aligned(16))) uint8_t act[2][STAGE];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 15, g = lane >> 4;
+  const int n0 = blockIdx.x * (64 * NT) + wave * (16 * NT);
+  const int m0 = blockIdx.y * ROWS;
+  const int k_begin = blockIdx.z * p.k_per_split;
+  const int nch = (min(p.K, k_begin + p.k_per_split) - k_begin) >> 8;   // 256-byte chunks (K % 256 == 0, k_per_split too)
+
+  const uint8_t* wp[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) wp[j] = p.bt + (int64_t)min(n0 + j * 16 + r, p.N - 1) * p.ldb + k_begin + g * 16;
+  // staging: thread -> (row tid >> 4 + 16 u, slot tid & 15): 16 threads move one row's 256 bytes
+  const int s_row = tid >> 4, s_c = tid & 15;
+  const uint8_t* ap[XPT];
+  bool a_ok[XPT];
+#pragma unroll
+  for (int u = 0; u < XPT; ++u) {
+    const int m = m0 + s_row + 16 * u;
+    a_ok[u] = m < p.M;
+    ap[u] = p.a + (int64_t)min(m, p.M - 1) * p.lda + k_begin + s_c * 16;
+  }
+  const int s_dst = s_row * 256 + ((s_c ^ (s_row & 15)) << 4);    // + u * 4096
+  const int x_src = r * 256;                                       // + t * 4096 + (((4 ks + g) ^ r) << 4)
+
+  typename A::type acc[NT][MT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int t = 0; t < MT; ++t) acc[j][t] = A::zero();
+
+  uint4 xs[XPT], w[D][4][NT];
+#pragma unroll
+  for (int u = 0; u < XPT; ++u) {
+    xs[u] = a_ok[u] ? ld16(ap[u]) : make_uint4(0, 0, 0, 0);
+    *reinterpret_cast<uint4*>(act[0] + s_dst + u * 4096) = xs[u];
+  }
+#pragma unroll
+  for (int d = 0; d < D - 1; ++d)
+    if (d < nch) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) w[d][ks][j] = ld16(wp[j] + d * 256 + ks * 64);
+    }
+  __syncthreads();
+
+  for (int c0 = 0; c0 < nch; c0 += D) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      const int c = c0 + d;
+      if (c >= nch) break;   // uniform
+      // requested before this chunk is multiplied: the next chunk's activations, the weights D - 1 chunks ahead (into the
+      // ring slot the previous chunk left)
+      const bool more = c + 1 < nch;
+      if (more) {
+#pragma unroll
+        for (int u = 0; u < XPT; ++u) xs[u] = a_ok[u] ? ld16(ap[u] + (int64_t)(c + 1) * 256) : make_uint4(0, 0, 0, 0);
+      }
+      if (c + D - 1 < nch) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) w[(d + D - 1) % D][ks][j] = ld16(wp[j] + (int64_t)(c + D - 1) * 256 + ks * 64);
+      }
+      const uint8_t* buf = act[c & 1] + x_src;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        uint4 x[MT];
+#pragma unroll
+        for (int t = 0; t < MT; ++t) x[t] = *reinterpret_cast<const uint4*>(buf + t * 4096 + (((4 * ks + g) ^ r) << 4));
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+          for (int t = 0; t < MT; ++t) acc[j][t] = A::mma(w[d][ks][j], x[t], acc[j][t]);
+      }
+      if (more) {
+#pragma unroll
+        for (int u = 0; u < XPT; ++u) *reinterpret_cast<uint4*>(act[(c + 1) & 1] + s_dst + u * 4096) = xs[u];
+      }
+      __syncthreads();   // the other buffer is complete, and every wave is done with this one
+    }
+  }
+
+  // epilogue (scaled_mm_kernel's, without the cross-wave sum): D[row = n_idx][col = m]; lane (m = l & 15, g) holds n = 16 j + 4 g + i
+  using elem_t = decltype(acc[0][0][0] + acc[0][0][0]);
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int nb = n0 + j * 16 + 4 * g;
+    if (nb >= p.N) continue;
+    if (p.splits > 1) {  // raw partial sums; scaled_mm_reduce_kernel finishes
+      elem_t* slab = reinterpret_cast<elem_t*>(p.slab) + (int64_t)blockIdx.z * p.M * p.N;
+#pragma unroll
+      for (int t = 0; t < MT; ++t) {
+        const int m = m0 + t * 16 + r;
+        if (m >= p.M) continue;
+        elem_t* dst = slab + (int64_t)m * p.N + nb;
+        if (nb + 3 < p.N && (p.N & 3) == 0) {
+          *reinterpret_cast<typename A::type*>(dst) = acc[j][t];
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (nb + i < p.N) dst[i] = acc[j][t][i];
+        }
+      }
+      continue;
+    }
+    float bs[4], bv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int n = min(nb + i, p.N - 1);
+      bs[i] = p.b_scales[p.b_per_col ? n : 0];
+      bv[i] = p.bias ? T::to_float(reinterpret_cast<const uint16_t*>(p.bias)[n]) : 0.f;
+    }
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+      const int m = m0 + t * 16 + r;
+      if (m >= p.M) continue;
+      const float as = p.a_scales[p.a_per_row ? m : 0];
+      float o[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        // multiplies(a_scales, multiplies(b_scales, acc)); with a bias the outer node is multiply_add
+        // (scaled_mm_c2x.cu:117-131, :157-171) -- no "+ 0" without one: it would turn -0 into +0
+        const float tmp = bs[i] * (float)acc[j][t][i];
+        o[i] = p.bias ? fmaf(as, tmp, bv[i]) : as * tmp;
+      }
+      uint16_t* dst = reinterpret_cast<uint16_t*>(p.out) + (int64_t)m * p.ldc + nb;
+      if (nb + 3 < p.N && (reinterpret_cast<uintptr_t>(dst) & 7) == 0) {
+        uint2 pk;
+        pk.x = T::pack2(o[0], o[1]);
+        pk.y = T::pack2(o[2], o[3]);
+        *reinterpret_cast<uint2*>(dst) = pk;
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (nb + i < p.N) dst[i] = T::from_float(o[i]);
+      }
+    }
+  }
+}
+
+
 // sums the split-K slabs in the accumulator's own type, then the same epilogue arithmetic
 template <typename T, bool FP8>
 __global__ __launch_bounds__(256) void scaled_mm_reduce_kernel(const MMParams p) {
@@ -227,6 +385,7 @@ __global__ __launch_bounds__(256) void scaled_mm_reduce_kernel(const MMParams p)
 struct MMPlan {
   int mt, nt, un;  // tiles per wave, 64-byte k-steps in flight
   int splits, k_per_split;
+  int wide;        // scaled_mm_wide_kernel (waves split N, activations through LDS)
 };
 
 static int env_int(const char* name, int dflt) {
@@ -236,7 +395,38 @@ static int env_int(const char* name, int dflt) {
 
 // Tile and split-K choice, by shape (Llama-3-8B projections measured on MI355X).
 static MMPlan mm_plan(int M, int N, int K, int64_t scratch_bytes) {
-  MMPlan pl{1, 1, 4, 1, K};
+  MMPlan pl{1, 1, 4, 1, K, 0};
+  // 17 .. 64 rows, K in whole 256-byte chunks: the wide kernel where it was measured ahead (MI355X, int8, us,
+  // tools/sweep_w8a8_wide.py -> profiles/r04_w8a8_wide.txt): many columns -- gate_up M = 64: 36.4 against 44.9 with two
+  // column tiles per wave, unsliced (M = 32: 32.1 against 37.1 in two slices) -- and a long K with few columns -- down:
+  // 23.6 against 29.0 with one tile per wave in eight slices.  A short K with few columns (qkv, o_proj) has too few
+  // workgroups per byte either way and stays with the K-splitting kernel.  NMV_MM_WIDE=0 / NMV_MM_NT / NMV_MM_SPLITS force.
+  if (M > 16 && M <= 64 && K % 256 == 0 && env_int("NMV_MM_WIDE", 1)) {
+    const int forced_nt = env_int("NMV_MM_NT", 0), forced_s = env_int("NMV_MM_SPLITS", 0);
+    int nt = 0, sp = 1;
+    if (N >= 16384) {
+      nt = 2;
+      sp = M <= 32 ? 2 : 1;
+    } else if (K >= 8192 && N <= 8192) {
+      nt = 1;
+      sp = 8;
+    }
+    if (forced_nt || forced_s) {   // development / tests: any valid form of the wide kernel
+      nt = (forced_nt == 1 || forced_nt == 2 || forced_nt == 4) ? forced_nt : (nt ? nt : 2);
+      sp = forced_s > 0 ? forced_s : sp;
+      if ((sp & (sp - 1)) != 0 || sp > 8) nt = 0;
+    }
+    while (nt && sp > 1 && ((K / 256) % sp != 0 || K / sp < 512 || (int64_t)sp * M * N * 4 > scratch_bytes)) sp >>= 1;
+    if (nt) {
+      pl.wide = 1;
+      pl.mt = M <= 32 ? 2 : 4;
+      pl.nt = nt;
+      pl.un = 4;
+      pl.splits = sp;
+      pl.k_per_split = K / sp;
+      return pl;
+    }
+  }
   const int n16 = (N + 15) / 16;
   int splits = 1;
   if (M <= 32) {
@@ -285,6 +475,25 @@ template <typename T, bool FP8>
 static void launch_mm(MMParams p, const MMPlan& pl, hipStream_t s) {
   p.splits = pl.splits;
   p.k_per_split = pl.k_per_split;
+  if (pl.wide) {
+#define MMW_CASE(MT_, NT_)                                                                            \
+    if (pl.mt == MT_ && pl.nt == NT_) {                                                               \
+      dim3 grid((p.N + 64 * NT_ - 1) / (64 * NT_), (p.M + 16 * MT_ - 1) / (16 * MT_), pl.splits);     \
+      hipLaunchKernelGGL((scaled_mm_wide_kernel<T, FP8, MT_, NT_>), grid, dim3(MM_THREADS), 0, s, p); \
+    }
+    MMW_CASE(2, 1)
+    MMW_CASE(2, 2)
+    MMW_CASE(2, 4)
+    MMW_CASE(4, 1)
+    MMW_CASE(4, 2)
+    MMW_CASE(4, 4)
+#undef MMW_CASE
+    if (pl.splits > 1) {
+      const int64_t items = (int64_t)p.M * ((p.N + 3) / 4);
+      hipLaunchKernelGGL((scaled_mm_reduce_kernel<T, FP8>), dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, p);
+    }
+    return;
+  }
 #define MM_CASE(MT_, NT_, UN_)                                                                       \
   if (pl.mt == MT_ && pl.nt == NT_) {                                                                \
     dim3 grid((p.N + 16 * NT_ - 1) / (16 * NT_), (p.M + 16 * MT_ - 1) / (16 * MT_), pl.splits);      \

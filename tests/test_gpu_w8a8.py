@@ -187,6 +187,37 @@ def test_cutlass_scaled_mm_split_k_and_tiles(gpu_device, monkeypatch, kind, m, n
             assert torch.allclose(o.float(), ref.float(), rtol=2**-7 * 1.01, atol=2e-2)
 
 
+@pytest.mark.parametrize("kind", ["int8", "fp8"])
+@pytest.mark.parametrize("m,n,k", [(17, 256, 512), (33, 208, 1024), (48, 6144, 4096), (64, 4096, 14336), (64, 1088, 2048)])
+def test_cutlass_scaled_mm_wide_kernel(gpu_device, monkeypatch, kind, m, n, k):
+    """17 .. 64 rows, K in whole 256-byte chunks: the waves of a workgroup split N and share the activations through LDS
+    (scaled_mm_wide_kernel).  Against the K-splitting kernel (NMV_MM_WIDE=0): bit-identical for int8 (exact int32
+    sums), fp32 summation order apart for fp8; every column-tile count and slice count; ragged N; the oracle."""
+    from neural_magic_vllm_amd import _custom_ops as ops
+    g = torch.Generator().manual_seed(5)
+    conv = to_int8 if kind == "int8" else to_fp8
+    a = conv(torch.randn((m, k), generator=g) * (20 if kind == "int8" else 1))
+    bt = conv(torch.randn((n, k), generator=g) * (20 if kind == "int8" else 1))
+    sa = torch.rand((m, 1), generator=g) / 100
+    sb = torch.rand((1, n), generator=g) / 100
+    bias = torch.randn((n, ), generator=g).to(torch.bfloat16)
+    d = gpu_device
+    args = (a.to(d), bt.to(d).t(), sa.to(d), sb.to(d), torch.bfloat16, bias.to(d))
+    monkeypatch.setenv("NMV_MM_WIDE", "0")
+    old = ops.cutlass_scaled_mm(*args).cpu()
+    monkeypatch.setenv("NMV_MM_WIDE", "1")
+    outs = [ops.cutlass_scaled_mm(*args).cpu()]
+    for nt, splits in ((1, 1), (2, 2), (4, 1), (4, 4), (1, 8)):
+        monkeypatch.setenv("NMV_MM_NT", str(nt))
+        monkeypatch.setenv("NMV_MM_SPLITS", str(splits))
+        outs.append(ops.cutlass_scaled_mm(*args).cpu())
+    ref = oracle.scaled_mm(a, bt.t(), sa, sb, torch.bfloat16, bias)
+    for i, o in enumerate(outs):
+        if kind == "int8":
+            assert torch.equal(old.view(torch.int16), o.view(torch.int16)), i
+        assert torch.allclose(o.float(), ref.float(), rtol=2**-7 * 1.01, atol=1e-3 if kind == "int8" else 2e-2), i
+
+
 # ---------------------------------------------------------------------------------------------
 # against fixtures produced by the REFERENCE's own code (tools/make_golden_w8a8.py): its test helpers'
 # inputs + baseline_scaled_mm outputs, its int8-quant test's expected tensors, per_tensor_quantize
