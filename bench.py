@@ -198,6 +198,67 @@ def gemm_roofline(runner, batch, dev, groups=32):
             "reference_op": ref_op}
 
 
+MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA
+
+
+@torch.inference_mode()
+def prefill_gemm_roofline(runner, prompt_len, dev, groups=8):
+    """the prompt step's dominant kernels: the 4 W4A16 GEMMs of a decoder layer at M = prompt_len exactly as the model
+    issues them there (qkv / o / down leave fp32 slabs for the following launch when the layer defers, gate_up carries
+    silu * up), `groups` launch groups rotating over the layers' weights, one hipGraph, HIP events: MFMA-bound,
+    2 M N K flops per GEMM against the dense bf16 peak"""
+    layers = runner.model.model.layers
+
+    def mods_of(L):
+        return [L.self_attn.qkv_proj, L.self_attn.o_proj, L.mlp.gate_up_proj, L.mlp.down_proj]
+
+    mods = mods_of(layers[0])
+    xs = [torch.randn((prompt_len, m.input_size_per_partition), device=dev, dtype=runner.dtype) for m in mods]
+
+    def run(li, only=None):
+        for j, (m, x) in enumerate(zip(mods_of(layers[li % len(layers)]), xs)):
+            if only is not None and only != j:
+                continue
+            if getattr(m, "gate_up_interleaved", False):
+                m.quant_method.apply_silu_mul(m, x)
+            elif j != 2 and m.quant_method.can_defer(m, prompt_len):
+                m.quant_method.apply_partial(m, x)
+            else:
+                m.quant_method.apply(m, x)
+
+    def timed(only):
+        run(0, only)
+        torch.cuda.synchronize(dev)
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            run(0, only)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            for i in range(groups):
+                run(i, only)
+        graph.replay()
+        torch.cuda.synchronize(dev)
+        stream = torch.cuda.current_stream(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        graph.replay()
+        e1.record(stream)
+        torch.cuda.synchronize(dev)
+        return e0.elapsed_time(e1) / groups * 1e3  # us per group
+
+    flops = [2.0 * prompt_len * m.input_size_per_partition * m.output_size_per_partition for m in mods]
+    us = timed(None)
+    per = {nm: round(timed(j), 2) for j, nm in enumerate(("qkv_proj", "o_proj", "gate_up_proj", "down_proj"))}
+    achieved = sum(flops) / (us * 1e-6) / 1e12
+    return {"bound": "mfma", "kernel": "w4a16_prefill_kernel / w4a16_prefill_small_kernel on the MFMA-native tensor: the 4 GEMM launches "
+                                        f"of one decoder layer at M = {prompt_len} as the prompt step issues them",
+            "achieved": round(achieved, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
+            "flops_per_launch_group": int(sum(flops)), "avg_us_per_launch_group": round(us, 2), "per_gemm_us": per,
+            "timing": "HIP events around a hipGraph replay"}
+
+
 @torch.inference_mode()
 def ttft(runner, dev, prompt_len, runs=5):
     """p50 time to first token: one prompt of `prompt_len` tokens through the whole model (our
@@ -591,6 +652,8 @@ def main():
     if rank == 0 and world == 1 and not args.no_sweep:
         out["ttft_ms_p50"] = {"prompt_tokens": args.context, "batch": 1,
                               "value": ttft(runner, dev, args.context)}
+        if args.quant == "w4a16":
+            out["ttft_ms_p50"]["gemm_roofline"] = prefill_gemm_roofline(runner, args.context, dev)
     if rank == 0 and world == 1 and args.e2e:
         out["e2e"] = e2e_latency(runner, dev, prompt_len=args.context)
     if world == 1 and not args.no_sweep:
