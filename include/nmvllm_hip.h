@@ -186,6 +186,11 @@ int nmv_gptq_marlin_gemm_partial(float* slab, int64_t slab_bytes, const void* a,
 int nmv_fused_add_rms_norm_partial(void* out, const float* slab, int splits, void* residual,
                                    const void* weight, float epsilon, int num_tokens,
                                    int hidden_size, nmv_dtype_t dtype, void* stream);
+/* ... and with the slabs in the MODEL dtype, [splits, num_tokens, hidden_size] of 2-byte elements (mode 3 of
+ * nmv_w4_native_gemm: prompt-sized calls, where the slabs are most of the launch's bytes): summed in fp32, rounded once. */
+int nmv_fused_add_rms_norm_partial16(void* out, const void* slab, int splits, void* residual,
+                                     const void* weight, float epsilon, int num_tokens,
+                                     int hidden_size, nmv_dtype_t dtype, void* stream);
 /* rotary_embedding_and_cache whose qkv row is the slab sum of nmv_gptq_marlin_gemm_partial
  * (slab [splits, num_tokens, (heads + 2 kv_heads) * head_size] fp32): qkv_out receives the rounded
  * row with q / k rotated (neox style, rot_dim == head_size; cos_sin_cache [max_pos, head_size]); k / v
@@ -197,6 +202,14 @@ int nmv_rotary_embedding_and_cache_partial(const int64_t* positions, const float
                                            const int64_t* slot_mapping, int block_size,
                                            nmv_dtype_t dtype, nmv_kv_dtype_t kv_dtype, float kv_scale,
                                            void* stream);
+/* ... and with the slabs in the MODEL dtype (mode 3 of nmv_w4_native_gemm) */
+int nmv_rotary_embedding_and_cache_partial16(const int64_t* positions, const void* slab, int splits,
+                                             void* qkv_out, int num_tokens, int num_heads,
+                                             int num_kv_heads, int head_size, const void* cos_sin_cache,
+                                             void* key_cache, void* value_cache,
+                                             const int64_t* slot_mapping, int block_size,
+                                             nmv_dtype_t dtype, nmv_kv_dtype_t kv_dtype, float kv_scale,
+                                             void* stream);
 /* paged_attention_v1 / v2 whose query and new key / value are still the fp32 split-K slabs of the
  * qkv projection (slab [splits, num_seqs, (heads + 2 kv_heads) * head_size]): sum + round, neox
  * rotary embedding (rot_dim == head_size), the new token's k / v stored at slot_mapping[seq], then
@@ -444,6 +457,10 @@ int nmv_w4_native_prefill_plan(int size_m, int size_n, int size_k);
 int nmv_w4_native_gemm(void* c, const void* a, const int32_t* b_native, const void* b_scales, int32_t* workspace,
                        int64_t workspace_len, void* scratch, int64_t scratch_bytes, int size_m, int size_n,
                        int size_k, int num_groups, nmv_dtype_t dtype, int mode, void* stream);
+/* mode 3: as mode 2 (deferred reduction: `scratch` receives slab[splits][size_m][size_n], no ticket, no reduction) with
+ * the slabs in the MODEL dtype -- for the *_partial16 consumers.  Prompt-sized calls only: nmv_w4_native_gemm_slab16
+ * returns 1 when a call of these sizes supports it (its slab count is nmv_w4_native_gemm_splits). */
+int nmv_w4_native_gemm_slab16(int size_m, int size_n, int size_k);
 /* Calls of 17..64 rows (group 128) may run csrc/w4a16_ring.hip: loader waves fill an LDS ring by LDS-DMA, consumer waves
  * wait on per-slot words in LDS with bounded spins.  nmv_w4_ring_timeouts: workgroups that gave up on a slot since the
  * library was loaded (0 in a healthy process; their tiles are garbage); synchronises the device; -1 on a HIP error. */

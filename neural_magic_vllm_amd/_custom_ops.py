@@ -394,6 +394,11 @@ def w4_native_gemm_splits(size_m: int, size_n: int, size_k: int, num_groups: Opt
     return tb.w4_native_gemm_splits(size_m, size_n, size_k, num_groups)
 
 
+def w4_native_gemm_slab16(size_m: int, size_n: int, size_k: int) -> bool:
+    from neural_magic_vllm_amd import _torch_bindings as tb
+    return tb.w4_native_gemm_slab16(size_m, size_n, size_k)
+
+
 def w4_native_prefill_plan(size_m: int, size_n: int, size_k: int) -> bool:
     from neural_magic_vllm_amd import _torch_bindings as tb
     return tb.w4_native_prefill_plan(size_m, size_n, size_k)

@@ -28,7 +28,7 @@ class NmvError(RuntimeError):
 
 
 _lib: Optional[ctypes.CDLL] = None
-ABI_VERSION = 7   # nmv_abi_version() of the library this table describes (csrc/capi_common.hip)
+ABI_VERSION = 8   # nmv_abi_version() of the library this table describes (csrc/capi_common.hip)
 
 _P = c_void_p
 _I = c_int
@@ -61,7 +61,10 @@ SIGNATURES = {
     "nmv_gptq_marlin_gemm_partial_splits": (_I, [_I, _I, _I, _I]),
     "nmv_gptq_marlin_gemm_partial": (_I, [_P, _L, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "nmv_fused_add_rms_norm_partial": (_I, [_P, _P, _I, _P, _P, _F, _I, _I, _I, _P]),
+    "nmv_fused_add_rms_norm_partial16": (_I, [_P, _P, _I, _P, _P, _F, _I, _I, _I, _P]),
     "nmv_rotary_embedding_and_cache_partial": (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _I, _I,
+                                                    _F, _P]),
+    "nmv_rotary_embedding_and_cache_partial16": (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _I, _I,
                                                     _F, _P]),
     "nmv_ar_handle_bytes": (_I, []),
     "nmv_ar_create": (_I, [_P, _I, _I, _L, _P]),
@@ -80,6 +83,7 @@ SIGNATURES = {
     "nmv_w4_ring_timeouts": (_I, []),
     "nmv_prefetch_l3": (_I, [_P, _L, _I, _P]),
     "nmv_w4_native_prefill_plan": (_I, [_I, _I, _I]),
+    "nmv_w4_native_gemm_slab16": (_I, [_I, _I, _I]),
     "nmv_car_meta_size": (_L, []),
     "nmv_car_meta_alloc": (_I, [_L, _P, _P]),
     "nmv_car_meta_free": (_I, [_P]),

@@ -716,8 +716,14 @@ def w4_native_prefill_plan(size_m, size_n, size_k) -> bool:
     return bool(_lib.load().nmv_w4_native_prefill_plan(size_m, size_n, size_k))
 
 
+def w4_native_gemm_slab16(size_m, size_n, size_k) -> bool:
+    """does w4_native_gemm mode 3 (deferred reduction, slabs in the model dtype) exist for a call of these sizes"""
+    return bool(_lib.load().nmv_w4_native_gemm_slab16(size_m, size_n, size_k))
+
+
 def w4_native_gemm(a, b_native, scales, workspace, size_m, size_n, size_k, mode=0) -> torch.Tensor:
-    """mode 0: [M, N]; 1: silu(gate) * up -> [M, N/2]; 2: fp32 split-K slabs [splits, M, N] (deferred reduction)"""
+    """mode 0: [M, N]; 1: silu(gate) * up -> [M, N/2]; 2: fp32 split-K slabs [splits, M, N] (deferred reduction);
+    3: the same slabs in the model dtype (prompt-sized calls: w4_native_gemm_slab16)"""
     _req(a.is_contiguous() and a.shape == (size_m, size_k) and a.dtype in (torch.float16, torch.bfloat16),
          "w4_native_gemm: a must be contiguous fp16 / bf16 [M, K]")
     _req(b_native.dtype == torch.int32 and b_native.numel() == size_k // 8 * size_n, "w4_native_gemm: b is not a native tensor")
@@ -725,11 +731,11 @@ def w4_native_gemm(a, b_native, scales, workspace, size_m, size_n, size_k, mode=
          "w4_native_gemm: scales must be the natural [groups, N] tensor in A's dtype")
     L = _lib.load()
     dev = a.device
-    if mode == 2:
+    if mode in (2, 3):
         splits = L.nmv_w4_native_gemm_splits(size_m, size_n, size_k, scales.shape[0])
         _req(splits >= 1, "w4_native_gemm: shape not supported")
-        out = torch.empty((splits, size_m, size_n), dtype=torch.float32, device=dev)
-        scratch, nbytes, c = out, out.numel() * 4, None
+        out = torch.empty((splits, size_m, size_n), dtype=torch.float32 if mode == 2 else a.dtype, device=dev)
+        scratch, nbytes, c = out, out.numel() * out.element_size(), None
     else:
         c = torch.empty((size_m, size_n // 2 if mode == 1 else size_n), dtype=a.dtype, device=dev)
         nbytes = 0 if mode == 1 else int(L.nmv_gptq_marlin_gemm_scratch_bytes(size_m, size_n, size_k, 0))
@@ -771,12 +777,15 @@ def gptq_marlin_gemm_partial(a, b_q_weight, b_scales, size_m, size_n, size_k) ->
 
 def fused_add_rms_norm_partial(slab, residual, weight, epsilon) -> torch.Tensor:
     """residual += round(sum of the slabs); returns rms_norm(residual) * weight"""
-    _req(slab.dim() == 3 and slab.dtype == torch.float32 and slab.is_contiguous(), "norm_partial: slab [S, T, H] fp32")
+    _req(slab.dim() == 3 and slab.dtype in (torch.float32, residual.dtype) and slab.is_contiguous(),
+         "norm_partial: slab [S, T, H] fp32, or in the model dtype")
     _req(residual.is_contiguous() and residual.shape[-1] == slab.shape[2]
          and residual.numel() == slab.shape[1] * slab.shape[2], "norm_partial: residual shape")
     out = torch.empty_like(residual)
+    lib = _lib.load()
+    fn = lib.nmv_fused_add_rms_norm_partial if slab.dtype == torch.float32 else lib.nmv_fused_add_rms_norm_partial16
     with device_guard(residual):
-        check(_lib.load().nmv_fused_add_rms_norm_partial(
+        check(fn(
             ptr(out), ptr(slab), slab.shape[0], ptr(residual), ptr(weight), epsilon, slab.shape[1],
             slab.shape[2], dtype_code(residual.dtype), stream_of(residual)))
     return out
@@ -787,7 +796,8 @@ def rotary_embedding_and_cache_partial(positions, slab, num_heads, num_kv_heads,
                                        dtype) -> torch.Tensor:
     """qkv = round(sum of the split-K slabs); neox rope on q / k; k / v -> paged cache (skipped when
     key_cache is None); returns the rounded, rotated qkv row [T, (heads + 2 kv_heads) * head_size]"""
-    _req(slab.dim() == 3 and slab.dtype == torch.float32 and slab.is_contiguous(), "rope_partial: slab [S, T, N] fp32")
+    _req(slab.dim() == 3 and slab.dtype in (torch.float32, dtype) and slab.is_contiguous(),
+         "rope_partial: slab [S, T, N] fp32, or in the model dtype")
     s_, t, n = slab.shape
     _req(n == (num_heads + 2 * num_kv_heads) * head_size, "rope_partial: slab width != qkv width")
     _req(positions.dtype == torch.int64 and positions.numel() == t, "positions must be int64 [T]")
@@ -800,8 +810,10 @@ def rotary_embedding_and_cache_partial(positions, slab, num_heads, num_kv_heads,
         _req(key_cache.is_contiguous() and value_cache.is_contiguous(), "caches must be contiguous")
         _req(key_cache.shape[1] == num_kv_heads and value_cache.shape[1] == num_kv_heads, "cache kv-head count")
         block_size = key_cache.shape[3]
+    lib = _lib.load()
+    fn = lib.nmv_rotary_embedding_and_cache_partial if slab.dtype == torch.float32 else lib.nmv_rotary_embedding_and_cache_partial16
     with device_guard(slab):
-        check(_lib.load().nmv_rotary_embedding_and_cache_partial(
+        check(fn(
             ptr(positions), ptr(slab), s_, ptr(out), t, num_heads, num_kv_heads, head_size,
             ptr(cos_sin_cache), ptr(key_cache), ptr(value_cache), ptr(slot_mapping), block_size,
             dtype_code(dtype), kv_dtype_code(kv_cache_dtype), kv_scale, stream_of(slab)))

@@ -25,7 +25,7 @@ void append_error(const char* fmt, ...) {
 
 extern "C" const char* nmv_last_error(void) { return nmv::g_err; }
 // 2: nmv_gptq_marlin_gemm_partial_splits takes num_groups; round-2 signature changes of the attention / fp8-marlin entry points
-extern "C" int nmv_abi_version(void) { return 7; }
+extern "C" int nmv_abi_version(void) { return 8; }
 
 extern "C" int64_t nmv_get_device_attribute(int64_t attribute, int64_t device_id) {
   int device = (int)device_id, value = 0;

@@ -172,11 +172,21 @@ __global__ __launch_bounds__(THREADS) void rms_norm_reg_kernel(void* out_v, uint
     w[i] = ld16(weight + vc * 8);
     if constexpr (SLABS) {
       f32x4_t lo4 = {0.f, 0.f, 0.f, 0.f}, hi4 = {0.f, 0.f, 0.f, 0.f};
-      const float* src = slab + row + vc * 8;
+      if (splits < 0) {   // uniform: -splits slabs in the MODEL dtype (the prompt-sized GEMM's mode 3), summed in fp32
+        const uint16_t* src = reinterpret_cast<const uint16_t*>(slab) + row + vc * 8;
 #pragma unroll 4
-      for (int sp = 0; sp < splits; ++sp) {
-        lo4 += *reinterpret_cast<const f32x4_t*>(src + sp * slab_stride);
-        hi4 += *reinterpret_cast<const f32x4_t*>(src + sp * slab_stride + 4);
+        for (int sp = 0; sp < -splits; ++sp) {
+          const uint4 x = ld16(src + sp * slab_stride);
+          lo4[0] += lo_f<T>(x.x), lo4[1] += hi_f<T>(x.x), lo4[2] += lo_f<T>(x.y), lo4[3] += hi_f<T>(x.y);
+          hi4[0] += lo_f<T>(x.z), hi4[1] += hi_f<T>(x.z), hi4[2] += lo_f<T>(x.w), hi4[3] += hi_f<T>(x.w);
+        }
+      } else {
+        const float* src = slab + row + vc * 8;
+#pragma unroll 4
+        for (int sp = 0; sp < splits; ++sp) {
+          lo4 += *reinterpret_cast<const f32x4_t*>(src + sp * slab_stride);
+          hi4 += *reinterpret_cast<const f32x4_t*>(src + sp * slab_stride + 4);
+        }
       }
       xs[i][0] = T::pack2(lo4[0], lo4[1]), xs[i][1] = T::pack2(lo4[2], lo4[3]);
       xs[i][2] = T::pack2(hi4[0], hi4[1]), xs[i][3] = T::pack2(hi4[2], hi4[3]);
@@ -425,9 +435,18 @@ __global__ __launch_bounds__(256) void rope_and_cache_slab_kernel(
   uint16_t* dst_row = qkv_out + (int64_t)token_idx * row_elems;
   auto slab_sum4 = [&](int col, float (&o)[4]) {
     f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+    if (splits < 0) {   // uniform: -splits slabs in the MODEL dtype (the prompt-sized GEMM's mode 3)
+      const uint16_t* src16 = reinterpret_cast<const uint16_t*>(slab) + (int64_t)token_idx * row_elems + col;
 #pragma unroll 4
-    for (int sp = 0; sp < splits; ++sp)
-      acc += *reinterpret_cast<const f32x4_t*>(src_row + sp * slab_stride + col);
+      for (int sp = 0; sp < -splits; ++sp) {
+        const uint2 x = *reinterpret_cast<const uint2*>(src16 + sp * slab_stride);
+        acc[0] += lo_f<T>(x.x), acc[1] += hi_f<T>(x.x), acc[2] += lo_f<T>(x.y), acc[3] += hi_f<T>(x.y);
+      }
+    } else {
+#pragma unroll 4
+      for (int sp = 0; sp < splits; ++sp)
+        acc += *reinterpret_cast<const f32x4_t*>(src_row + sp * slab_stride + col);
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) o[i] = rnd<T>(acc[i]);  // the GEMM's output rounding
   };
@@ -692,9 +711,9 @@ extern "C" int nmv_rms_norm_dynamic_int8_quant(void* out_q, float* scales, const
   return NMV_OK;
 }
 
-extern "C" int nmv_fused_add_rms_norm_partial(void* out, const float* slab, int splits, void* residual,
-                                              const void* weight, float epsilon, int num_tokens,
-                                              int hidden_size, nmv_dtype_t dtype, void* stream) {
+static int fused_add_rms_norm_partial_impl(void* out, const float* slab, int splits, bool slab16, void* residual,
+                                           const void* weight, float epsilon, int num_tokens,
+                                           int hidden_size, nmv_dtype_t dtype, void* stream) {
   NMV_HALF_ONLY("fused_add_rms_norm_partial");
   NMV_CHECK(splits >= 1 && residual != nullptr && slab != nullptr, "fused_add_rms_norm_partial: bad arguments");
   NMV_CHECK(hidden_size % 8 == 0 && hidden_size <= 8192 &&
@@ -710,7 +729,7 @@ extern "C" int nmv_fused_add_rms_norm_partial(void* out, const float* slab, int 
 #define RMS_SLAB(T, TH_)                                                                               \
   hipLaunchKernelGGL((rms_norm_reg_kernel<T, true, 1, false, true, TH_>), grid, dim3(TH_), 0, s, out,  \
                      (uint16_t*)nullptr, (uint16_t*)residual, (const uint16_t*)weight,                 \
-                     (float*)nullptr, epsilon, hidden_size, slab, splits, stride)
+                     (float*)nullptr, epsilon, hidden_size, slab, slab16 ? -splits : splits, stride)
   if (dtype == NMV_F16) {
     if (vecs <= 256) RMS_SLAB(F16, 256); else if (vecs <= 512) RMS_SLAB(F16, 512); else RMS_SLAB(F16, 1024);
   } else {
@@ -719,6 +738,22 @@ extern "C" int nmv_fused_add_rms_norm_partial(void* out, const float* slab, int 
 #undef RMS_SLAB
   NMV_LAUNCH_CHECK();
   return NMV_OK;
+}
+
+extern "C" int nmv_fused_add_rms_norm_partial(void* out, const float* slab, int splits, void* residual,
+                                              const void* weight, float epsilon, int num_tokens,
+                                              int hidden_size, nmv_dtype_t dtype, void* stream) {
+  return fused_add_rms_norm_partial_impl(out, slab, splits, false, residual, weight, epsilon, num_tokens, hidden_size, dtype,
+                                         stream);
+}
+
+// the same with the slabs in the model dtype, [splits][num_tokens][hidden_size] of 2-byte elements (mode 3 of
+// nmv_w4_native_gemm): summed in fp32 in split order, rounded once
+extern "C" int nmv_fused_add_rms_norm_partial16(void* out, const void* slab, int splits, void* residual,
+                                                const void* weight, float epsilon, int num_tokens,
+                                                int hidden_size, nmv_dtype_t dtype, void* stream) {
+  return fused_add_rms_norm_partial_impl(out, (const float*)slab, splits, true, residual, weight, epsilon, num_tokens,
+                                         hidden_size, dtype, stream);
 }
 
 extern "C" int nmv_silu_and_mul_dynamic_int8_quant(void* out_q, float* scales, const void* input,
@@ -831,8 +866,8 @@ extern "C" int nmv_rotary_embedding_and_cache(const int64_t* positions, void* qu
   return NMV_OK;
 }
 
-extern "C" int nmv_rotary_embedding_and_cache_partial(const int64_t* positions, const float* slab,
-                                                      int splits, void* qkv_out, int num_tokens,
+static int rotary_embedding_and_cache_partial_impl(const int64_t* positions, const float* slab,
+                                                   int splits, bool slab16, void* qkv_out, int num_tokens,
                                                       int num_heads, int num_kv_heads, int head_size,
                                                       const void* cos_sin_cache, void* key_cache,
                                                       void* value_cache, const int64_t* slot_mapping,
@@ -855,7 +890,7 @@ extern "C" int nmv_rotary_embedding_and_cache_partial(const int64_t* positions, 
   hipStream_t s = (hipStream_t)stream;
 #define LAUNCH_RS(T, FP8)                                                                          \
   hipLaunchKernelGGL((rope_and_cache_slab_kernel<T, FP8>), grid, block, 0, s, positions, slab,     \
-                     splits, stride, (uint16_t*)qkv_out, (const uint16_t*)cos_sin_cache, num_heads, \
+                     slab16 ? -splits : splits, stride, (uint16_t*)qkv_out, (const uint16_t*)cos_sin_cache, num_heads, \
                      num_kv_heads, head_size, key_cache, value_cache, slot_mapping, block_size,    \
                      kv_scale)
   if (dtype == NMV_F16) {
@@ -866,6 +901,33 @@ extern "C" int nmv_rotary_embedding_and_cache_partial(const int64_t* positions, 
 #undef LAUNCH_RS
   NMV_LAUNCH_CHECK();
   return NMV_OK;
+}
+
+extern "C" int nmv_rotary_embedding_and_cache_partial(const int64_t* positions, const float* slab,
+                                                      int splits, void* qkv_out, int num_tokens,
+                                                      int num_heads, int num_kv_heads, int head_size,
+                                                      const void* cos_sin_cache, void* key_cache,
+                                                      void* value_cache, const int64_t* slot_mapping,
+                                                      int block_size, nmv_dtype_t dtype,
+                                                      nmv_kv_dtype_t kv_dtype, float kv_scale,
+                                                      void* stream) {
+  return rotary_embedding_and_cache_partial_impl(positions, slab, splits, false, qkv_out, num_tokens, num_heads, num_kv_heads,
+                                                 head_size, cos_sin_cache, key_cache, value_cache, slot_mapping, block_size,
+                                                 dtype, kv_dtype, kv_scale, stream);
+}
+
+// the same with the slabs in the model dtype (mode 3 of nmv_w4_native_gemm)
+extern "C" int nmv_rotary_embedding_and_cache_partial16(const int64_t* positions, const void* slab,
+                                                        int splits, void* qkv_out, int num_tokens,
+                                                        int num_heads, int num_kv_heads, int head_size,
+                                                        const void* cos_sin_cache, void* key_cache,
+                                                        void* value_cache, const int64_t* slot_mapping,
+                                                        int block_size, nmv_dtype_t dtype,
+                                                        nmv_kv_dtype_t kv_dtype, float kv_scale,
+                                                        void* stream) {
+  return rotary_embedding_and_cache_partial_impl(positions, (const float*)slab, splits, true, qkv_out, num_tokens, num_heads,
+                                                 num_kv_heads, head_size, cos_sin_cache, key_cache, value_cache, slot_mapping,
+                                                 block_size, dtype, kv_dtype, kv_scale, stream);
 }
 
 extern "C" int nmv_act_and_mul(void* out, const void* input, int num_tokens, int d, int act,

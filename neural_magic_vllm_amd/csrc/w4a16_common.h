@@ -106,6 +106,9 @@ struct GemmParams {
   // w4a16_stream_kernel only (w4a16_stream.hip): k_per_wg = (k groups of the workgroup) * n_stages * g_stage * 128
   int g_stage;            // 128-k scale groups per activation stage and k group
   int n_stages;           // activation stages (1 = the whole k range of the workgroup stays in LDS)
+  // w4a16_prefill.hip only, with epi == 2: the slabs are written in the MODEL dtype (slab[splits][M][N] of 2-byte
+  // elements) -- half the bytes the consumer launch has to read back at prompt size
+  int slab16;
 };
 
 

@@ -1446,7 +1446,7 @@ static int marlin_gemm_impl(void* c, const void* a, const int32_t* b_q_weight, c
                             int32_t* workspace, int64_t workspace_len, void* scratch,
                             int64_t scratch_bytes, int num_bits, int size_m, int size_n, int size_k,
                             int num_groups, int is_k_full, nmv_dtype_t dtype, void* stream,
-                            int epi = 0, int native = 0, int fp8 = 0) {
+                            int epi = 0, int native = 0, int fp8 = 0, int slab16 = 0) {
   // `workspace` (the reference's lock array, zero on entry and exit) holds the split-K tickets
   NMV_CHECK(dtype == NMV_F16 || dtype == NMV_BF16,
             "gpt_marlin_gemm only supports bfloat16 and float16");
@@ -1491,7 +1491,7 @@ static int marlin_gemm_impl(void* c, const void* a, const int32_t* b_q_weight, c
     W4PrefillPlan pp;
     if (w4p_make_plan(size_m, size_n, size_k, epi == 2 ? INT64_MAX : (workspace ? workspace_len : 0), epi == 1, &pp) &&
         (epi != 1 || (pp.splits == 1 && size_n % 128 == 0))) {
-      const int64_t need = (pp.splits > 1 || epi == 2) ? (int64_t)pp.splits * size_m * size_n * 4 : 0;
+      const int64_t need = (pp.splits > 1 || epi == 2) ? (int64_t)pp.splits * size_m * size_n * (slab16 ? 2 : 4) : 0;
       NMV_CHECK(need < (int64_t)1 << 31, "w4_native_gemm: split-K slab too large");
       NMV_CHECK(scratch_bytes >= need && (need == 0 || scratch != nullptr),
                 "w4_native_gemm: scratch too small (%lld < %lld)", (long long)scratch_bytes, (long long)need);
@@ -1514,12 +1514,15 @@ static int marlin_gemm_impl(void* c, const void* a, const int32_t* b_q_weight, c
       p.epi = epi;
       p.g_stage = 0;
       p.n_stages = 0;
+      p.slab16 = slab16;
       const int rc = w4p_launch(pp, p, dtype == NMV_F16, (hipStream_t)stream);
       NMV_CHECK(rc == 0, "w4_native_gemm: prefill kernel launch failed for splits=%d (rc %d)", pp.splits, rc);
       NMV_LAUNCH_CHECK();
       return NMV_OK;
     }
   }
+  NMV_CHECK(!slab16, "w4_native_gemm: 16-bit slabs (mode 3) exist for prompt-sized calls of the prefill kernels only "
+                     "(nmv_w4_native_gemm_slab16)");
   // 17..64 rows on the native tensor: loader / consumer waves over an LDS-DMA ring (w4a16_ring.hip)
   if (native && num_bits == 4 && !has_act_order && group_size == 128 && b_zeros == nullptr) {
     W4RingPlan rp;
@@ -1548,6 +1551,7 @@ static int marlin_gemm_impl(void* c, const void* a, const int32_t* b_q_weight, c
       p.epi = epi;
       p.g_stage = 0;
       p.n_stages = 0;
+      p.slab16 = 0;
       const int rc = w4r_launch(rp, p, dtype == NMV_F16, (hipStream_t)stream);
       NMV_CHECK(rc == 0, "w4_native_gemm: ring kernel launch failed for mt=%d splits=%d (rc %d)", rp.mt, rp.splits, rc);
       NMV_LAUNCH_CHECK();
@@ -1582,6 +1586,7 @@ static int marlin_gemm_impl(void* c, const void* a, const int32_t* b_q_weight, c
       p.epi = epi;
       p.g_stage = sp.g_stage;
       p.n_stages = sp.n_stages;
+      p.slab16 = 0;
       const int rc = w4s_launch(sp, p, dtype == NMV_F16, (hipStream_t)stream);
       NMV_CHECK(rc == 0, "gptq_marlin_gemm: no stream kernel for plan mt=%d nw=%d cpw=%d d=%d gst=%d (rc %d)", sp.mt,
                 sp.nw, sp.cpw, sp.d, sp.gst, rc);
@@ -1628,6 +1633,7 @@ static int marlin_gemm_impl(void* c, const void* a, const int32_t* b_q_weight, c
   p.epi = epi;
   p.native = native;
   p.fp8 = fp8;
+  p.slab16 = 0;
   hipStream_t s = (hipStream_t)stream;
   const int rc = dtype == NMV_F16 ? launch_gemm<F16>(pl, p, s) : launch_gemm<BF16>(pl, p, s);
   NMV_CHECK(rc == 0, "gptq_marlin_gemm: no kernel for plan mt=%d wn=%d wm=%d wk=%d", pl.mt, pl.wn,
@@ -1777,8 +1783,17 @@ extern "C" int nmv_w4_native_gemm(void* c, const void* a, const int32_t* b_nativ
                                   int32_t* workspace, int64_t workspace_len, void* scratch, int64_t scratch_bytes,
                                   int size_m, int size_n, int size_k, int num_groups, nmv_dtype_t dtype, int mode,
                                   void* stream) {
-  NMV_CHECK(mode >= 0 && mode <= 2, "w4_native_gemm: mode must be 0, 1 or 2");
-  return marlin_gemm_impl(c, a, b_native, b_scales, nullptr, nullptr, nullptr, mode == 2 ? nullptr : workspace,
-                          mode == 2 ? 0 : workspace_len, scratch, scratch_bytes, 4, size_m, size_n, size_k, num_groups, 1,
-                          dtype, stream, mode, 1);
+  NMV_CHECK(mode >= 0 && mode <= 3, "w4_native_gemm: mode must be 0, 1, 2 or 3");
+  const bool deferred = mode >= 2;
+  return marlin_gemm_impl(c, a, b_native, b_scales, nullptr, nullptr, nullptr, deferred ? nullptr : workspace,
+                          deferred ? 0 : workspace_len, scratch, scratch_bytes, 4, size_m, size_n, size_k, num_groups, 1,
+                          dtype, stream, deferred ? 2 : mode, 1, 0, mode == 3 ? 1 : 0);
+}
+
+/* mode 3 of nmv_w4_native_gemm -- deferred reduction with the slabs in the MODEL dtype, slab[splits][M][N] of 2-byte
+ * elements, for nmv_fused_add_rms_norm_partial16 / nmv_rotary_embedding_and_cache_partial16 to sum -- is served by the
+ * prompt-sized kernels only: 1 when a call of these sizes takes them (then nmv_w4_native_gemm_splits is its slab count). */
+extern "C" int nmv_w4_native_gemm_slab16(int size_m, int size_n, int size_k) {
+  W4PrefillPlan pp;
+  return (size_m > 0 && size_n > 0 && size_k > 0 && w4p_make_plan(size_m, size_n, size_k, INT64_MAX, false, &pp)) ? 1 : 0;
 }

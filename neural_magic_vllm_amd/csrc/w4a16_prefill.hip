@@ -423,7 +423,7 @@ __global__ __launch_bounds__(PF_NTHR, 2) void w4a16_prefill_kernel(const GemmPar
   }
   // split-K across workgroups: write-through fp32 slabs, ticket, the last workgroup of the tile sums them in split order
   // (w4a16_common.h); deferred mode (epi 2) leaves the slabs to the consumer
-  const int64_t slab_bytes = (int64_t)p.splits * p.M * p.N * 4;
+  const int64_t slab_bytes = (int64_t)p.splits * p.M * p.N * (p.slab16 ? 2 : 4);
   __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p.slab, 0, (int)slab_bytes, 0x00020000);
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -435,8 +435,9 @@ __global__ __launch_bounds__(PF_NTHR, 2) void w4a16_prefill_kernel(const GemmPar
       for (int r = 0; r < 16; ++r) {
         const int row = row_l + 32 * i + (r & 3) + 8 * (r >> 2);
         if (row >= p.M) continue;
-        const int off = (int)((((int64_t)split * p.M + row) * p.N + col) * 4);
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[i][j][r]), rs, off, 0, 16);
+        const int64_t elem = ((int64_t)split * p.M + row) * p.N + col;
+        if (p.slab16) __builtin_amdgcn_raw_buffer_store_b16(T::from_float(acc[i][j][r]), rs, (int)(elem * 2), 0, 16);
+        else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[i][j][r]), rs, (int)(elem * 4), 0, 16);
       }
   }
   if (p.epi == 2) return;
@@ -691,7 +692,7 @@ __global__ __launch_bounds__(PF_NTHR, 2) void w4a16_prefill_small_kernel(const G
     }
     return;
   }
-  const int64_t slab_bytes = (int64_t)p.splits * p.M * p.N * 4;
+  const int64_t slab_bytes = (int64_t)p.splits * p.M * p.N * (p.slab16 ? 2 : 4);
   __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p.slab, 0, (int)slab_bytes, 0x00020000);
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
@@ -701,8 +702,9 @@ __global__ __launch_bounds__(PF_NTHR, 2) void w4a16_prefill_small_kernel(const G
     for (int r = 0; r < 16; ++r) {
       const int row = row_l + (r & 3) + 8 * (r >> 2);
       if (row >= p.M) continue;
-      const int off = (int)((((int64_t)split * p.M + row) * p.N + col) * 4);
-      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[j][r]), rs, off, 0, 16);
+      const int64_t elem = ((int64_t)split * p.M + row) * p.N + col;
+      if (p.slab16) __builtin_amdgcn_raw_buffer_store_b16(T::from_float(acc[j][r]), rs, (int)(elem * 2), 0, 16);
+      else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[j][r]), rs, (int)(elem * 4), 0, 16);
     }
   }
   if (p.epi == 2) return;

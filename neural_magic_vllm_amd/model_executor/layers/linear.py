@@ -196,10 +196,11 @@ class ColumnParallelLinear(LinearBase):
         width = self.output_size_per_partition
         _place(param, loaded_weight, _Shard(None, 0, 0, width, 0, self.output_size, get_tensor_model_parallel_rank()))
 
-    def forward_partial(self, input_):
+    def forward_partial(self, input_, allow16: bool = False):
         """Deferred split-K (not in the reference): the fp32 slabs [splits, T, N_partition] of X A for
         a consumer that sums them (ops.rotary_embedding_and_cache_partial), or None when this layer
-        cannot defer (bias, gathered output, quantisation method / shape without the partial GEMM)."""
+        cannot defer (bias, gathered output, quantisation method / shape without the partial GEMM).
+        allow16: the consumer also reads slabs in the model dtype (prompt steps: LinearMethod.apply_partial)."""
         qm = self.quant_method
         if self.bias is not None or self.gather_output or not hasattr(qm, "apply_partial") \
                 or not isinstance(input_, torch.Tensor) or not input_.is_cuda or not qm.can_defer_reduce(self):
@@ -207,7 +208,7 @@ class ColumnParallelLinear(LinearBase):
         rows = input_.numel() // input_.shape[-1]
         if not _method_can_defer(qm, self, rows, self.output_size_per_partition, self.input_size):
             return None
-        return qm.apply_partial(self, input_)
+        return qm.apply_partial(self, input_, allow16) if allow16 else qm.apply_partial(self, input_)
 
     def forward(self, input_):
         fused_bias, returned_bias = self._split_bias()
@@ -313,11 +314,12 @@ class RowParallelLinear(LinearBase):
             loaded_weight = loaded_weight.narrow(axis, get_tensor_model_parallel_rank() * rows, rows)
         _copy_checked(param.data, loaded_weight)
 
-    def forward_partial(self, input_):
+    def forward_partial(self, input_, allow16: bool = False):
         """Deferred split-K (not in the reference): the fp32 slabs [splits, T, N] of X A, for a
         consumer that sums them (ops.fused_add_rms_norm_partial), or None when this layer cannot
         defer -- a result that still has to be all-reduced or biased, or a quantisation method /
-        shape without the partial GEMM."""
+        shape without the partial GEMM.  allow16: the consumer also reads slabs in the model dtype (the norm launch does;
+        the all-reduce of a tensor-parallel group does not)."""
         if not self._can_defer(input_):
             return None
         if self.tp_size > 1:
@@ -327,6 +329,8 @@ class RowParallelLinear(LinearBase):
             rows = input_.numel() // input_.shape[-1]
             if not self.reduce_results or car is None or not car.can_reduce(rows * self.output_size):
                 return None
+        if allow16 and self.tp_size == 1:
+            return self.quant_method.apply_partial(self, input_, True)
         return self.quant_method.apply_partial(self, input_)
 
     def _can_defer(self, input_) -> bool:

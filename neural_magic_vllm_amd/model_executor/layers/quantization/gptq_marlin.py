@@ -327,14 +327,19 @@ class GPTQMarlinLinearMethod(LinearMethodBase):
             return ops.w4_native_gemm_splits(rows, n, k, groups) >= 1
         return ops.gptq_marlin_gemm_partial_splits(rows, n, k, groups) >= 1
 
-    def apply_partial(self, layer: torch.nn.Module, x: torch.Tensor) -> torch.Tensor:
+    def apply_partial(self, layer: torch.nn.Module, x: torch.Tensor, allow16: bool = False) -> torch.Tensor:
         """x @ W as fp32 split-K slabs [splits, T, N]; their sum in split order, rounded to the model dtype, is
-        bit-identical to apply()"""
+        bit-identical to apply().  allow16 (the caller's consumer reads slabs of either width: the norm and the rope +
+        cache launches): a prompt-sized call leaves its slabs in the MODEL dtype -- at 512 rows the slabs are a fifth of
+        the layer's bytes, and half of that is saved; each slab is rounded once before the fp32 sum (within the op's
+        tolerance, not bit-identical to apply())"""
         self._ready(layer)
         rows = x.reshape(-1, x.shape[-1])
         m, n, k = rows.shape[0], layer.output_size_per_partition, layer.input_size_per_partition
         if self._native(layer, m):
-            return ops.w4_native_gemm(rows, layer.qweight_native, layer.scales_native, None, m, n, k, mode=2)
+            mode = 3 if (allow16 and m > self.NATIVE_MAX_M and os.environ.get("NMV_W4_SLAB16", "1") != "0"
+                         and ops.w4_native_gemm_slab16(m, n, k)) else 2
+            return ops.w4_native_gemm(rows, layer.qweight_native, layer.scales_native, None, m, n, k, mode=mode)
         return ops.gptq_marlin_gemm_partial(rows, layer.qweight, layer.scales, m, n, k)
 
     # ---- gate_up with silu_and_mul in the GEMM's epilogue -----------------------------------------------------------

@@ -93,7 +93,7 @@ class LlamaMLP(nn.Module):
 
     def _down(self, x):
         if self.fused_glue and not isinstance(x, Int8Activations):
-            slab = self.down_proj.forward_partial(x)
+            slab = self.down_proj.forward_partial(x, allow16=True)
             if slab is not None:
                 return SplitKPartial(slab)   # summed by the next layer's input_layernorm
         x, _ = self.down_proj(x)
@@ -148,7 +148,10 @@ class LlamaAttention(nn.Module):
         if self.fused_glue and isinstance(hidden_states, torch.Tensor) and hidden_states.dim() == 2 \
                 and self.attn_prologue != "plain":
             # deferred split-K: the rope + cache launch sums the qkv projection's fp32 slabs
-            slab = self.qkv_proj.forward_partial(hidden_states)
+            # a prompt step's slabs go to the rope + cache launch, which also reads them in the model dtype; a decode
+            # step's go to the attention launch's prologue (fp32 only)
+            prompt_only = getattr(attn_metadata, "num_prefill_tokens", 0) > 0 and getattr(attn_metadata, "num_decode_tokens", 0) == 0
+            slab = self.qkv_proj.forward_partial(hidden_states, allow16=prompt_only)
             if slab is not None:
                 # decode-only batch: rope + cache write + paged attention in one launch
                 attn_output = None
@@ -181,7 +184,7 @@ class LlamaAttention(nn.Module):
 
     def _o(self, attn_output: torch.Tensor):
         if self.fused_glue:
-            slab = self.o_proj.forward_partial(attn_output)
+            slab = self.o_proj.forward_partial(attn_output, allow16=True)
             if slab is not None:
                 return SplitKPartial(slab)   # summed by post_attention_layernorm
         output, _ = self.o_proj(attn_output)

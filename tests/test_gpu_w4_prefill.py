@@ -143,3 +143,49 @@ def test_prefill_gemm_rows_past_m_do_not_leak(gpu_device, prefill):
     out = ops.w4_native_gemm(big_a[:m], b, s.to(d), ws, m, n, k, 0)
     assert torch.isfinite(out.float()).all()
     assert rel_err(out.cpu(), (a[:m].double() @ w_ref.double()).float()) < 6e-3
+
+
+@pytest.mark.parametrize("dtype", [torch.half, torch.bfloat16])
+@pytest.mark.parametrize("m,k,n", [(100, 512, 448), (512, 4096, 1024), (300, 1024, 6144)])
+def test_prefill_gemm_slabs_in_the_model_dtype(gpu_device, prefill, dtype, m, k, n):
+    """mode 3: the deferred slabs in the model dtype are the fp32 slabs of mode 2, each element rounded once"""
+    from neural_magic_vllm_amd import _custom_ops as ops
+    assert ops.w4_native_gemm_slab16(m, n, k) and not ops.w4_native_gemm_slab16(64, n, k)
+    a, q_w, s, w_ref = problem(31, m, k, n, dtype)
+    s32 = native_gemm(a, q_w, s, k, n, gpu_device, 2)
+    s16 = native_gemm(a, q_w, s, k, n, gpu_device, 3)
+    assert s16.dtype == dtype and s16.shape == s32.shape
+    assert torch.equal(s16.view(torch.int16), s32.to(dtype).view(torch.int16))
+    out = s16.float().sum(0)
+    assert rel_err(out.cpu(), (a.double() @ w_ref.double()).float()) < 6e-3
+
+
+@pytest.mark.parametrize("dtype", [torch.half, torch.bfloat16])
+def test_slab_consumers_read_model_dtype_slabs(gpu_device, dtype):
+    """the norm and the rope + cache launches on slabs in the model dtype: bit-identical to the same launches on fp32
+    slabs that hold the same (already rounded) values"""
+    from neural_magic_vllm_amd import _custom_ops as ops
+    d = gpu_device
+    g = torch.Generator().manual_seed(41)
+    splits, t, hidden = 5, 37, 4096
+    slab16 = (torch.randn((splits, t, hidden), generator=g) * 0.5).to(dtype).to(d)
+    res = torch.randn((t, hidden), generator=g).to(dtype).to(d)
+    w = torch.randn((hidden, ), generator=g).to(dtype).to(d)
+    r16, r32 = res.clone(), res.clone()
+    o16 = ops.fused_add_rms_norm_partial(slab16, r16, w, 1e-5)
+    o32 = ops.fused_add_rms_norm_partial(slab16.float(), r32, w, 1e-5)
+    assert torch.equal(o16.view(torch.int16), o32.view(torch.int16)) and torch.equal(r16.view(torch.int16), r32.view(torch.int16))
+    heads, kv_heads, hs, bs = 8, 2, 128, 16
+    nq = (heads + 2 * kv_heads) * hs
+    qkv16 = (torch.randn((3, t, nq), generator=g)).to(dtype).to(d)
+    pos = torch.randint(0, 500, (t, ), generator=g).to(d)
+    cos_sin = torch.randn((512, hs), generator=g).to(dtype).to(d)
+    slots = torch.randperm(8 * bs, generator=g)[:t].to(d)
+    outs = []
+    for sl in (qkv16, qkv16.float()):
+        kc = torch.zeros((8, kv_heads, hs // 8, bs, 8), dtype=dtype, device=d)
+        vc = torch.zeros((8, kv_heads, hs, bs), dtype=dtype, device=d)
+        q = ops.rotary_embedding_and_cache_partial(pos, sl, heads, kv_heads, hs, cos_sin, kc, vc, slots, "auto", 1.0, dtype)
+        outs.append((q, kc, vc))
+    for x, y in zip(outs[0], outs[1]):
+        assert torch.equal(x.view(torch.int16), y.view(torch.int16))
