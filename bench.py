@@ -222,7 +222,7 @@ def prefill_gemm_roofline(runner, prompt_len, dev, groups=8):
             if getattr(m, "gate_up_interleaved", False):
                 m.quant_method.apply_silu_mul(m, x)
             elif j != 2 and m.quant_method.can_defer(m, prompt_len):
-                m.quant_method.apply_partial(m, x)
+                m.quant_method.apply_partial(m, x, True)    # as LlamaAttention / LlamaMLP call it at tp = 1: slabs in the model dtype
             else:
                 m.quant_method.apply(m, x)
 
