@@ -362,6 +362,7 @@ __global__ __launch_bounds__(MM_THREADS) void scaled_mm_wide_kernel(const MMPara
 template <typename T, bool FP8>
 __global__ __launch_bounds__(256) void scaled_mm_reduce_kernel(const MMParams p) {
   using elem_t = typename std::conditional<FP8, float, int>::type;
+  typedef elem_t vec4_t __attribute__((ext_vector_type(4)));
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int n4 = (p.N + 3) / 4;
   if (idx >= (int64_t)p.M * n4) return;
@@ -370,14 +371,35 @@ __global__ __launch_bounds__(256) void scaled_mm_reduce_kernel(const MMParams p)
   const int64_t slab_stride = (int64_t)p.M * p.N;
   const float as = p.a_scales[p.a_per_row ? m : 0];
   uint16_t* dst = reinterpret_cast<uint16_t*>(p.out) + (int64_t)m * p.ldc + nb;
+  elem_t v[4] = {0, 0, 0, 0};
+  if (nb + 3 < p.N && (p.N & 3) == 0) {
+    // whole 16-byte vectors, the loads of up to 8 slabs in flight together (the launch is latency, not bytes); the
+    // additions stay in split order (fp8: the fp32 sum is the order-dependent one)
+    for (int s0 = 0; s0 < p.splits; s0 += 8) {
+      vec4_t q[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (s0 + u < p.splits) q[u] = *reinterpret_cast<const vec4_t*>(src + (s0 + u) * slab_stride);
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (s0 + u < p.splits) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] += q[u][i];
+        }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (nb + i >= p.N) break;
+      for (int s = 0; s < p.splits; ++s) v[i] += src[s * slab_stride + i];
+    }
+  }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     if (nb + i >= p.N) break;
-    elem_t v = 0;
-    for (int s = 0; s < p.splits; ++s) v += src[s * slab_stride + i];
     const float bs = p.b_scales[p.b_per_col ? nb + i : 0];
     const float bv = p.bias ? T::to_float(reinterpret_cast<const uint16_t*>(p.bias)[nb + i]) : 0.f;
-    const float tmp = bs * (float)v;
+    const float tmp = bs * (float)v[i];
     dst[i] = T::from_float(p.bias ? fmaf(as, tmp, bv) : as * tmp);
   }
 }
