@@ -10,12 +10,13 @@ Life of a layer
                    interchange tensor (in place, the parameter keeps its storage), `marlin_permute_scales`
   every call       `gptq_marlin_gemm` (csrc/w4a16_stream.hip up to 64 rows, csrc/w4a16_gemm.hip beyond)
 
-Beyond the reference's LinearMethod (used by the decode harness, each bit-identical to `apply` + the op it absorbs;
-DESIGN.md 3.2): `apply_partial` leaves the split-K reduction to the next launch, `apply_silu_mul` folds silu_and_mul
-into the gate_up GEMM's epilogue on column-interleaved weights, and an MFMA-native copy of the codes (group 128;
-kept beside the Marlin tensor unless NMV_W4_NATIVE=0: + 0.5 byte per weight) serves calls of up to 64 rows through
-csrc/w4a16_stream.hip's native form -- no lane exchange, no activation transpose; the Marlin tensor keeps the
-prompt-sized calls and the reference op `gptq_marlin_gemm`."""
+Beyond the reference's LinearMethod (used by the decode harness): `apply_partial` leaves the split-K
+reduction to the next launch, `apply_silu_mul` folds silu_and_mul into the gate_up GEMM's epilogue on column-interleaved
+weights, and for the prevalent format (4-bit symmetric, group 128, no act-order) the first call builds an MFMA-native
+tensor of the codes INSTEAD of the Marlin tensor (`nmv_w4_native_repack`; 0.5 byte per weight on the rank): every call of
+such a layer goes to `nmv_w4_native_gemm` -- csrc/w4a16_stream.hip / w4a16_ring.hip up to 64 rows, csrc/w4a16_prefill.hip
+beyond.  NMV_W4_KEEP_MARLIN=1 keeps both tensors and sends each prompt-sized call to the faster kernel; NMV_W4_NATIVE=0
+keeps the Marlin tensor only (the reference's layout, what the op `gptq_marlin_gemm` itself always takes)."""
 import enum
 import os
 from typing import Any, Dict, List, Optional
