@@ -93,3 +93,29 @@ def test_lds_optin_is_tracked_per_device():
     assert lib.w4r_dbg_lds_optin(ctypes.byref(mask), 1) == 0
     assert lib.w4r_dbg_lds_optin(ctypes.byref(mask), 7) == 1 and mask.value == 0b10000011
     assert lib.w4r_dbg_lds_optin(ctypes.byref(mask), 64) == 1 and lib.w4r_dbg_lds_optin(ctypes.byref(mask), 64) == 1   # untracked: always
+
+
+def test_prompt_sized_plans_are_host_logic_and_pinned():
+    """the planners run on the host (no GPU): the split counts and routing answers DESIGN.md 3.3 / 3.6 quote for the
+    Llama-3-8B projections -- a change of a planner constant shows up here before it shows up in a profile"""
+    from neural_magic_vllm_amd import _lib
+    L = _lib.load()
+    shapes = {"qkv": (6144, 4096), "o": (4096, 4096), "gate_up": (28672, 4096), "down": (4096, 14336)}
+
+    def splits(m, name):
+        n, k = shapes[name]
+        return L.nmv_w4_native_gemm_splits(m, n, k, k // 128)
+    # 512-token prompt step: the wide projection fills the chip with 224 large tiles and is never sliced; the narrow ones
+    # are sliced (qkv: 48 large tiles x 4, down: 32 x 8) or take the small tile (o_proj: 128 small tiles x 2)
+    assert [splits(512, nm) for nm in ("qkv", "o", "gate_up", "down")] == [4, 2, 1, 8]
+    assert splits(2048, "gate_up") == 1 and splits(4096, "down") == 1
+    # a holder of both tensors sends a prompt-sized call to the native tensor from 512 rows and 64 large tiles on
+    flags = {m: [L.nmv_w4_native_prefill_plan(m, *shapes[nm]) for nm in ("qkv", "o", "gate_up", "down")] for m in (256, 512, 1024)}
+    assert flags == {256: [0, 0, 0, 0], 512: [0, 0, 1, 0], 1024: [1, 1, 1, 1]}
+    # model-dtype slabs exist for prompt-sized calls only
+    assert L.nmv_w4_native_gemm_slab16(65, 4096, 4096) == 1 and L.nmv_w4_native_gemm_slab16(64, 4096, 4096) == 0
+    # W8A8 at 17..64 rows: gate_up unsliced at 64 rows and in two slices at 32, down in eight; qkv / o_proj and M <= 16 unsliced
+    assert L.nmv_scaled_mm_scratch_bytes(64, 28672, 4096) == 0
+    assert L.nmv_scaled_mm_scratch_bytes(32, 28672, 4096) == 2 * 32 * 28672 * 4
+    assert L.nmv_scaled_mm_scratch_bytes(64, 4096, 14336) == 8 * 64 * 4096 * 4
+    assert L.nmv_scaled_mm_scratch_bytes(64, 4096, 4096) == 0 and L.nmv_scaled_mm_scratch_bytes(16, 4096, 14336) == 0
